@@ -1,0 +1,257 @@
+"""Record golden vectors from the reference's OWN modules (build container only).
+
+    python tests/golden/make_golden.py [section ...]
+
+Imports /root/reference through tests/golden/_refload.py, fills the reference
+modules with the deterministic synthetic weights of tal_asrd_amd.synth, runs
+them on CPU fp32 and stores inputs/expected outputs as small .npz/.json
+fixtures next to this script.  The fixtures are data; no reference source is
+stored.  Sections: keys unit sd asr decode gru flow
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from tests.golden._refload import load_reference  # noqa: E402
+from tal_asrd_amd import synth  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def fill(module, prefix=""):
+    """Load synth weights into a reference module (keys optionally namespaced by `prefix`)."""
+    shapes = {prefix + k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = synth.fill_state_dict(shapes)
+    own = module.state_dict()
+    for k in own:
+        if prefix + k in sd:
+            own[k] = torch.from_numpy(sd[prefix + k].copy())
+    module.load_state_dict(own)
+    return module.eval()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def rows(n, k):
+    """k deterministic row indices in [0, n) including both ends."""
+    return np.unique(np.linspace(0, n - 1, k).round().astype(np.int64))
+
+
+def top2_margin(logits):
+    t = torch.topk(logits, 2, dim=-1).values
+    return (t[..., 0] - t[..., 1]).numpy()
+
+
+def sec_keys(ns):
+    out = {}
+    out["SDModel"] = [[k, list(v.shape)] for k, v in ns.models.SDModel().state_dict().items()]
+    m = ns.models.ASRModel("2x", num_speakers=6008, use_speaker_head=True)
+    out["ASRModel_2x_spk"] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    m = ns.models.ASRModel("1x", num_speakers=40, use_speaker_head=False)
+    out["ASRModel_1x_tok"] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    out["CoreRNN"] = [[k, list(v.shape)] for k, v in ns.uisrnn.CoreRNN(256, 512, 1, 256).state_dict().items()]
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote state_dict_keys.json")
+
+
+def sec_unit(ns):
+    M = ns.models
+    # small TDS
+    tds = fill(M.TDS(input_size=8, sizes=[8, 16, 24, 32], depths=[1, 1, 2], kernel_size=21), "tds_small.")
+    x = synth.synth_tensor("tds_small/x", (2, 8, 200), 1.0)
+    save("tds_small", x=x, y=tds(torch.from_numpy(x)).numpy())
+    # single TDSBlock
+    blk = fill(M.TDSBlock(32, 21, 8), "tdsblock.")
+    x = synth.synth_tensor("tdsblock/x", (2, 32, 50), 1.0)
+    save("tdsblock", x=x, y=blk(torch.from_numpy(x)).numpy())
+    # decoder layer, small
+    layer = fill(M.ModRZTXDecoderLayer(d_model=64, nhead=4, dim_feedforward=256), "declayer.")
+    tgt = synth.synth_tensor("declayer/tgt", (7, 2, 64), 1.0)
+    mem = synth.synth_tensor("declayer/mem", (13, 2, 64), 1.0)
+    causal = torch.triu(torch.ones(7, 7), 1)
+    causal = causal.masked_fill(causal == 1, float("-inf"))
+    kpm = np.zeros((2, 13), dtype=bool)
+    kpm[1, 9:] = True
+    res = {"tgt": tgt, "mem": mem, "kpm": kpm}
+    for tag, tm, km in (("plain", None, None), ("causal", causal, None),
+                        ("kpm", None, torch.from_numpy(kpm)), ("causal_kpm", causal, torch.from_numpy(kpm))):
+        y = layer(torch.from_numpy(tgt), torch.from_numpy(mem), tgt_mask=tm, memory_key_padding_mask=km)
+        res["y_" + tag] = y.numpy()
+        res["w_" + tag] = layer.src_attn_weights.numpy()
+    save("declayer_small", **res)
+    # positional encoding
+    pe = ns.modules.PositionalEncoding(64, max_len=32).eval()
+    x = synth.synth_tensor("posenc/x", (2, 5, 64), 1.0)
+    save("posenc", pe=pe.pe.numpy(), x=x, y=pe(torch.from_numpy(x)).numpy())
+
+
+def _sd_fixture(ns, name, audio, audio_lens=None, n_rows=8):
+    model = fill(ns.models.SDModel())
+    a = torch.from_numpy(audio)
+    mel = model.extract_features(a)
+    enc = model.encode_features(mel, None if audio_lens is None else torch.tensor(audio_lens))
+    eo = enc["encoder_out"]
+    feat = model.spk_embed_proj(eo)
+    logits = model.decode(enc)
+    ids = logits.argmax(-1)
+    B, Tp = ids.shape
+    r = rows(Tp, n_rows)
+    mr = rows(mel.shape[1], 16)
+    out = dict(
+        audio_seed=1234, audio_len=audio.shape[1], batch=B,
+        mel_rows=mr, mel_sample=mel[:, mr].numpy(), mel_sum=mel.double().sum(dim=(1, 2)).numpy(),
+        mel_abs_sum=mel.double().abs().sum(dim=(1, 2)).numpy(),
+        enc_rows=r, enc_sample=eo[:, r].numpy(), enc_chan_sum=eo.double().sum(dim=1).numpy(),
+        feat=feat.numpy().astype(np.float32),
+        logit_rows=r, logit_sample=logits[:, r].numpy(),
+        ids=ids.numpy().astype(np.int32), margin=top2_margin(logits).astype(np.float32),
+        logit_max=logits.max(-1).values.numpy(),
+    )
+    if audio_lens is not None:
+        out["audio_lens"] = np.asarray(audio_lens)
+        out["mask"] = enc["encoder_padding_mask"].numpy()
+    save(name, **out)
+
+
+def sec_sd(ns):
+    # config 1: 30 s clip, B=1 (whole-clip call as reconcile.get_speaker_ids does)
+    _sd_fixture(ns, "sd_30s", synth.synth_audio_batch(1, 480000, 1234))
+    # ragged B=2 call: global-mean coupling + padding mask
+    lens = [480000, 400000]
+    _sd_fixture(ns, "sd_b2_ragged", synth.synth_audio_batch(2, 480000, 1234, lens=lens), audio_lens=lens)
+    # config 2: 5 min clip
+    _sd_fixture(ns, "sd_5min", synth.synth_audio_batch(1, 4800000, 1234), n_rows=12)
+
+
+def _asr_model(ns):
+    return fill(ns.models.ASRModel("2x", num_speakers=6008, vocab_size=10000, use_speaker_head=True))
+
+
+def sec_asr(ns):
+    model = _asr_model(ns)
+    lens = [480000, 400000]
+    audio = synth.synth_audio_batch(2, 480000, 1234, lens=lens)
+    enc = model.encode(torch.from_numpy(audio), torch.tensor(lens))
+    r = rows(enc["encoder_out"].shape[1], 12)
+    save("asr_enc_b2", audio_lens=np.asarray(lens), rows=r,
+         encoder_out=enc["encoder_out"][:, r].numpy(), speaker_out=enc["speaker_out"][:, r].numpy(),
+         enc_sum=enc["encoder_out"].double().sum(dim=1).numpy(),
+         spk_sum=enc["speaker_out"].double().sum(dim=1).numpy(),
+         mask=enc["encoder_padding_mask"].numpy())
+
+
+def _tokens(name, B, U, vocab=10000):
+    u = synth.hash_uniform(name, B * U).astype(np.float64)
+    return np.minimum(((u + 1.0) * 0.5 * vocab).astype(np.int64), vocab - 1).reshape(B, U)
+
+
+def sec_decode(ns):
+    """Decoder fixtures: memory = first 357 encoder frames of the 30 s clip."""
+    model = _asr_model(ns)
+    audio = synth.synth_audio_batch(1, 480000, 1234)
+    enc = model.encode(torch.from_numpy(audio), torch.tensor([480000]))
+    S = 357
+    mem = {"encoder_out": enc["encoder_out"][:, :S].contiguous(),
+           "speaker_out": enc["speaker_out"][:, :S].contiguous(),
+           "encoder_padding_mask": enc["encoder_padding_mask"][:, :S].contiguous()}
+    out = {"S": S}
+    for U in (1, 7, 64):
+        y = _tokens("decode/y%d" % U, 1, U)
+        out["y_%d" % U] = y
+        for causal in (True, False):
+            tag = "U%d_%s" % (U, "causal" if causal else "full")
+            logits = model.decode(torch.from_numpy(y), mem, causal_mask=causal)
+            out["logits_last_" + tag] = logits[:, -1].numpy()
+            out["logits_first_" + tag] = logits[:, 0].numpy()
+            out["attn_last_" + tag] = torch.stack(
+                [l.src_attn_weights[:, -1] for l in model.decoder.layers], 0).numpy()
+            spk = model.decode_spk(torch.from_numpy(y), mem, causal_mask=causal)
+            out["spk_last_" + tag] = spk[:, -1].numpy()
+    # B=2 with a real key-padding mask (ragged batch), memory = full T'
+    lens = [480000, 400000]
+    audio = synth.synth_audio_batch(2, 480000, 1234, lens=lens)
+    enc2 = model.encode(torch.from_numpy(audio), torch.tensor(lens))
+    y = _tokens("decode/yb2", 2, 9)
+    out["y_b2"] = y
+    logits = model.decode(torch.from_numpy(y), enc2, causal_mask=False)
+    out["logits_last_b2"] = logits[:, -1].numpy()
+    out["attn_last_b2"] = torch.stack([l.src_attn_weights[:, -1] for l in model.decoder.layers], 0).numpy()
+    out["spk_last_b2"] = model.decode_spk(torch.from_numpy(y), enc2, causal_mask=False)[:, -1].numpy()
+    save("asr_decode", **out)
+
+
+def sec_gru(ns):
+    rnn = fill(ns.uisrnn.CoreRNN(256, 512, 1, 256), "corernn.")
+    x1 = synth.synth_tensor("gru/x1", (1, 1, 256), 1.0)
+    h0 = synth.synth_tensor("gru/h0", (1, 1, 512), 1.0)
+    m1, h1 = rnn(torch.from_numpy(x1), torch.from_numpy(h0))
+    x3 = synth.synth_tensor("gru/x3", (3, 2, 256), 1.0)
+    m3, h3 = rnn(torch.from_numpy(x3), None)
+    save("gru", x1=x1, h0=h0, m1=m1.numpy(), h1=h1.numpy(), x3=x3, m3=m3.numpy(), h3=h3.numpy())
+    rnn2 = fill(ns.uisrnn.CoreRNN(256, 512, 2, 256), "corernn2.")
+    m2, h2 = rnn2(torch.from_numpy(x3), None)
+    save("gru_depth2", x3=x3, m3=m2.numpy(), h3=h2.numpy())
+
+
+def sec_flow(ns):
+    """Control-flow fixtures: the reference's own
+    System.generate / System.generate_unaligned (tal/asr/system.py:68-524) are
+    called as plain functions on a stand-in `self` that carries the filled
+    reference ASRModel."""
+    import types
+    System = ns.system.System
+    model = _asr_model(ns)
+    EOS, BOS = 1, 0
+    tok = types.SimpleNamespace(eos_token_id=EOS, bos_token_id=BOS, pad_token_id=2)
+
+    # --- aligned beam search, B=2 ragged, beam 1 and 3, with the speaker head (spk_weight>0)
+    lens = [160000, 120000]
+    audio = synth.synth_audio_batch(2, 160000, 77, lens=lens)
+    for beam, spkw in ((1, 1.0), (3, 0.0)):
+        me = types.SimpleNamespace(model=model, lm=None, tokenizer=tok,
+                                   args=types.SimpleNamespace(spk_weight=spkw, lm_weight=0.0))
+        seqs, spks = System.generate(me, torch.from_numpy(audio), torch.full((2, 1), BOS, dtype=torch.long),
+                                     torch.tensor(lens), length=24, beam_size=beam, terminate_token=EOS,
+                                     force_half=False, force_output=True)
+        out = {"audio_seed": 77, "audio_lens": np.asarray(lens), "length": 24, "beam": beam}
+        for i, s in enumerate(seqs):
+            out["seq_%d" % i] = s.numpy()
+            if spks[i] is not None:
+                out["spk_%d" % i] = spks[i].numpy()
+        save("flow_generate_beam%d" % beam, **out)
+
+    # --- unaligned sliding-window decode on a 60 s clip (audio pre-rounded to the
+    # fp16 grid because system.py:285 casts to half before encode)
+    L = 960000
+    audio = synth.synth_audio_batch(1, L, 4321)
+    audio = audio.astype(np.float16).astype(np.float32)
+    me = types.SimpleNamespace(model=model, lm=None, tokenizer=tok,
+                               args=types.SimpleNamespace(spk_weight=0.0, lm_weight=0.0))
+    gen, align = System.generate_unaligned(me, torch.from_numpy(audio), torch.full((1, 1), EOS, dtype=torch.long),
+                                           torch.tensor([L]), max_iters=260, stall_patience=25)
+    save("flow_unaligned", audio_seed=4321, audio_len=L, max_iters=260,
+         generated=gen.numpy(), chunk_start=np.asarray([int(c[0]) for c, _ in align]),
+         attn=np.stack([a.numpy()[0] for _, a in align]).astype(np.float32))
+
+
+SECTIONS = {"keys": sec_keys, "unit": sec_unit, "sd": sec_sd, "asr": sec_asr,
+            "decode": sec_decode, "gru": sec_gru, "flow": sec_flow}
+
+if __name__ == "__main__":
+    ns = load_reference()
+    todo = sys.argv[1:] or list(SECTIONS)
+    for s in todo:
+        print("== section", s)
+        SECTIONS[s](ns)

@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio frames/s, waveform-on-device -> log-mel -> TDS encoder ->
+diarization head (128-d features + argmax speaker ids), BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (launched by torch.distributed.run for N > 1, rank/addr from the
+env).  A step = one pass of the hot path over this rank's clip(s) already resident in
+HBM.  Default workload (config[2] of BASELINE.json): ONE 1-hour 16 kHz synthetic clip per
+GPU processed as a single B=1 call, exactly how the reference's whole-episode
+diarization path consumes audio (tal/baseline/reconcile.py:76-85).  Weak scaling: every
+rank processes its own clip (independent episodes; no data-path collective except the
+result gather of ids + features to rank 0, which is inside the timed region).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     -- dominant kernel (fp32 MFMA dense layer): algorithmic flops / HIP-event
+                  time of its launches inside the timed region vs the 157.3 TFLOP/s peak
+  cpu_baseline -- the CPU oracle (a port of the reference's PyTorch-CPU path) timed on
+                  this box's host cores on a bounded 5-minute sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+MAC_PER_FRAME_GEMM = 6_272_000 + 119_168 / 1.0  # pointwise pairs + SD head (per mel frame)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--seconds", type=float, default=3600.0, help="clip length per segment")
+    ap.add_argument("--segments", type=int, default=1, help="segments (independent B=1 calls) per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=300.0, help="clip length of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event timing")
+    return ap.parse_args()
+
+
+def build_model(dev):
+    from tal_asrd_amd import SDModel, synth
+    model = SDModel()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.fill_state_dict(shapes)
+    own = model.state_dict()
+    for k, v in sd.items():
+        own[k] = torch.from_numpy(v.copy())
+    model.load_state_dict(own)
+    return model.to(dev), sd
+
+
+def cpu_baseline(sd, seconds):
+    """The oracle (CPU restatement of the reference's PyTorch-CPU path) on a bounded sample."""
+    from oracle import tal_oracle as O
+    from tal_asrd_amd import synth
+    L = int(seconds * 16000)
+    audio = synth.synth_audio_batch(1, L, 1234)
+    frames = 1 + L // 160
+    cores = torch.get_num_threads()
+    O.sd_path(audio, sd)  # warm-up
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.sd_path(audio, sd)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[1]
+    return {"value": frames / med, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%.0f s synthetic clip (%d frames), torch-CPU fp32, %d threads, median of 3 after 1 warm-up"
+                      % (seconds, frames, cores)}
+
+
+def main():
+    args = parse()
+    import __graft_entry__ as g
+    g.build()
+    from tal_asrd_amd import _native, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    model, sd = build_model(dev)
+    if dist is not None:
+        # weights come from rank 0 over RCCL/xGMI (one flat broadcast per tensor, start-up only)
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0)
+
+    L = int(args.seconds * 16000)
+    frames = 1 + L // 160
+    clips = [torch.from_numpy(synth.synth_audio_batch(1, L, 1234 + rank * args.segments + i)).to(dev)
+             for i in range(args.segments)]
+    torch.cuda.synchronize()
+
+    gather_feat = gather_ids = None
+
+    def step():
+        outs = []
+        for clip in clips:
+            feat, ids = model.speaker_ids(clip)
+            outs.append((feat, ids))
+        if dist is not None:
+            feat = torch.cat([o[0].reshape(-1, o[0].shape[-1]) for o in outs])
+            ids = torch.cat([o[1].reshape(-1) for o in outs])
+            dist.gather(feat, gather_feat if rank == 0 else None, dst=0)
+            dist.gather(ids, gather_ids if rank == 0 else None, dst=0)
+        return outs
+
+    with torch.no_grad():
+        if dist is not None and rank == 0:
+            f0, i0 = model.speaker_ids(clips[0])
+            n_rows = f0.shape[-2] * args.segments
+            gather_feat = [torch.empty(n_rows, f0.shape[-1], device=dev) for _ in range(world)]
+            gather_ids = [torch.empty(n_rows, dtype=torch.int32, device=dev) for _ in range(world)]
+        for _ in range(args.warmup):
+            step()
+        lib = _native.lib()
+        prof = not args.no_prof
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if prof:
+            lib.tal_prof_reset()
+            lib.tal_prof_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if prof:
+            lib.tal_prof_enable(0)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_frames = world * args.segments * frames * args.steps
+        line = {
+            "metric": "audio frames/sec (16 kHz, 10 ms hop) end-to-end log-mel -> TDS encoder -> diarization head",
+            "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d x %.0f s 16 kHz clip per GPU, each a whole-episode B=1 call "
+                                   "(BASELINE.json configs[2]; SDModel path of tal/baseline/reconcile.py:76-85: "
+                                   "log-mel -> TDS 80-800-1120-1440 -> 128-d feat + argmax over 6008 speakers)"
+                                   % (args.segments, args.seconds),
+                       "frames_per_gpu_per_step": args.segments * frames, "weights": "synthetic deterministic",
+                       "audio_resident_in_hbm": True},
+        }
+        if prof:
+            ms, n, work = C.c_double(), C.c_int64(), C.c_double()
+            kern = {}
+            for cls, name in ((0, "gemm_nt_f32"), (1, "gconv_res"), (2, "gconv_s2"), (3, "logmel"), (4, "other")):
+                _native.check(lib.tal_prof_collect(cls, C.byref(ms), C.byref(n), C.byref(work)))
+                kern[name] = {"ms_total": ms.value, "launches": n.value, "work": work.value}
+            gm = kern["gemm_nt_f32"]
+            achieved = gm["work"] / (gm["ms_total"] * 1e-3) / 1e12 if gm["ms_total"] > 0 else 0.0
+            line["roofline"] = {"bound": "mfma", "kernel": "tal::gemm_nt_f32_kernel (fp32 MFMA dense layer)",
+                                "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                                "avg_launch_ms": gm["ms_total"] / max(gm["launches"], 1),
+                                "launches": gm["launches"],
+                                "algorithmic_flops_per_launch": gm["work"] / max(gm["launches"], 1)}
+            tot = sum(k["ms_total"] for k in kern.values())
+            line["kernel_time_share"] = {k: (v["ms_total"] / tot if tot else 0.0) for k, v in kern.items()}
+            line["kernel_ms_per_step"] = {k: v["ms_total"] / args.steps for k, v in kern.items()}
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, args.cpu_seconds)
+            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

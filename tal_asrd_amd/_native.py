@@ -1,0 +1,101 @@
+"""ctypes binding of the C-ABI library (include/tal_asrd.h -> libtal_asrd_hip.so).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc, gfx950).  There
+is NO fallback: if the library is missing or an entry point fails, the product
+path raises.  This module never imports anything from oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtal_asrd_hip.so")
+
+TAL_MAX_STAGES = 4
+TAL_MAX_DEPTH = 8
+
+c_float_p = C.c_void_p  # device pointers travel as integers
+
+
+class TdsBlockW(C.Structure):
+    _fields_ = [("conv_w", C.c_void_p), ("conv_b", C.c_void_p), ("fc0_w", C.c_void_p), ("fc0_b", C.c_void_p),
+                ("fc3_w", C.c_void_p), ("fc3_b", C.c_void_p), ("resweight", C.c_float), ("_pad", C.c_int32)]
+
+
+class TdsDesc(C.Structure):
+    _fields_ = [("n_stages", C.c_int32), ("groups", C.c_int32),
+                ("channels", C.c_int32 * (TAL_MAX_STAGES + 1)), ("depths", C.c_int32 * TAL_MAX_STAGES),
+                ("down_w", C.c_void_p * TAL_MAX_STAGES), ("down_b", C.c_void_p * TAL_MAX_STAGES),
+                ("blocks", (TdsBlockW * TAL_MAX_DEPTH) * TAL_MAX_STAGES)]
+
+
+# name -> (restype, argtypes); must list every symbol include/tal_asrd.h declares
+# (tests/test_abi.py checks header <-> table <-> library).
+_i, _i64, _sz, _f, _p = C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_void_p
+SIGNATURES = {
+    "tal_version": (_i, []),
+    "tal_last_error": (C.c_char_p, []),
+    "tal_logmel_num_frames": (_i64, [_i64]),
+    "tal_logmel_plan_bytes": (_sz, []),
+    "tal_logmel_plan_init": (_i, [_p, _p, _p, _p]),
+    "tal_logmel_workspace_bytes": (_sz, [_i, _i64]),
+    "tal_logmel_fwd": (_i, [_p, _p, _i, _i64, _f, _i, _p, _p, _p, _p, _sz, _p]),
+    "tal_subtract_scalar": (_i, [_p, _i64, _p, _p]),
+    "tal_linear_fwd": (_i, [_p, _p, _p, _p, _f, _i, _i64, _i, _i, _p, _p]),
+    "tal_pack_gconv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "tal_gconv_s2_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _p, _p]),
+    "tal_gconv_res_fwd": (_i, [_p, _p, _p, _f, _i, _i64, _i, _i, _p, _p]),
+    "tal_tds_out_len": (_i64, [C.POINTER(TdsDesc), _i64]),
+    "tal_tds_workspace_bytes": (_sz, [C.POINTER(TdsDesc), _i, _i64]),
+    "tal_tds_fwd": (_i, [C.POINTER(TdsDesc), _p, _i, _i64, _p, _p, _sz, _p]),
+    "tal_sd_head_workspace_bytes": (_sz, [_i64, _i]),
+    "tal_sd_head_fwd": (_i, [_p, _i64, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _sz, _p]),
+    "tal_argmax_rows": (_i, [_p, _i64, _i, _p, _p]),
+    "tal_prof_enable": (_i, [_i]),
+    "tal_prof_reset": (_i, []),
+    "tal_prof_collect": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                "tal_asrd_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU/PyTorch fallback for the hot path." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().tal_last_error()
+        raise NativeError("%s failed (rc=%d): %s" % (what or "tal call", rc, msg.decode() if msg else ""))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_handle():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t, what):
+    if not t.is_cuda:
+        raise NativeError("%s: the hot path only runs on the GPU (HIP kernels); got a %s tensor and there is "
+                          "deliberately no CPU fallback" % (what, t.device))

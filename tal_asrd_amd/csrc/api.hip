@@ -1,0 +1,262 @@
+// C-ABI entry points (include/tal_asrd.h) that compose the kernels: error string, dense
+// layer, TDS encoder driver, diarization head.
+#include <string.h>
+
+#include "common.h"
+
+namespace tal {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- per-launch event timing ------------------------------------------------------------
+static const int PROF_MAX = 8192;
+static bool g_prof_on = false;
+static int g_prof_n = 0;
+static hipEvent_t g_prof_ev[PROF_MAX][2];
+static int g_prof_cls[PROF_MAX];
+static double g_prof_work[PROF_MAX];
+static int g_prof_created = 0;
+
+ProfScope::ProfScope(int cls, double work, hipStream_t stream) : slot(-1), s(stream) {
+    if (!g_prof_on || g_prof_n >= PROF_MAX) return;
+    slot = g_prof_n++;
+    if (slot >= g_prof_created) {
+        hipEventCreate(&g_prof_ev[slot][0]);
+        hipEventCreate(&g_prof_ev[slot][1]);
+        g_prof_created = slot + 1;
+    }
+    g_prof_cls[slot] = cls;
+    g_prof_work[slot] = work;
+    hipEventRecord(g_prof_ev[slot][0], s);
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) hipEventRecord(g_prof_ev[slot][1], s);
+}
+
+// Row-wise argmax, one wave per row; ties resolve to the lowest index (torch.argmax).
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int64_t M, int N,
+                                                         int32_t* __restrict__ ids) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * N;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < N; i += 64) {
+        const float v = xr[i];
+        if (v > best || (v == best && i < bi)) {
+            best = v;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) ids[row] = bi == 0x7fffffff ? 0 : bi;
+}
+
+int launch_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, hipStream_t s) {
+    TAL_CHECK_ARG(x && ids && N > 0 && M >= 0, "tal_argmax_rows: bad argument");
+    if (M == 0) return TAL_OK;
+    ProfScope prof(PROF_OTHER, (double)M * N * 4.0, s);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, x, M, N, ids);
+    TAL_CHECK_LAUNCH("tal_argmax_rows");
+    return TAL_OK;
+}
+
+static int64_t conv_out_len(int64_t t) { return t < 21 ? 0 : (t - 21) / 2 + 1; }
+
+}  // namespace tal
+
+using namespace tal;
+
+extern "C" int tal_version(void) { return 100; /* 0.1.0 */ }
+
+extern "C" const char* tal_last_error(void) { return g_err; }
+
+extern "C" int tal_prof_enable(int on) {
+    g_prof_on = on != 0;
+    return TAL_OK;
+}
+
+extern "C" int tal_prof_reset(void) {
+    g_prof_n = 0;
+    return TAL_OK;
+}
+
+extern "C" int tal_prof_collect(int cls, double* total_ms, int64_t* launches, double* total_work) {
+    TAL_CHECK_ARG(cls >= 0 && cls < PROF_NCLASS && total_ms && launches && total_work, "tal_prof_collect: bad argument");
+    double ms = 0.0, work = 0.0;
+    int64_t n = 0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        if (g_prof_cls[i] != cls) continue;
+        if (hipEventSynchronize(g_prof_ev[i][1]) != hipSuccess) {
+            set_error("tal_prof_collect: event sync failed");
+            return TAL_EHIP;
+        }
+        float t = 0.f;
+        hipEventElapsedTime(&t, g_prof_ev[i][0], g_prof_ev[i][1]);
+        ms += t;
+        work += g_prof_work[i];
+        ++n;
+    }
+    *total_ms = ms;
+    *launches = n;
+    *total_work = work;
+    return TAL_OK;
+}
+
+extern "C" int tal_linear_fwd(const float* x, const float* w, const float* b, const float* res, float alpha, int mode,
+                              int64_t M, int N, int K, float* y, void* stream) {
+    return launch_linear(x, w, b, res, alpha, mode, M, N, K, y, (hipStream_t)stream);
+}
+
+extern "C" int tal_gconv_s2_fwd(const float* x, const float* w_packed, const float* bias, int B, int64_t T_in,
+                                int C_in, int C_out, int groups, float* y, void* stream) {
+    return launch_gconv_s2(x, w_packed, bias, B, T_in, C_in, C_out, groups, y, (hipStream_t)stream);
+}
+
+extern "C" int tal_gconv_res_fwd(const float* x, const float* w_packed, const float* bias, float alpha, int B,
+                                 int64_t T, int C, int groups, float* y, void* stream) {
+    return launch_gconv_res(x, w_packed, bias, alpha, B, T, C, groups, y, (hipStream_t)stream);
+}
+
+extern "C" int tal_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, void* stream) {
+    return launch_argmax_rows(x, M, N, ids, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// TDS encoder driver
+// ---------------------------------------------------------------------------------------
+static int check_desc(const tal_tds_desc* d) {
+    TAL_CHECK_ARG(d, "tal_tds: null descriptor");
+    TAL_CHECK_ARG(d->n_stages >= 1 && d->n_stages <= TAL_MAX_STAGES, "tal_tds: n_stages=%d", d->n_stages);
+    TAL_CHECK_ARG(d->groups > 0, "tal_tds: groups=%d", d->groups);
+    for (int i = 0; i <= d->n_stages; ++i)
+        TAL_CHECK_ARG(d->channels[i] > 0 && d->channels[i] % d->groups == 0, "tal_tds: channels[%d]=%d", i, d->channels[i]);
+    for (int i = 0; i < d->n_stages; ++i) {
+        TAL_CHECK_ARG(d->depths[i] >= 0 && d->depths[i] <= TAL_MAX_DEPTH, "tal_tds: depths[%d]=%d", i, d->depths[i]);
+        TAL_CHECK_ARG(d->channels[i + 1] % 4 == 0 || d->depths[i] == 0, "tal_tds: channels[%d]=%d must be a multiple of 4 for the pointwise layers", i + 1, d->channels[i + 1]);
+    }
+    return TAL_OK;
+}
+
+extern "C" int64_t tal_tds_out_len(const tal_tds_desc* d, int64_t T) {
+    if (!d) return -1;
+    for (int i = 0; i < d->n_stages; ++i) T = conv_out_len(T);
+    return T;
+}
+
+static size_t tds_buf_floats(const tal_tds_desc* d, int B, int64_t T) {
+    size_t mx = 0;
+    for (int i = 0; i < d->n_stages; ++i) {
+        T = conv_out_len(T);
+        const size_t n = (size_t)B * (size_t)T * (size_t)d->channels[i + 1];
+        if (n > mx) mx = n;
+    }
+    return (mx + 63) & ~(size_t)63;
+}
+
+extern "C" size_t tal_tds_workspace_bytes(const tal_tds_desc* d, int B, int64_t T) {
+    if (!d || B <= 0 || T <= 0) return 0;
+    return 3 * tds_buf_floats(d, B, T) * sizeof(float);
+}
+
+extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t T, float* y, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    TAL_CHECK_ARG(x && y && workspace, "tal_tds_fwd: null pointer");
+    TAL_CHECK_ARG(B > 0 && tal_tds_out_len(d, T) > 0, "tal_tds_fwd: T=%lld too short for %d stride-2 k=21 stages", (long long)T, d->n_stages);
+    if (workspace_bytes < tal_tds_workspace_bytes(d, B, T)) {
+        set_error("tal_tds_fwd: workspace %zu < %zu bytes", workspace_bytes, tal_tds_workspace_bytes(d, B, T));
+        return TAL_ENOMEM;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nf = tds_buf_floats(d, B, T);
+    float* buf[3] = {reinterpret_cast<float*>(workspace), reinterpret_cast<float*>(workspace) + nf,
+                     reinterpret_cast<float*>(workspace) + 2 * nf};
+    const float* cur = x;
+    int64_t Tc = T;
+    for (int i = 0; i < d->n_stages; ++i) {
+        const int cin = d->channels[i], c = d->channels[i + 1];
+        const int64_t To = conv_out_len(Tc);
+        const bool last_stage = i == d->n_stages - 1;
+        // resize conv: cur -> a
+        float* a = (last_stage && d->depths[i] == 0) ? y : buf[0];
+        rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s);
+        if (rc) return rc;
+        const int64_t M = (int64_t)B * To;
+        for (int j = 0; j < d->depths[i]; ++j) {
+            const tal_tds_block_w& bw = d->blocks[i][j];
+            TAL_CHECK_ARG(bw.conv_w && bw.conv_b && bw.fc0_w && bw.fc0_b && bw.fc3_w && bw.fc3_b, "tal_tds_fwd: null weight in block %d.%d", i, j);
+            // x1 = x + rw * relu(gconv(x))            : a -> buf[1]
+            rc = launch_gconv_res(a, bw.conv_w, bw.conv_b, bw.resweight, B, To, c, d->groups, buf[1], s);
+            if (rc) return rc;
+            // h = relu(fc0(x1))                        : buf[1] -> buf[2]
+            rc = launch_linear(buf[1], bw.fc0_w, bw.fc0_b, nullptr, 0.f, 1, M, c, c, buf[2], s);
+            if (rc) return rc;
+            // x2 = x1 + rw * fc3(h)                    : buf[2] (+res buf[1]) -> a'
+            float* outp = (last_stage && j == d->depths[i] - 1) ? y : buf[0];
+            rc = launch_linear(buf[2], bw.fc3_w, bw.fc3_b, buf[1], bw.resweight, 2, M, c, c, outp, s);
+            if (rc) return rc;
+            a = outp;
+        }
+        cur = a;
+        Tc = To;
+    }
+    return TAL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Diarization head
+// ---------------------------------------------------------------------------------------
+static const int64_t SD_CHUNK = 16384;
+
+extern "C" size_t tal_sd_head_workspace_bytes(int64_t M, int S) {
+    const int64_t rows = M < SD_CHUNK ? M : SD_CHUNK;
+    return (size_t)(rows > 0 ? rows : 1) * (size_t)S * sizeof(float);
+}
+
+extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_embed, const float* b_embed, int E,
+                               const float* w_logit, const float* b_logit, int S, float* feat, float* logits,
+                               int32_t* ids, void* workspace, size_t workspace_bytes, void* stream) {
+    TAL_CHECK_ARG(x && w_embed && w_logit && feat, "tal_sd_head_fwd: null pointer");
+    TAL_CHECK_ARG(M >= 0 && C > 0 && E > 0 && S > 0, "tal_sd_head_fwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_linear(x, w_embed, b_embed, nullptr, 0.f, 0, M, E, C, feat, s);
+    if (rc) return rc;
+    if (!logits && !ids) return TAL_OK;
+    if (logits) {
+        rc = launch_linear(feat, w_logit, b_logit, nullptr, 0.f, 0, M, S, E, logits, s);
+        if (rc) return rc;
+        return ids ? launch_argmax_rows(logits, M, S, ids, s) : TAL_OK;
+    }
+    TAL_CHECK_ARG(workspace, "tal_sd_head_fwd: ids without logits needs a workspace");
+    if (workspace_bytes < tal_sd_head_workspace_bytes(M, S)) {
+        set_error("tal_sd_head_fwd: workspace %zu < %zu bytes", workspace_bytes, tal_sd_head_workspace_bytes(M, S));
+        return TAL_ENOMEM;
+    }
+    float* tmp = reinterpret_cast<float*>(workspace);
+    for (int64_t r0 = 0; r0 < M; r0 += SD_CHUNK) {
+        const int64_t rows = M - r0 < SD_CHUNK ? M - r0 : SD_CHUNK;
+        rc = launch_linear(feat + r0 * E, w_logit, b_logit, nullptr, 0.f, 0, rows, S, E, tmp, s);
+        if (rc) return rc;
+        rc = launch_argmax_rows(tmp, rows, S, ids + r0, s);
+        if (rc) return rc;
+    }
+    return TAL_OK;
+}

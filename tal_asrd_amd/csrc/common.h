@@ -1,0 +1,58 @@
+// Shared helpers for the gfx950 kernels (internal; the public ABI is include/tal_asrd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/tal_asrd.h"
+
+namespace tal {
+
+void set_error(const char* fmt, ...);
+
+#define TAL_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            tal::set_error(__VA_ARGS__);         \
+            return TAL_EINVAL;                   \
+        }                                        \
+    } while (0)
+
+#define TAL_CHECK_LAUNCH(what)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            tal::set_error("%s: launch failed: %s", what, hipGetErrorString(e__));    \
+            return TAL_EHIP;                                                          \
+        }                                                                             \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// wave-uniform wave index inside the workgroup, provably uniform to the compiler
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// Optional per-launch HIP-event timing (tal_prof_*): bench.py brackets every launch of a
+// kernel class with two events on the launch stream and reads the average duration back.
+enum ProfClass { PROF_GEMM = 0, PROF_GCONV_RES = 1, PROF_GCONV_S2 = 2, PROF_LOGMEL = 3, PROF_OTHER = 4, PROF_NCLASS = 5 };
+struct ProfScope {
+    int slot;
+    hipStream_t s;
+    ProfScope(int cls, double work, hipStream_t stream);
+    ~ProfScope();
+};
+
+// internal launchers shared between translation units
+int launch_linear(const float* x, const float* w, const float* b, const float* res, float alpha, int mode,
+                  int64_t M, int N, int K, float* y, hipStream_t s);
+int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, int64_t T_in, int C_in, int C_out,
+                    int groups, float* y, hipStream_t s);
+int launch_gconv_res(const float* x, const float* wp, const float* bias, float alpha, int B, int64_t T, int C,
+                     int groups, float* y, hipStream_t s);
+int launch_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, hipStream_t s);
+
+}  // namespace tal

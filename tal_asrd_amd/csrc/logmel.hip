@@ -1,0 +1,253 @@
+// Log-mel front-end: LogMelSpec.forward (tal/asr/models.py:35-53) with the torchaudio
+// 0.4.0 MelSpectrogram semantics restated in SURVEY.md section 8c:
+//   reflect-pad 200 | frames of 400 @ hop 160 | periodic Hann | 400-point one-sided DFT |
+//   re^2+im^2 | 201x80 HTK mel filterbank | log(. + eps) | minus one global scalar mean.
+//
+// One workgroup = 32 consecutive frames of one batch item.  The 5360 samples the frames
+// span are read once, coalesced, into LDS (reflect indexing resolved at load time; one pad
+// word per hop keeps the frame-strided MFMA operand reads conflict-free).  The windowed DFT
+// is a [32 x 400] . [400 x (re|im) x 224] contraction on the fp32 matrix cores against a
+// Hann-folded twiddle table that stays L2-resident (0.7 MB), so there is no per-sample
+// window multiply and no bit-reversal traffic; re/im of a bin land in the same lane of two
+// accumulators, so the power spectrum is formed in registers.  The (sparse, triangular) mel
+// projection, the log and the partial sum for the global mean are done from an LDS copy of
+// the power tile; the output is written once, coalesced, as [B, T, 80].
+#include <math.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace tal {
+
+constexpr int NFFT = 400;
+constexpr int HOP = 160;
+constexpr int NBIN = 201;
+constexpr int NMEL = 80;
+constexpr int FB = 32;                         // frames per workgroup
+constexpr int NTILE = 7;                       // 7 x 32 = 224 >= 201 bins
+constexpr int NS = (FB - 1) * HOP + NFFT;      // 5360 samples per workgroup
+constexpr int NSP = NS + NS / HOP + 2;         // + one pad word per hop
+constexpr int PLD = NTILE * 32 + 1;            // power tile pitch (225)
+constexpr int MAXW = 48;                       // max mel filter support in bins
+
+struct LogmelPlan {
+    float basis[NTILE * NFFT * 2 * 32];  // [tile][n][re|im][32 bins], Hann folded in
+    int mel_lo[NMEL];
+    int mel_cnt[NMEL];
+    float mel_w[NMEL * MAXW];
+};
+
+__global__ __launch_bounds__(256) void logmel_kernel(const LogmelPlan* __restrict__ plan,
+                                                    const float* __restrict__ audio, int64_t L, int64_t T, float eps,
+                                                    float* __restrict__ out, double* __restrict__ partial) {
+    __shared__ float samp[NSP];
+    __shared__ float P[FB * PLD];
+    __shared__ double red[4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = wave_id();
+    const int b = blockIdx.y;
+    const int64_t f0 = (int64_t)blockIdx.x * FB;
+    const float* ab = audio + (int64_t)b * L;
+
+    const int64_t p0 = f0 * HOP - NFFT / 2;
+    for (int i = tid; i < NS; i += 256) {
+        int64_t p = p0 + i;
+        if (p < 0) p = -p;                       // reflect (no edge repeat), as torch.stft pad_mode='reflect'
+        if (p >= L) p = 2 * (L - 1) - p;
+        p = p < 0 ? 0 : (p >= L ? L - 1 : p);    // frames past T (tail block) only
+        samp[i + i / HOP] = ab[p];
+    }
+    __syncthreads();
+
+    const int fi = lane & 31;  // frame (A row) / bin (B col) index inside the tile
+    const int kh = lane >> 5;  // which of the 2 k's of a 32x32x2 step
+    for (int j = w; j < NTILE; j += 4) {
+        f32x16 are, aim;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) are[e] = aim[e] = 0.f;
+        const float* bp = plan->basis + (int64_t)j * NFFT * 64 + kh * 64 + fi;
+        const float* sp = samp + fi * (HOP + 1) + kh;
+#pragma unroll 8
+        for (int s2 = 0; s2 < NFFT / 2; ++s2) {
+            const int k = 2 * s2;
+            const float a = sp[k + (k + kh) / HOP];
+            const float br = bp[k * 64];
+            const float bi = bp[k * 64 + 32];
+            are = __builtin_amdgcn_mfma_f32_32x32x2f32(a, br, are, 0, 0, 0);
+            aim = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bi, aim, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int frame = (e & 3) + 8 * (e >> 2) + 4 * kh;
+            P[frame * PLD + j * 32 + fi] = are[e] * are[e] + aim[e] * aim[e];
+        }
+    }
+    __syncthreads();
+
+    double local = 0.0;
+    for (int idx = tid; idx < FB * NMEL; idx += 256) {
+        const int frame = idx / NMEL;
+        const int m = idx - frame * NMEL;
+        const int lo = plan->mel_lo[m];
+        const int cnt = plan->mel_cnt[m];
+        const float* wm = plan->mel_w + m * MAXW;
+        const float* pr = P + frame * PLD + lo;
+        float sum = 0.f;
+        for (int i = 0; i < cnt; ++i) sum = fmaf(pr[i], wm[i], sum);
+        const float v = logf(sum + eps);
+        if (f0 + frame < T) {
+            out[((int64_t)b * T + f0 + frame) * NMEL + m] = v;
+            local += (double)v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if (lane == 0) red[w] = local;
+    __syncthreads();
+    if (tid == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// fixed-order reduction of the per-workgroup partial sums -> {sum, count} and the float mean
+__global__ __launch_bounds__(256) void logmel_mean_kernel(const double* __restrict__ partial, int64_t n, double count,
+                                                         float* __restrict__ mean_out, double* __restrict__ sum_out,
+                                                         float* __restrict__ mean_ws) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mean = (float)(red[0] / count);
+        mean_ws[0] = mean;
+        if (mean_out) mean_out[0] = mean;
+        if (sum_out) {
+            sum_out[0] = red[0];
+            sum_out[1] = count;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void subtract_scalar_kernel(float* __restrict__ x, int64_t n,
+                                                             const float* __restrict__ mean) {
+    const float m = mean[0];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = n >> 2;
+    float4* x4 = reinterpret_cast<float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = x4[i];
+        v.x -= m; v.y -= m; v.z -= m; v.w -= m;
+        x4[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] -= m;
+}
+
+static int launch_subtract(float* x, int64_t n, const float* mean, hipStream_t s) {
+    if (n == 0) return TAL_OK;
+    int64_t blocks = cdiv(n / 4 + 1, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(subtract_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, mean);
+    TAL_CHECK_LAUNCH("tal_subtract_scalar");
+    return TAL_OK;
+}
+
+}  // namespace tal
+
+using namespace tal;
+
+extern "C" int64_t tal_logmel_num_frames(int64_t L) { return 1 + L / HOP; }
+
+extern "C" size_t tal_logmel_plan_bytes(void) { return sizeof(LogmelPlan); }
+
+extern "C" int tal_logmel_plan_init(const float* window, const float* fb, void* plan, void* stream) {
+    TAL_CHECK_ARG(window && fb && plan, "tal_logmel_plan_init: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<float> hwin(NFFT), hfb(NBIN * NMEL);
+    if (hipMemcpyAsync(hwin.data(), window, NFFT * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(hfb.data(), fb, NBIN * NMEL * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        set_error("tal_logmel_plan_init: cannot read window/fb from the device");
+        return TAL_EHIP;
+    }
+    std::vector<char> buf(sizeof(LogmelPlan));
+    LogmelPlan* hp = reinterpret_cast<LogmelPlan*>(buf.data());
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int j = 0; j < NTILE; ++j)
+        for (int n = 0; n < NFFT; ++n)
+            for (int c = 0; c < 32; ++c) {
+                const int bin = j * 32 + c;
+                double re = 0.0, im = 0.0;
+                if (bin < NBIN) {
+                    const int ph = (int)(((int64_t)bin * n) % NFFT);  // exact phase reduction
+                    const double ang = two_pi * (double)ph / (double)NFFT;
+                    re = (double)hwin[n] * cos(ang);
+                    im = -(double)hwin[n] * sin(ang);
+                }
+                hp->basis[((j * NFFT + n) * 2 + 0) * 32 + c] = (float)re;
+                hp->basis[((j * NFFT + n) * 2 + 1) * 32 + c] = (float)im;
+            }
+    for (int m = 0; m < NMEL; ++m) {
+        int lo = -1, hi = -1;
+        for (int k = 0; k < NBIN; ++k)
+            if (hfb[k * NMEL + m] != 0.f) {
+                if (lo < 0) lo = k;
+                hi = k;
+            }
+        const int cnt = lo < 0 ? 0 : hi - lo + 1;
+        TAL_CHECK_ARG(cnt <= MAXW, "tal_logmel_plan_init: mel filter %d spans %d bins (max %d)", m, cnt, MAXW);
+        hp->mel_lo[m] = lo < 0 ? 0 : lo;
+        hp->mel_cnt[m] = cnt;
+        for (int i = 0; i < MAXW; ++i) hp->mel_w[m * MAXW + i] = i < cnt ? hfb[(lo + i) * NMEL + m] : 0.f;
+    }
+    if (hipMemcpyAsync(plan, hp, sizeof(LogmelPlan), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        set_error("tal_logmel_plan_init: cannot upload the plan");
+        return TAL_EHIP;
+    }
+    return TAL_OK;
+}
+
+extern "C" size_t tal_logmel_workspace_bytes(int B, int64_t L) {
+    const int64_t T = 1 + L / HOP;
+    return (size_t)(B * cdiv(T, FB) + 4) * sizeof(double);
+}
+
+extern "C" int tal_logmel_fwd(const void* plan, const float* audio, int B, int64_t L, float eps, int subtract_mean,
+                              float* out, float* mean_out, double* sum_out, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    TAL_CHECK_ARG(plan && audio && out && workspace, "tal_logmel_fwd: null pointer");
+    TAL_CHECK_ARG(B > 0 && L > NFFT / 2, "tal_logmel_fwd: need B>0 and L>%d for reflect padding (L=%lld)", NFFT / 2, (long long)L);
+    if (workspace_bytes < tal_logmel_workspace_bytes(B, L)) {
+        set_error("tal_logmel_fwd: workspace %zu < %zu bytes", workspace_bytes, tal_logmel_workspace_bytes(B, L));
+        return TAL_ENOMEM;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t T = 1 + L / HOP;
+    const int64_t nblk = cdiv(T, FB);
+    double* partial = reinterpret_cast<double*>(workspace);
+    float* mean_ws = reinterpret_cast<float*>(partial + B * nblk + 2);
+    {
+        // algorithmic HBM bytes: read L samples, write T*80 floats per item
+        ProfScope prof(PROF_LOGMEL, (double)B * ((double)L + (double)T * NMEL) * 4.0, s);
+        hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, s,
+                           reinterpret_cast<const LogmelPlan*>(plan), audio, L, T, eps, out, partial);
+    }
+    TAL_CHECK_LAUNCH("tal_logmel_fwd");
+    hipLaunchKernelGGL(logmel_mean_kernel, dim3(1), dim3(256), 0, s, partial, (int64_t)B * nblk,
+                       (double)B * (double)T * (double)NMEL, mean_out, sum_out, mean_ws);
+    TAL_CHECK_LAUNCH("tal_logmel_fwd(mean)");
+    if (subtract_mean) return launch_subtract(out, (int64_t)B * T * NMEL, mean_ws, s);
+    return TAL_OK;
+}
+
+extern "C" int tal_subtract_scalar(float* x, int64_t n, const float* mean, void* stream) {
+    TAL_CHECK_ARG(x && mean && n >= 0, "tal_subtract_scalar: bad argument");
+    TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0, "tal_subtract_scalar: x must be 16-byte aligned");
+    return launch_subtract(x, n, mean, (hipStream_t)stream);
+}

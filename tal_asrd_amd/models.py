@@ -1,0 +1,437 @@
+"""Host-side mirror of the reference's model classes (tal/asr/models.py), backed by
+the HIP kernels of libtal_asrd_hip.so.
+
+Same class names, constructor signatures, method names, return dicts and
+state_dict keys as the reference, so `System.generate*`-style control flow and
+checkpoint loading work unchanged:
+
+    LogMelSpec, TDSBlock, TDS, SDModel, ASRModel, ModRZTXDecoderLayer
+
+Differences that are deliberate and documented in DESIGN.md:
+  * inference only: dropout / SpecAugment (models.py:531-566) are not built;
+  * activations are time-major [B, T, C] inside; `TDS.forward` keeps the
+    reference's [B, C, T] contract by transposing at its edge, while
+    `encode_features` (which receives and returns time-major tensors in the
+    reference too) never transposes;
+  * fp32 end to end (the reference's .half() casts are GPU-era AMP plumbing);
+  * CPU tensors are rejected: there is no fallback path.
+The nn.Conv1d / nn.Linear / nn.MultiheadAttention children are parameter
+containers that keep the reference's key names and default initialisation; the
+wrappers below override `forward` so that a direct call (e.g.
+`model.spk_embed_proj(x)` in tal/baseline/reconcile.py:81) also runs the HIP path.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+from . import ops
+from .modules import PositionalEncoding, weight_init
+
+DEFAULT_SR = 16000  # tal/asr/data/__init__.py:6
+KERNEL_SIZE = 21
+
+
+# ----------------------------------------------------------------------------
+# torchaudio-0.4.0-compatible buffers (restated; the library is not available)
+# ----------------------------------------------------------------------------
+def _htk_filterbank(n_freqs, n_mels, sample_rate, f_min=0.0, f_max=None):
+    """[n_freqs, n_mels] triangular HTK-mel filters without area normalisation
+    (torchaudio 0.4.0 MelScale / create_fb_matrix semantics)."""
+    f_max = float(sample_rate // 2) if f_max is None else float(f_max)
+    freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    lo = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    hi = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    edges_mel = torch.linspace(lo, hi, n_mels + 2)
+    edges_hz = 700.0 * (10.0 ** (edges_mel / 2595.0) - 1.0)
+    width = edges_hz[1:] - edges_hz[:-1]
+    dist = edges_hz.unsqueeze(0) - freqs.unsqueeze(1)
+    falling = (-1.0 * dist[:, :-2]) / width[:-1]
+    rising = dist[:, 2:] / width[1:]
+    return torch.clamp(torch.min(falling, rising), min=0.0)
+
+
+class _Spectrogram(nn.Module):
+    def __init__(self, n_fft):
+        super().__init__()
+        self.register_buffer("window", torch.hann_window(n_fft))
+
+
+class _MelScale(nn.Module):
+    def __init__(self, n_mels, sample_rate, n_freqs):
+        super().__init__()
+        self.register_buffer("fb", _htk_filterbank(n_freqs, n_mels, sample_rate))
+
+
+class MelSpectrogram(nn.Module):
+    """Buffer holder with torchaudio's attribute paths (`spectrogram.window`,
+    `mel_scale.fb`), so reference checkpoints load with strict=True."""
+
+    def __init__(self, sample_rate, n_mels, n_fft, win_length, hop_length):
+        super().__init__()
+        if (sample_rate, n_fft, win_length, hop_length, n_mels) != (16000, 400, 400, 160, 80):
+            raise N.NativeError("the HIP front-end is built for 16 kHz / 400 / 400 / 160 / 80 mels "
+                                "(tal/asr/models.py:24-32)")
+        self.spectrogram = _Spectrogram(n_fft)
+        self.mel_scale = _MelScale(n_mels, sample_rate, n_fft // 2 + 1)
+
+
+class LogMelSpec(nn.Module):
+    """tal/asr/models.py:15-53."""
+
+    def __init__(self, sr=DEFAULT_SR, n_mels=80, eps=1e-6):
+        super().__init__()
+        self.mel_transform = MelSpectrogram(sample_rate=sr, n_mels=n_mels, n_fft=int(25 / 1000 * sr),
+                                            win_length=int(25 / 1000 * sr), hop_length=int(10 / 1000 * sr))
+        self.eps = eps
+        self._plan = None
+        self._plan_key = None
+
+    def plan(self):
+        win, fb = self.mel_transform.spectrogram.window, self.mel_transform.mel_scale.fb
+        key = (win.data_ptr(), win._version, fb.data_ptr(), fb._version)
+        if self._plan is None or self._plan_key != key:
+            self._plan = ops.logmel_plan(win, fb)
+            self._plan_key = key
+        return self._plan
+
+    @torch.no_grad()
+    def forward(self, audio: torch.Tensor):
+        """audio [batch, audio_len] -> [batch, frames, n_mels], minus the global mean of this call."""
+        N.require_cuda(audio, "LogMelSpec.forward")
+        return ops.logmel(self.plan(), audio, eps=self.eps, subtract_mean=True)
+
+
+# ----------------------------------------------------------------------------
+# parameter containers whose direct call runs the HIP path
+# ----------------------------------------------------------------------------
+class Linear(nn.Linear):
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class PointwiseConv1d(nn.Conv1d):
+    """Conv1d(k=1) == dense layer over channels; called on time-major [B, T, C]."""
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class GroupedConv1d(nn.Conv1d):
+    """Conv1d(k=21, groups=G) holder; `packed()` caches the kernel-side weight layout."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._packed = None
+        self._packed_key = None
+
+    def packed(self):
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        if self._packed is None or self._packed_key != key:
+            self._packed = ops.pack_gconv_weight(self.weight.detach(), self.groups)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, x):
+        """time-major [B, T, C_in] -> [B, T_out, C_out] (plain conv + bias, no activation)."""
+        if self.stride[0] != 2 or self.padding[0] != 0:
+            raise N.NativeError("GroupedConv1d.forward: only the stride-2 / pad-0 resize conv is exposed directly")
+        return ops.gconv_s2(x, self.packed(), self.bias, self.out_channels, self.groups)
+
+
+class TDSBlock(nn.Module):
+    """tal/asr/models.py:298-331: x + rw*relu(gconv(x)); x + rw*fc(x)."""
+
+    def __init__(self, hidden, kernel_size, groups, dropout=0.1):
+        super().__init__()
+        if kernel_size != KERNEL_SIZE:
+            raise N.NativeError("TDSBlock: the HIP kernels are built for kernel_size=21")
+        self.conv = nn.Sequential(
+            GroupedConv1d(hidden, hidden, kernel_size=kernel_size, stride=1, groups=groups,
+                          padding=kernel_size // 2),
+            nn.ReLU(), nn.Dropout(dropout))
+        self.fc = nn.Sequential(
+            PointwiseConv1d(hidden, hidden, kernel_size=1, stride=1), nn.ReLU(), nn.Dropout(dropout),
+            PointwiseConv1d(hidden, hidden, kernel_size=1, stride=1), nn.Dropout(dropout))
+        self.resweight = nn.Parameter(torch.Tensor([0]))
+
+    def forward_time_major(self, x):
+        rw = float(self.resweight)
+        g = self.conv[0]
+        x = ops.gconv_res(x, g.packed(), g.bias, rw, g.groups)
+        h = ops.linear(x, self.fc[0].weight, self.fc[0].bias, mode=1)
+        return ops.linear(h, self.fc[3].weight, self.fc[3].bias, mode=2, res=x, alpha=rw)
+
+    def forward(self, x):
+        """x [batch, features, time] as in the reference."""
+        return self.forward_time_major(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+
+
+class TDS(nn.Module):
+    """tal/asr/models.py:349-397.  `forward` keeps the [B, C, T] contract;
+    `forward_time_major` is the native entry ([B, T, C] in and out, one C call)."""
+
+    def __init__(self, input_size, sizes, depths, kernel_size=21, dropout=0.1):
+        super().__init__()
+        if kernel_size != KERNEL_SIZE:
+            raise N.NativeError("TDS: the HIP kernels are built for kernel_size=21")
+        if len(sizes) - 1 > N.TAL_MAX_STAGES or max(depths) > N.TAL_MAX_DEPTH:
+            raise N.NativeError("TDS: at most %d stages of depth %d" % (N.TAL_MAX_STAGES, N.TAL_MAX_DEPTH))
+        self.extract_block_id = 1
+        self.sizes = sizes
+        self.depths = list(depths)
+        self.input_size = input_size
+        self.blocks = nn.Sequential(*[
+            nn.Sequential(
+                GroupedConv1d(sizes[i - 1], sizes[i], kernel_size=kernel_size, stride=2, groups=input_size),
+                nn.Sequential(*[TDSBlock(sizes[i], kernel_size, input_size, dropout=dropout)
+                                for _ in range(depths[i - 1])]))
+            for i in range(1, len(sizes))])
+        self._desc = None
+        self._desc_key = None
+        self._keep = None
+
+    def _descriptor(self, first=0, last=None):
+        """Build (and cache) the tal_tds_desc for stages [first, last)."""
+        last = len(self.sizes) - 1 if last is None else last
+        key = [first, last]
+        for p in self.parameters():
+            key.append((p.data_ptr(), p._version))
+        key = tuple(key)
+        if self._desc is not None and self._desc_key == key:
+            return self._desc
+        d = N.TdsDesc()
+        keep = []
+        d.n_stages = last - first
+        d.groups = self.input_size
+        for s in range(first, last + 1):
+            d.channels[s - first] = self.sizes[s]
+        for s in range(first, last):
+            i = s - first
+            down, chain = self.blocks[s][0], self.blocks[s][1]
+            d.depths[i] = len(chain)
+            pw = down.packed()
+            keep.append(pw)
+            d.down_w[i] = pw.data_ptr()
+            d.down_b[i] = down.bias.data_ptr()
+            for j, blk in enumerate(chain):
+                g = blk.conv[0]
+                gp = g.packed()
+                keep.append(gp)
+                bw = d.blocks[i][j]
+                bw.conv_w, bw.conv_b = gp.data_ptr(), g.bias.data_ptr()
+                bw.fc0_w, bw.fc0_b = blk.fc[0].weight.data_ptr(), blk.fc[0].bias.data_ptr()
+                bw.fc3_w, bw.fc3_b = blk.fc[3].weight.data_ptr(), blk.fc[3].bias.data_ptr()
+                bw.resweight = float(blk.resweight)
+        self._desc, self._desc_key, self._keep = d, key, keep
+        return d
+
+    def forward_time_major(self, x, first=0, last=None):
+        N.require_cuda(x, "TDS.forward")
+        last = len(self.sizes) - 1 if last is None else last
+        if first == last:
+            return x
+        return ops.tds_forward(self._descriptor(first, last), x, self.sizes[last])
+
+    def extract(self, x):
+        """Feature extraction network: blocks[:extract_block_id] ([B, C, T])."""
+        y = self.forward_time_major(x.permute(0, 2, 1).contiguous(), 0, self.extract_block_id)
+        return y.permute(0, 2, 1).contiguous()
+
+    def aggregate(self, x):
+        y = self.forward_time_major(x.permute(0, 2, 1).contiguous(), self.extract_block_id, len(self.sizes) - 1)
+        return y.permute(0, 2, 1).contiguous()
+
+    def forward(self, x):
+        """x: mel features [batch, features, time] -> [batch, sizes[-1], time']."""
+        return self.forward_time_major(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+
+
+def padding_mask(audio_lens, t_out, device):
+    """tal/asr/models.py:176-187, literally: scaled = lens // (lens.max() // T'); mask[i, scaled_i:] = 1.
+    Integer math on the host (the reference loops over .tolist() as well)."""
+    lens = audio_lens.detach().cpu().to(torch.int64)
+    scaled = lens // (lens.max() // int(t_out))
+    mask = torch.zeros(lens.numel(), int(t_out), dtype=torch.bool)
+    for i, l in enumerate(scaled.tolist()):
+        mask[i, l:] = 1
+    return mask.to(device)
+
+
+class SDModel(nn.Module):
+    """Separate-diarizer baseline (tal/asr/models.py:400-485)."""
+
+    def __init__(self, num_speakers=6008, n_mels=80, dropout=0.2, embed_size=128):
+        super().__init__()
+        self.num_speakers = num_speakers
+        tds_sizes = [n_mels, 10 * n_mels, 14 * n_mels, 18 * n_mels]
+        tds_depths = [2, 3, 6]
+        self.logmelspec = LogMelSpec(n_mels=n_mels)
+        self.encoder = TDS(n_mels, tds_sizes, tds_depths, dropout=dropout)
+        self.dropout = nn.Dropout(dropout)
+        self.spk_embed_proj = Linear(tds_sizes[-1], embed_size)
+        self.spk_logit_proj = Linear(embed_size, num_speakers)
+        self.apply(weight_init())
+        self.eval()
+
+    def get_encoder_params(self):
+        return list(self.encoder.parameters())
+
+    def extract_features(self, x, specaug=True):
+        return self.logmelspec(x)
+
+    def encode_features(self, x: torch.Tensor, audio_lens: torch.LongTensor = None):
+        x = self.encoder.forward_time_major(x)
+        mask = None if audio_lens is None else padding_mask(audio_lens, x.size(1), x.device)
+        return {"encoder_out": x, "encoder_padding_mask": mask}
+
+    def encode(self, x: torch.Tensor, audio_lens: torch.LongTensor = None):
+        return self.encode_features(self.extract_features(x), audio_lens)
+
+    def decode(self, encoder_out, past=None, causal_mask=True):
+        _, logits, _ = ops.sd_head(encoder_out["encoder_out"], self.spk_embed_proj.weight, self.spk_embed_proj.bias,
+                                   self.spk_logit_proj.weight, self.spk_logit_proj.bias,
+                                   want_logits=True, want_ids=False)
+        return logits
+
+    def forward(self, x, audio_lens):
+        encoder_out = self.encode(x, audio_lens)
+        return self.decode(encoder_out), encoder_out
+
+    @torch.no_grad()
+    def speaker_ids(self, x_wav, want_logits=False):
+        """The fused form of tal/baseline/reconcile.py:76-85 (get_speaker_ids): whole-episode
+        waveform [1, L] -> (feat [T', 128], ids [T'] int32[, logits]) without materialising
+        the [T', 6008] logits unless asked."""
+        enc = self.encode(x_wav, None)
+        feat, logits, ids = ops.sd_head(enc["encoder_out"], self.spk_embed_proj.weight, self.spk_embed_proj.bias,
+                                        self.spk_logit_proj.weight, self.spk_logit_proj.bias,
+                                        want_logits=want_logits, want_ids=True)
+        return (feat, ids, logits) if want_logits else (feat, ids)
+
+
+class ModRZTXDecoderLayer(nn.Module):
+    """ReZero decoder layer that caches cross-attention weights (tal/asr/models.py:488-528).
+    Parameter layout identical to the reference (nn.MultiheadAttention packed in-proj)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu"):
+        super().__init__()
+        if activation != "relu":
+            raise N.NativeError("ModRZTXDecoderLayer: only the ReLU FFN is built (tal/asr/models.py:125)")
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = Linear(dim_feedforward, d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+        self.resweight = nn.Parameter(torch.Tensor([0]))
+        self.resweight_src = nn.Parameter(torch.Tensor([0]))
+        self.nhead = nhead
+        self.src_attn_weights = None
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None):
+        from .decoder import decoder_layer_forward
+        return decoder_layer_forward(self, tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask,
+                                     memory_key_padding_mask)
+
+
+class ASRModel(nn.Module):
+    """Joint ASR + speaker model (tal/asr/models.py:56-295)."""
+
+    def __init__(self, model_type="2x", num_speakers=0, n_mels=80, vocab_size=10000, n_head=4, max_positions=512,
+                 dropout=0.2, embed_size=64, spk_embed=128, use_speaker_head=False):
+        super().__init__()
+        self.embed_size = embed_size
+        self.num_speakers = num_speakers
+        self.max_positions = max_positions
+        self.use_speaker_head = use_speaker_head
+        self.model_type = model_type
+        self.n_head = n_head
+        tds_sizes = [n_mels, 10 * n_mels, 14 * n_mels, 18 * n_mels]
+        tds_depths = [2, 3, 6]
+        if model_type == "1x":
+            d_hidden, n_layers = 256, 4
+        elif model_type == "2x":
+            d_hidden, n_layers = 512, 4
+        else:
+            raise Exception("Invalid model type")
+        self.pos_dec_encoder = PositionalEncoding(d_hidden, max_len=max_positions, dropout=dropout)
+        self.logmelspec = LogMelSpec(n_mels=n_mels)
+        self.encoder = TDS(n_mels, tds_sizes, tds_depths, dropout=dropout)
+        self.dropout = nn.Dropout(dropout)
+        self.decoder_proj = Linear(tds_sizes[-1], d_hidden)
+        num_tokens = vocab_size if use_speaker_head else vocab_size + num_speakers
+        if self.embed_size:
+            self.embedding = nn.Embedding(num_tokens, embed_size)
+            self.embedding_proj = Linear(embed_size, d_hidden, bias=False)
+            self.lm_head = Linear(embed_size, num_tokens, bias=False)
+        else:
+            self.embedding = nn.Embedding(num_tokens, d_hidden)
+            self.lm_head = Linear(d_hidden, num_tokens, bias=False)
+        self.lm_head.weight = self.embedding.weight  # tied (models.py:117)
+        self.decoder = _decoder_stack(d_hidden, n_head, dropout, n_layers)
+        if self.use_speaker_head:
+            self.spk_enc_proj = Linear(tds_sizes[-1], d_hidden)
+            self.spk_decoder = _decoder_stack(d_hidden, n_head, dropout, n_layers // 2)
+            self.speaker_head = nn.Sequential(Linear(d_hidden, spk_embed), Linear(spk_embed, num_speakers))
+        self.apply(weight_init())
+        self.eval()
+
+    def get_encoder_params(self):
+        return list(self.encoder.parameters())
+
+    def extract_features(self, x, specaug=True):
+        return self.logmelspec(x)
+
+    def encode_features(self, x: torch.Tensor, audio_lens: torch.LongTensor = None):
+        x = self.encoder.forward_time_major(x)
+        spk_h = ops.linear(x, self.spk_enc_proj.weight, self.spk_enc_proj.bias) if self.use_speaker_head else None
+        x = ops.linear(x, self.decoder_proj.weight, self.decoder_proj.bias)
+        mask = None if audio_lens is None else padding_mask(audio_lens, x.size(1), x.device)
+        return {"speaker_out": spk_h, "encoder_out": x, "encoder_padding_mask": mask}
+
+    def encode(self, x: torch.Tensor, audio_lens: torch.LongTensor = None):
+        return self.encode_features(self.extract_features(x), audio_lens)
+
+    def decode(self, y_prev, encoder_out, past=None, causal_mask=True):
+        from .decoder import asr_decode
+        return asr_decode(self, y_prev, encoder_out, causal_mask)
+
+    def decode_spk(self, y_prev, encoder_out, causal_mask=True):
+        from .decoder import asr_decode_spk
+        return asr_decode_spk(self, y_prev, encoder_out, causal_mask)
+
+    def forward(self, x, y_prev, audio_lens):
+        encoder_out = self.encode(x, audio_lens)
+        lm_out = self.decode(y_prev, encoder_out)
+        spk_out = self.decode_spk(y_prev, encoder_out) if self.use_speaker_head else None
+        return (lm_out, spk_out), encoder_out
+
+
+class TransformerDecoder(nn.Module):
+    """Layer stack with the key layout of nn.TransformerDecoder (`layers.N.*`, norm=None) and the
+    plain torch-1.4 loop the reference was written against."""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+        self.num_layers = len(layers)
+        self.norm = None
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None):
+        out = tgt
+        for layer in self.layers:
+            out = layer(out, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                        tgt_key_padding_mask=tgt_key_padding_mask,
+                        memory_key_padding_mask=memory_key_padding_mask)
+        return out
+
+
+def _decoder_stack(d_model, n_head, dropout, n_layers):
+    return TransformerDecoder([ModRZTXDecoderLayer(d_model=d_model, dim_feedforward=d_model * 4, nhead=n_head,
+                                                   dropout=dropout, activation="relu") for _ in range(n_layers)])

@@ -1,0 +1,167 @@
+"""Tensor-level wrappers over the C-ABI (include/tal_asrd.h).  torch is used only
+for device memory and the current HIP stream; every op below is a hand-written
+HIP kernel and raises if the native library or a GPU is missing.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _f32c(t, what):
+    N.require_cuda(t, what)
+    if t.dtype != torch.float32:
+        raise N.NativeError("%s: expected float32, got %s (the reference's .half() casts are GPU-era AMP "
+                            "conventions; this path computes in fp32)" % (what, t.dtype))
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------ log-mel
+def logmel_plan(window, fb):
+    """Device plan (Hann-folded DFT basis + sparse mel filters) for tal_logmel_fwd."""
+    lib = N.lib()
+    window = _f32c(window, "logmel_plan(window)")
+    fb = _f32c(fb, "logmel_plan(fb)")
+    if tuple(window.shape) != (400,) or tuple(fb.shape) != (201, 80):
+        raise N.NativeError("logmel_plan: window/fb must be [400] and [201, 80], got %s %s"
+                            % (tuple(window.shape), tuple(fb.shape)))
+    plan = torch.empty(lib.tal_logmel_plan_bytes(), dtype=torch.uint8, device=window.device)
+    N.check(lib.tal_logmel_plan_init(N.ptr(window), N.ptr(fb), N.ptr(plan), N.stream_handle()),
+            "tal_logmel_plan_init")
+    return plan
+
+
+def logmel(plan, audio, eps=1e-6, subtract_mean=True, return_stats=False):
+    """audio [B, L] -> [B, T, 80] (LogMelSpec.forward, tal/asr/models.py:35-53)."""
+    lib = N.lib()
+    audio = _f32c(audio, "logmel")
+    if audio.dim() != 2:
+        raise N.NativeError("logmel: audio must be [batch, samples]")
+    B, L = audio.shape
+    T = lib.tal_logmel_num_frames(L)
+    out = torch.empty(B, T, 80, dtype=torch.float32, device=audio.device)
+    mean = torch.empty(1, dtype=torch.float32, device=audio.device)
+    stats = torch.empty(2, dtype=torch.float64, device=audio.device)
+    nws = lib.tal_logmel_workspace_bytes(B, L)
+    ws = _ws(nws, audio.device)
+    N.check(lib.tal_logmel_fwd(N.ptr(plan), N.ptr(audio), B, L, eps, 1 if subtract_mean else 0, N.ptr(out),
+                               N.ptr(mean), N.ptr(stats), N.ptr(ws), nws, N.stream_handle()), "tal_logmel_fwd")
+    return (out, mean, stats) if return_stats else out
+
+
+def subtract_scalar_(x, mean):
+    lib = N.lib()
+    N.check(lib.tal_subtract_scalar(N.ptr(x), x.numel(), N.ptr(mean), N.stream_handle()), "tal_subtract_scalar")
+    return x
+
+
+# ------------------------------------------------------------------ dense
+def linear(x, weight, bias=None, mode=0, res=None, alpha=0.0, out=None):
+    """y = epilogue(x . W^T + b) over the last dim; weight [N, K] (nn.Linear / 1x1 Conv1d layout)."""
+    lib = N.lib()
+    x = _f32c(x, "linear")
+    w2 = weight.reshape(weight.shape[0], -1)
+    w2 = _f32c(w2, "linear(weight)")
+    K = x.shape[-1]
+    Nout = w2.shape[0]
+    if w2.shape[1] != K:
+        raise N.NativeError("linear: x[..., %d] vs weight %s" % (K, tuple(weight.shape)))
+    M = x.numel() // K
+    y = out if out is not None else torch.empty(*x.shape[:-1], Nout, dtype=torch.float32, device=x.device)
+    if res is not None:
+        res = _f32c(res, "linear(res)")
+    if bias is not None:
+        bias = _f32c(bias, "linear(bias)")
+    N.check(lib.tal_linear_fwd(N.ptr(x), N.ptr(w2), N.ptr(bias), N.ptr(res), float(alpha), int(mode), M, Nout, K,
+                               N.ptr(y), N.stream_handle()), "tal_linear_fwd")
+    return y
+
+
+# ------------------------------------------------------------------ grouped conv
+def pack_gconv_weight(weight, groups):
+    """reference Conv1d weight [C_out, C_in/G, 21] -> packed [G][C_in/G][21][C_out/G]."""
+    lib = N.lib()
+    w = _f32c(weight, "pack_gconv_weight")
+    c_out, cig, ks = w.shape
+    packed = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    N.check(lib.tal_pack_gconv_weight(N.ptr(w), N.ptr(packed), c_out, cig, ks, groups, N.stream_handle()),
+            "tal_pack_gconv_weight")
+    return packed
+
+
+def gconv_s2(x, w_packed, bias, c_out, groups):
+    """x [B, T, C_in] -> [B, (T-21)//2+1, C_out] (tal/asr/models.py:363-364)."""
+    lib = N.lib()
+    x = _f32c(x, "gconv_s2")
+    B, T, c_in = x.shape
+    y = torch.empty(B, (T - 21) // 2 + 1, c_out, dtype=torch.float32, device=x.device)
+    N.check(lib.tal_gconv_s2_fwd(N.ptr(x), N.ptr(w_packed), N.ptr(bias), B, T, c_in, c_out, groups, N.ptr(y),
+                                 N.stream_handle()), "tal_gconv_s2_fwd")
+    return y
+
+
+def gconv_res(x, w_packed, bias, alpha, groups):
+    """x + alpha * relu(gconv21(x)) on [B, T, C] (tal/asr/models.py:304-308,329)."""
+    lib = N.lib()
+    x = _f32c(x, "gconv_res")
+    B, T, c = x.shape
+    y = torch.empty_like(x)
+    N.check(lib.tal_gconv_res_fwd(N.ptr(x), N.ptr(w_packed), N.ptr(bias), float(alpha), B, T, c, groups, N.ptr(y),
+                                  N.stream_handle()), "tal_gconv_res_fwd")
+    return y
+
+
+# ------------------------------------------------------------------ TDS driver
+def tds_forward(desc, x, c_out):
+    """x [B, T, C0] -> [B, T', C_last] through tal_tds_fwd (whole encoder, one C call)."""
+    lib = N.lib()
+    x = _f32c(x, "tds_forward")
+    B, T, _ = x.shape
+    t_out = lib.tal_tds_out_len(C.byref(desc), T)
+    if t_out <= 0:
+        raise N.NativeError("tds_forward: %d frames are too few for the stride-2 k=21 stages" % T)
+    y = torch.empty(B, t_out, c_out, dtype=torch.float32, device=x.device)
+    nws = lib.tal_tds_workspace_bytes(C.byref(desc), B, T)
+    ws = _ws(nws, x.device)
+    N.check(lib.tal_tds_fwd(C.byref(desc), N.ptr(x), B, T, N.ptr(y), N.ptr(ws), nws, N.stream_handle()),
+            "tal_tds_fwd")
+    return y
+
+
+# ------------------------------------------------------------------ diarization head
+def sd_head(x, w_embed, b_embed, w_logit, b_logit, want_logits=True, want_ids=True):
+    """x [..., C] -> (feat [..., E], logits [..., S] | None, ids [...] int32 | None)."""
+    lib = N.lib()
+    x = _f32c(x, "sd_head")
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    E, S = w_embed.shape[0], w_logit.shape[0]
+    dev = x.device
+    feat = torch.empty(*x.shape[:-1], E, dtype=torch.float32, device=dev)
+    logits = torch.empty(*x.shape[:-1], S, dtype=torch.float32, device=dev) if want_logits else None
+    ids = torch.empty(x.shape[:-1], dtype=torch.int32, device=dev) if want_ids else None
+    nws = lib.tal_sd_head_workspace_bytes(M, S) if (want_ids and not want_logits) else 0
+    ws = _ws(nws, dev)
+    N.check(lib.tal_sd_head_fwd(N.ptr(x), M, Cc, N.ptr(_f32c(w_embed, "w")), N.ptr(b_embed), E,
+                                N.ptr(_f32c(w_logit, "w")), N.ptr(b_logit), S, N.ptr(feat), N.ptr(logits),
+                                N.ptr(ids), N.ptr(ws), nws, N.stream_handle()), "tal_sd_head_fwd")
+    return feat, logits, ids
+
+
+def argmax_rows(x):
+    lib = N.lib()
+    x = _f32c(x, "argmax_rows")
+    Nn = x.shape[-1]
+    M = x.numel() // Nn
+    ids = torch.empty(x.shape[:-1], dtype=torch.int32, device=x.device)
+    N.check(lib.tal_argmax_rows(N.ptr(x), M, Nn, N.ptr(ids), N.stream_handle()), "tal_argmax_rows")
+    return ids
+
+
+def add_positional(x, pe):
+    raise N.NativeError("add_positional: decoder kernels are not built yet")

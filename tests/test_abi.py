@@ -1,0 +1,121 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol
+include/tal_asrd.h declares, the Python mirror keeps the reference's state_dict keys,
+host logic (padding mask, frame counts) matches the oracle, and the product path
+refuses to run without a GPU instead of silently falling back."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import GOLDEN, ROOT
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "tal_asrd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tal_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_matches_binding_table():
+    from tal_asrd_amd import _native
+    assert _header_symbols() == sorted(_native.SIGNATURES)
+
+
+def test_library_exports_every_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from tal_asrd_amd import _native
+    lib = _native.lib()
+    for name in _header_symbols():
+        assert hasattr(lib, name), name
+    assert lib.tal_version() >= 100
+    assert lib.tal_logmel_num_frames(480000) == 3001
+    assert lib.tal_logmel_num_frames(15999) == 100
+    assert lib.tal_logmel_plan_bytes() > 0
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirror of tal_tds_desc must have the C layout (8-byte pointers, natural alignment)."""
+    import ctypes as C
+    from tal_asrd_amd import _native
+    assert C.sizeof(_native.TdsBlockW) == 6 * 8 + 8
+    expect = 4 + 4 + 5 * 4 + 4 * 4          # ints
+    expect = (expect + 7) // 8 * 8           # align for pointers
+    expect += 4 * 8 * 2 + 4 * 8 * C.sizeof(_native.TdsBlockW)
+    assert C.sizeof(_native.TdsDesc) == expect
+
+
+def test_error_path_no_gpu_needed():
+    """Argument validation happens before any launch, so it is testable on CPU."""
+    import ctypes as C
+    from tal_asrd_amd import _native
+    lib = _native.lib()
+    rc = lib.tal_linear_fwd(None, None, None, None, 0.0, 0, 4, 4, 4, None, None)
+    assert rc == -1
+    assert b"null pointer" in lib.tal_last_error()
+    d = _native.TdsDesc()
+    d.n_stages = 9
+    assert lib.tal_tds_workspace_bytes(C.byref(d), 1, 100) >= 0
+    rc = lib.tal_tds_fwd(C.byref(d), None, 1, 100, None, None, 0, None)
+    assert rc == -1 and b"n_stages" in lib.tal_last_error()
+
+
+@pytest.mark.parametrize("name,ctor", [
+    ("SDModel", lambda m: m.SDModel()),
+    ("ASRModel_2x_spk", lambda m: m.ASRModel("2x", num_speakers=6008, use_speaker_head=True)),
+    ("ASRModel_1x_tok", lambda m: m.ASRModel("1x", num_speakers=40, use_speaker_head=False)),
+])
+def test_state_dict_keys_match_reference(name, ctor):
+    from tal_asrd_amd import models
+    ref = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))[name]
+    own = [[k, list(v.shape)] for k, v in ctor(models).state_dict().items()]
+    assert own == ref
+
+
+def test_buffers_match_oracle():
+    from oracle import tal_oracle as O
+    from tal_asrd_amd import models, modules
+    m = models.LogMelSpec()
+    np.testing.assert_array_equal(m.mel_transform.mel_scale.fb.numpy(), O.mel_filterbank().numpy())
+    np.testing.assert_allclose(m.mel_transform.spectrogram.window.numpy(), O.hann_window().numpy(), atol=1e-7)
+    np.testing.assert_array_equal(modules.sinusoid_table(32, 64).numpy(), O.positional_encoding(32, 64).numpy())
+
+
+def test_padding_mask_host_logic():
+    from oracle import tal_oracle as O
+    from tal_asrd_amd import padding_mask
+    for lens, t in (([480000, 400000], 358), ([4800000, 123457, 4800000], 3733), ([16000], 8)):
+        got = padding_mask(torch.tensor(lens), t, "cpu").numpy()
+        np.testing.assert_array_equal(got, O.padding_mask(lens, t))
+
+
+def test_no_cpu_fallback():
+    from tal_asrd_amd import NativeError, SDModel
+    m = SDModel()
+    with pytest.raises(NativeError):
+        m.encode(torch.zeros(1, 16000))
+    with pytest.raises(NativeError):
+        m.spk_embed_proj(torch.zeros(4, 1440))
+
+
+def test_product_does_not_import_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "tal_asrd_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+
+
+def test_synth_is_deterministic():
+    from tal_asrd_amd import synth
+    a = synth.synth_audio(16000, 7)
+    b = synth.synth_audio(16000, 7)
+    np.testing.assert_array_equal(a, b)
+    assert abs(a).max() <= 0.5 and (a == 0).sum() > 1000
+    w = synth.fill_state_dict({"x.weight": (4, 8), "x.bias": (4,), "b.resweight": (1,)})
+    assert w["x.weight"].shape == (4, 8) and 0.2 <= float(w["b.resweight"][0]) <= 0.32
+    assert abs(w["x.weight"]).max() <= 1 / np.sqrt(8)

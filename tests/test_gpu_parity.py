@@ -1,0 +1,242 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Every call goes through the
+C-ABI library (ctypes); the oracle / golden fixtures are the checker only."""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden, has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+LOGIT_TOL = 1e-3   # BASELINE.json: logits within 1e-3 fp32 of the reference CPU path
+MEL_TOL = 1e-3     # log-mel domain (SURVEY.md section 7 minimum slice)
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _load(model, sd):
+    own = model.state_dict()
+    for k, v in sd.items():
+        assert k in own, k
+        own[k] = torch.from_numpy(np.array(v, copy=True))
+    model.load_state_dict(own)
+    return model.to(dev())
+
+
+@pytest.fixture(scope="module")
+def sd_model(sd_weights):
+    from tal_asrd_amd import SDModel
+    return _load(SDModel(), sd_weights)
+
+
+@pytest.fixture(scope="module")
+def asr_model(asr_weights):
+    from tal_asrd_amd import ASRModel
+    return _load(ASRModel("2x", num_speakers=6008, vocab_size=10000, use_speaker_head=True), asr_weights)
+
+
+# ------------------------------------------------------------------ dense layer
+@pytest.mark.parametrize("M,N,K,mode", [
+    (128, 160, 32, 0), (1, 1, 4, 0), (130, 161, 36, 1), (257, 800, 800, 2), (64, 6008, 128, 0),
+    (513, 1440, 1440, 1), (7, 512, 2048, 2), (300, 24, 16, 0),
+])
+def test_linear_matches_fp64(M, N, K, mode):
+    """Asymmetric random operands (transpose-detecting), fp64 host reference."""
+    from tal_asrd_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = x.double() @ w.double().t() + b.double()
+    if mode == 1:
+        ref = ref.clamp_min(0)
+    if mode == 2:
+        ref = res.double() + 0.3 * ref
+    y = ops.linear(x.to(dev()), w.to(dev()), b.to(dev()), mode=mode, res=res.to(dev()) if mode == 2 else None,
+                   alpha=0.3)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), atol=2e-5 * max(1.0, K ** 0.5 / 8), rtol=1e-5)
+
+
+def test_linear_identity_asymmetric():
+    """A = I against an asymmetric W catches a transposed C write."""
+    from tal_asrd_amd import ops
+    K = 160
+    w = torch.arange(K * K, dtype=torch.float32).reshape(K, K) / 1000.0
+    y = ops.linear(torch.eye(K).to(dev()), w.to(dev()))
+    np.testing.assert_array_equal(y.cpu().numpy(), w.t().numpy())
+
+
+# ------------------------------------------------------------------ log-mel
+@pytest.mark.parametrize("B,L", [(1, 16000), (2, 15999), (1, 480000), (3, 4000), (1, 201), (1, 5281)])
+def test_logmel_matches_oracle(B, L):
+    from oracle import tal_oracle as O
+    from tal_asrd_amd import LogMelSpec, synth
+    audio = synth.synth_audio_batch(B, L, 99)
+    m = LogMelSpec().to(dev())
+    y = m(torch.from_numpy(audio).to(dev()))
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (B, 1 + L // 160, 80)
+    ref32 = O.logmel(audio).numpy()
+    ref64 = O.logmel_f64(audio)
+    got = y.cpu().numpy()
+    assert np.abs(got - ref32).max() < MEL_TOL
+    assert np.abs(got - ref64).max() < MEL_TOL
+    assert abs(float(got.astype(np.float64).mean())) < 1e-5   # global mean removed
+
+
+def test_logmel_silence_and_stats():
+    """All-zero audio -> every value log(eps), mean subtracted -> exactly 0; stats expose (sum,count)."""
+    from tal_asrd_amd import LogMelSpec, ops
+    m = LogMelSpec().to(dev())
+    a = torch.zeros(2, 8000, device=dev())
+    y = m(a)
+    assert float(y.abs().max()) < 1e-6
+    raw, mean, stats = ops.logmel(m.plan(), a, subtract_mean=False, return_stats=True)
+    np.testing.assert_allclose(raw.cpu().numpy(), np.log(np.float32(1e-6)), rtol=1e-6)
+    assert stats[1].item() == 2 * 51 * 80
+    np.testing.assert_allclose(stats[0].item() / stats[1].item(), mean.item(), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ grouped convs
+@pytest.mark.parametrize("cig,cog,T,B", [(1, 10, 333, 2), (10, 14, 300, 1), (14, 18, 277, 2), (2, 3, 64, 1)])
+def test_gconv_s2_matches_torch(cig, cog, T, B):
+    from tal_asrd_amd import ops
+    G = 80 if cig != 2 else 8
+    g = torch.Generator().manual_seed(cig * 100 + cog)
+    x = torch.randn(B, G * cig, T, generator=g)
+    w = torch.randn(G * cog, cig, 21, generator=g) / (21 * cig) ** 0.5
+    b = torch.randn(G * cog, generator=g)
+    ref = torch.nn.functional.conv1d(x.double(), w.double(), b.double(), stride=2, groups=G).permute(0, 2, 1)
+    wp = ops.pack_gconv_weight(w.to(dev()), G)
+    y = ops.gconv_s2(x.permute(0, 2, 1).contiguous().to(dev()), wp, b.to(dev()), G * cog, G)
+    np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("cg,T,B", [(10, 700, 2), (14, 256, 1), (18, 300, 2), (18, 5, 1), (4, 50, 2)])
+def test_gconv_res_matches_torch(cg, T, B):
+    from tal_asrd_amd import ops
+    G = 80 if cg != 4 else 8
+    g = torch.Generator().manual_seed(cg)
+    x = torch.randn(B, G * cg, T, generator=g)
+    w = torch.randn(G * cg, cg, 21, generator=g) / (21 * cg) ** 0.5
+    b = torch.randn(G * cg, generator=g)
+    xd = x.double()
+    ref = (xd + 0.25 * torch.relu(torch.nn.functional.conv1d(xd, w.double(), b.double(), padding=10, groups=G)))
+    wp = ops.pack_gconv_weight(w.to(dev()), G)
+    y = ops.gconv_res(x.permute(0, 2, 1).contiguous().to(dev()), wp, b.to(dev()), 0.25, G)
+    np.testing.assert_allclose(y.cpu().double().numpy(), ref.permute(0, 2, 1).numpy(), atol=2e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ golden: small TDS / block through the module API
+def test_tds_small_golden():
+    from tal_asrd_amd import TDS, synth
+    g = golden("tds_small")
+    m = TDS(input_size=8, sizes=[8, 16, 24, 32], depths=[1, 1, 2], kernel_size=21)
+    sd = synth.fill_state_dict({"tds_small." + k: tuple(v.shape) for k, v in m.state_dict().items()})
+    _load(m, {k[len("tds_small."):]: v for k, v in sd.items()})
+    y = m(torch.from_numpy(g["x"]).to(dev()))
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], atol=2e-5, rtol=0)
+
+
+def test_tdsblock_golden():
+    from tal_asrd_amd import TDSBlock, synth
+    g = golden("tdsblock")
+    m = TDSBlock(32, 21, 8)
+    sd = synth.fill_state_dict({"tdsblock." + k: tuple(v.shape) for k, v in m.state_dict().items()})
+    _load(m, {k[len("tdsblock."):]: v for k, v in sd.items()})
+    y = m(torch.from_numpy(g["x"]).to(dev()))
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], atol=2e-5, rtol=0)
+
+
+# ------------------------------------------------------------------ golden: full SD path (configs 1 and 2)
+def _check_sd_golden(model, name, with_lens):
+    from tal_asrd_amd import synth
+    g = golden(name)
+    B, L = int(g["batch"]), int(g["audio_len"])
+    lens = g["audio_lens"].tolist() if with_lens else None
+    audio = torch.from_numpy(synth.synth_audio_batch(B, L, int(g["audio_seed"]), lens=lens)).to(dev())
+    with torch.no_grad():
+        mel = model.extract_features(audio)
+        np.testing.assert_allclose(mel[:, g["mel_rows"]].cpu().numpy(), g["mel_sample"], atol=MEL_TOL, rtol=0)
+        enc = model.encode_features(mel, None if lens is None else torch.tensor(lens))
+        eo = enc["encoder_out"]
+        np.testing.assert_allclose(eo[:, g["enc_rows"]].cpu().numpy(), g["enc_sample"], atol=LOGIT_TOL, rtol=0)
+        np.testing.assert_allclose(eo.double().sum(dim=1).cpu().numpy(), g["enc_chan_sum"], atol=5e-2, rtol=1e-4)
+        logits = model.decode(enc)
+        np.testing.assert_allclose(logits[:, g["logit_rows"]].cpu().numpy(), g["logit_sample"], atol=LOGIT_TOL, rtol=0)
+        np.testing.assert_allclose(logits.max(-1).values.cpu().numpy(), g["logit_max"], atol=LOGIT_TOL, rtol=0)
+        feat = model.spk_embed_proj(eo)
+        if "feat" in g.files and g["feat"].shape[1] == feat.shape[1]:
+            np.testing.assert_allclose(feat.cpu().numpy(), g["feat"], atol=LOGIT_TOL, rtol=0)
+        from tal_asrd_amd import ops
+        ids = ops.argmax_rows(logits).cpu().numpy()
+        np.testing.assert_array_equal(ids, logits.argmax(-1).cpu().numpy())   # argmax kernel == torch.argmax
+        bad = ids != g["ids"]
+        assert not (bad & (g["margin"] > LOGIT_TOL)).any(), "speaker id differs away from a near-tie"
+        assert bad.sum() <= 2
+        if with_lens:
+            np.testing.assert_array_equal(enc["encoder_padding_mask"].cpu().numpy(), g["mask"])
+    return float(np.abs(logits[:, g["logit_rows"]].cpu().numpy() - g["logit_sample"]).max())
+
+
+def test_sd_30s_golden(sd_model):
+    err = _check_sd_golden(sd_model, "sd_30s", False)
+    print("sd_30s max logit err %.3e" % err)
+
+
+def test_sd_b2_ragged_golden(sd_model):
+    _check_sd_golden(sd_model, "sd_b2_ragged", True)
+
+
+def test_sd_5min_golden(sd_model):
+    _check_sd_golden(sd_model, "sd_5min", False)
+
+
+def test_speaker_ids_fused_path(sd_model):
+    """reconcile.get_speaker_ids form: ids without materialised logits == ids with logits."""
+    from tal_asrd_amd import synth
+    g = golden("sd_30s")
+    audio = torch.from_numpy(synth.synth_audio_batch(1, 480000, 1234)).to(dev())
+    feat, ids = sd_model.speaker_ids(audio)
+    feat2, ids2, logits = sd_model.speaker_ids(audio, want_logits=True)
+    np.testing.assert_array_equal(ids.cpu().numpy(), ids2.cpu().numpy())
+    np.testing.assert_allclose(feat.cpu().numpy(), g["feat"], atol=LOGIT_TOL, rtol=0)
+    assert (ids.cpu().numpy() != g["ids"]).sum() == 0
+
+
+def test_asr_encode_golden(asr_model):
+    from tal_asrd_amd import synth
+    g = golden("asr_enc_b2")
+    lens = g["audio_lens"].tolist()
+    audio = torch.from_numpy(synth.synth_audio_batch(2, 480000, 1234, lens=lens)).to(dev())
+    with torch.no_grad():
+        enc = asr_model.encode(audio, torch.tensor(lens))
+    r = g["rows"]
+    np.testing.assert_allclose(enc["encoder_out"][:, r].cpu().numpy(), g["encoder_out"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(enc["speaker_out"][:, r].cpu().numpy(), g["speaker_out"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_array_equal(enc["encoder_padding_mask"].cpu().numpy(), g["mask"])
+
+
+# ------------------------------------------------------------------ size-independent properties at full size
+def test_time_shift_equivariance_full_size(sd_model):
+    """Interior encoder frames depend only on their receptive field (output c <- mel frames
+    [8c-640, 8c+780]): shifting the mel input by 8 frames shifts the output by 1."""
+    g = torch.Generator().manual_seed(5)
+    mel = torch.randn(1, 30001, 80, generator=g).to(dev())
+    a = sd_model.encoder.forward_time_major(mel)
+    b = sd_model.encoder.forward_time_major(mel[:, 8:].contiguous())
+    lo, hi = 100, a.shape[1] - 120
+    np.testing.assert_allclose(a[0, lo + 1:hi + 1].cpu().numpy(), b[0, lo:hi].cpu().numpy(), atol=2e-4, rtol=0)
+
+
+def test_batch_items_independent(sd_model):
+    """Encoder output of a batch item does not depend on its neighbours (zero padding is per item)."""
+    g = torch.Generator().manual_seed(6)
+    mel = torch.randn(3, 2000, 80, generator=g).to(dev())
+    full = sd_model.encoder.forward_time_major(mel)
+    one = sd_model.encoder.forward_time_major(mel[1:2].contiguous())
+    np.testing.assert_array_equal(full[1].cpu().numpy(), one[0].cpu().numpy())

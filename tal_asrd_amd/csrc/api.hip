@@ -189,29 +189,36 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
     const size_t nf = tds_buf_floats(d, B, T);
     float* buf[3] = {reinterpret_cast<float*>(workspace), reinterpret_cast<float*>(workspace) + nf,
                      reinterpret_cast<float*>(workspace) + 2 * nf};
+    // three rotating buffers; `ia` = index of the buffer holding the live activations (-1: caller's x).
+    // No launch ever reads and writes the same buffer (workgroups read halos of their neighbours).
     const float* cur = x;
+    int ia = -1;
     int64_t Tc = T;
     for (int i = 0; i < d->n_stages; ++i) {
         const int cin = d->channels[i], c = d->channels[i + 1];
         const int64_t To = conv_out_len(Tc);
         const bool last_stage = i == d->n_stages - 1;
-        // resize conv: cur -> a
-        float* a = (last_stage && d->depths[i] == 0) ? y : buf[0];
+        // resize conv: cur -> a (a buffer other than cur's)
+        const int io = (ia + 1) % 3;
+        float* a = (last_stage && d->depths[i] == 0) ? y : buf[io];
         rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s);
         if (rc) return rc;
+        ia = io;
         const int64_t M = (int64_t)B * To;
         for (int j = 0; j < d->depths[i]; ++j) {
             const tal_tds_block_w& bw = d->blocks[i][j];
             TAL_CHECK_ARG(bw.conv_w && bw.conv_b && bw.fc0_w && bw.fc0_b && bw.fc3_w && bw.fc3_b, "tal_tds_fwd: null weight in block %d.%d", i, j);
-            // x1 = x + rw * relu(gconv(x))            : a -> buf[1]
-            rc = launch_gconv_res(a, bw.conv_w, bw.conv_b, bw.resweight, B, To, c, d->groups, buf[1], s);
+            float* x1 = buf[(ia + 1) % 3];
+            float* h = buf[(ia + 2) % 3];
+            // x1 = x + rw * relu(gconv(x))            : a -> x1
+            rc = launch_gconv_res(a, bw.conv_w, bw.conv_b, bw.resweight, B, To, c, d->groups, x1, s);
             if (rc) return rc;
-            // h = relu(fc0(x1))                        : buf[1] -> buf[2]
-            rc = launch_linear(buf[1], bw.fc0_w, bw.fc0_b, nullptr, 0.f, 1, M, c, c, buf[2], s);
+            // h = relu(fc0(x1))                        : x1 -> h
+            rc = launch_linear(x1, bw.fc0_w, bw.fc0_b, nullptr, 0.f, 1, M, c, c, h, s);
             if (rc) return rc;
-            // x2 = x1 + rw * fc3(h)                    : buf[2] (+res buf[1]) -> a'
-            float* outp = (last_stage && j == d->depths[i] - 1) ? y : buf[0];
-            rc = launch_linear(buf[2], bw.fc3_w, bw.fc3_b, buf[1], bw.resweight, 2, M, c, c, outp, s);
+            // x2 = x1 + rw * fc3(h)                    : h (+res x1) -> a's buffer (dead since the gconv)
+            float* outp = (last_stage && j == d->depths[i] - 1) ? y : buf[ia];
+            rc = launch_linear(h, bw.fc3_w, bw.fc3_b, x1, bw.resweight, 2, M, c, c, outp, s);
             if (rc) return rc;
             a = outp;
         }

@@ -6,10 +6,14 @@
 // One workgroup = 32 consecutive frames of one batch item.  The 5360 samples the frames
 // span are read once, coalesced, into LDS (reflect indexing resolved at load time; one pad
 // word per hop keeps the frame-strided MFMA operand reads conflict-free).  The windowed DFT
-// is a [32 x 400] . [400 x (re|im) x 224] contraction on the fp32 matrix cores against a
-// Hann-folded twiddle table that stays L2-resident (0.7 MB), so there is no per-sample
-// window multiply and no bit-reversal traffic; re/im of a bin land in the same lane of two
-// accumulators, so the power spectrum is formed in registers.  The (sparse, triangular) mel
+// is a [32 x 400] . [400 x (re|im) x 208] contraction on the FP64 matrix cores
+// (v_mfma_f64_16x16x4_f64) against a Hann-folded float64 twiddle table that stays L2-resident
+// (1.3 MB): no per-sample window multiply, no bit-reversal traffic, and -- the reason for
+// fp64 -- no fp32 round-off in the 400-term sums.  Near-silent frames have mel power within
+// a few 1e-6 of eps, where an fp32 matrix-DFT is off by up to 1e-3 in the log domain (measured;
+// the reference's fp32 FFT is off by 2e-4 from the float64 truth, this kernel by ~1e-7).  The
+// front-end is ~2 % of the path's time, so fp64 costs nothing visible.  re/im of a bin land
+// in the same lane of two accumulators, so the power spectrum is formed in registers.  The (sparse, triangular) mel
 // projection, the log and the partial sum for the global mean are done from an LDS copy of
 // the power tile; the output is written once, coalesced, as [B, T, 80].
 #include <math.h>
@@ -25,14 +29,14 @@ constexpr int HOP = 160;
 constexpr int NBIN = 201;
 constexpr int NMEL = 80;
 constexpr int FB = 32;                         // frames per workgroup
-constexpr int NTILE = 7;                       // 7 x 32 = 224 >= 201 bins
+constexpr int NTILE = 13;                      // 13 x 16 = 208 >= 201 bins
 constexpr int NS = (FB - 1) * HOP + NFFT;      // 5360 samples per workgroup
 constexpr int NSP = NS + NS / HOP + 2;         // + one pad word per hop
-constexpr int PLD = NTILE * 32 + 1;            // power tile pitch (225)
+constexpr int PLD = NTILE * 16 + 1;            // power tile pitch (209)
 constexpr int MAXW = 48;                       // max mel filter support in bins
 
 struct LogmelPlan {
-    float basis[NTILE * NFFT * 2 * 32];  // [tile][n][re|im][32 bins], Hann folded in
+    double basis[NTILE * NFFT * 2 * 16];  // [tile][n][re|im][16 bins], Hann folded in
     int mel_lo[NMEL];
     int mel_cnt[NMEL];
     float mel_w[NMEL * MAXW];
@@ -62,27 +66,36 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelPlan* __restric
     }
     __syncthreads();
 
-    const int fi = lane & 31;  // frame (A row) / bin (B col) index inside the tile
-    const int kh = lane >> 5;  // which of the 2 k's of a 32x32x2 step
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    const int fi = lane & 15;  // frame (A row) / bin (B col) index inside a 16x16 tile
+    const int kq = lane >> 4;  // which of the 4 k's of a 16x16x4 step
     for (int j = w; j < NTILE; j += 4) {
-        f32x16 are, aim;
+        f64x4 re0 = {0., 0., 0., 0.}, im0 = re0, re1 = re0, im1 = re0;
+        const double* bp = plan->basis + ((int64_t)j * NFFT + kq) * 32 + fi;
+        const float* sp0 = samp + fi * (HOP + 1) + kq;
+        const float* sp1 = sp0 + 16 * (HOP + 1);
+#pragma unroll 1
+        for (int k0 = 0; k0 < NFFT; k0 += 40) {       // 40 | HOP: a chunk never straddles a pad word
+            const int base = k0 + k0 / HOP;           // (k + kq) / HOP == k0 / HOP inside the chunk
+            const double* bq = bp + k0 * 32;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) are[e] = aim[e] = 0.f;
-        const float* bp = plan->basis + (int64_t)j * NFFT * 64 + kh * 64 + fi;
-        const float* sp = samp + fi * (HOP + 1) + kh;
-#pragma unroll 8
-        for (int s2 = 0; s2 < NFFT / 2; ++s2) {
-            const int k = 2 * s2;
-            const float a = sp[k + (k + kh) / HOP];
-            const float br = bp[k * 64];
-            const float bi = bp[k * 64 + 32];
-            are = __builtin_amdgcn_mfma_f32_32x32x2f32(a, br, are, 0, 0, 0);
-            aim = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bi, aim, 0, 0, 0);
+            for (int kk = 0; kk < 40; kk += 4) {
+                const double a0 = (double)sp0[base + kk];
+                const double a1 = (double)sp1[base + kk];
+                const double br = bq[kk * 32];
+                const double bi = bq[kk * 32 + 16];
+                re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, br, re0, 0, 0, 0);
+                im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bi, im0, 0, 0, 0);
+                re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, br, re1, 0, 0, 0);
+                im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bi, im1, 0, 0, 0);
+            }
         }
+        // f64 16x16 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int frame = (e & 3) + 8 * (e >> 2) + 4 * kh;
-            P[frame * PLD + j * 32 + fi] = are[e] * are[e] + aim[e] * aim[e];
+        for (int e = 0; e < 4; ++e) {
+            const int frame = kq + 4 * e;
+            P[frame * PLD + j * 16 + fi] = (float)(re0[e] * re0[e] + im0[e] * im0[e]);
+            P[(frame + 16) * PLD + j * 16 + fi] = (float)(re1[e] * re1[e] + im1[e] * im1[e]);
         }
     }
     __syncthreads();
@@ -180,8 +193,8 @@ extern "C" int tal_logmel_plan_init(const float* window, const float* fb, void* 
     const double two_pi = 6.283185307179586476925286766559;
     for (int j = 0; j < NTILE; ++j)
         for (int n = 0; n < NFFT; ++n)
-            for (int c = 0; c < 32; ++c) {
-                const int bin = j * 32 + c;
+            for (int c = 0; c < 16; ++c) {
+                const int bin = j * 16 + c;
                 double re = 0.0, im = 0.0;
                 if (bin < NBIN) {
                     const int ph = (int)(((int64_t)bin * n) % NFFT);  // exact phase reduction
@@ -189,8 +202,8 @@ extern "C" int tal_logmel_plan_init(const float* window, const float* fb, void* 
                     re = (double)hwin[n] * cos(ang);
                     im = -(double)hwin[n] * sin(ang);
                 }
-                hp->basis[((j * NFFT + n) * 2 + 0) * 32 + c] = (float)re;
-                hp->basis[((j * NFFT + n) * 2 + 1) * 32 + c] = (float)im;
+                hp->basis[((j * NFFT + n) * 2 + 0) * 16 + c] = re;
+                hp->basis[((j * NFFT + n) * 2 + 1) * 16 + c] = im;
             }
     for (int m = 0; m < NMEL; ++m) {
         int lo = -1, hi = -1;

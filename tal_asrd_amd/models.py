@@ -157,7 +157,7 @@ class TDSBlock(nn.Module):
         self.resweight = nn.Parameter(torch.Tensor([0]))
 
     def forward_time_major(self, x):
-        rw = float(self.resweight)
+        rw = float(self.resweight.detach())
         g = self.conv[0]
         x = ops.gconv_res(x, g.packed(), g.bias, rw, g.groups)
         h = ops.linear(x, self.fc[0].weight, self.fc[0].bias, mode=1)
@@ -223,7 +223,7 @@ class TDS(nn.Module):
                 bw.conv_w, bw.conv_b = gp.data_ptr(), g.bias.data_ptr()
                 bw.fc0_w, bw.fc0_b = blk.fc[0].weight.data_ptr(), blk.fc[0].bias.data_ptr()
                 bw.fc3_w, bw.fc3_b = blk.fc[3].weight.data_ptr(), blk.fc[3].bias.data_ptr()
-                bw.resweight = float(blk.resweight)
+                bw.resweight = float(blk.resweight.detach())
         self._desc, self._desc_key, self._keep = d, key, keep
         return d
 

@@ -140,6 +140,84 @@ int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_embed, cons
 int tal_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, void* stream);
 
 /* ------------------------------------------------------------------ *
+ * Transformer decoder: ASRModel.decode / decode_spk, tal/asr/models.py:203-289,
+ * ModRZTXDecoderLayer :488-528 (+ torch.nn.MultiheadAttention), PositionalEncoding
+ * tal/modules.py:41-64.  Activations are batch-major [B, U, E] (rows = b*U+u).
+ * ------------------------------------------------------------------ */
+/* embedding -> embedding_proj (no bias; NULL when embed_size == 0) -> + pe[:U]
+ * (models.py:218-223).  tokens int64 [B, U]; emb [V, E0]; proj [D, E0]; pe [max_len, D];
+ * out [B, U, D].  Returns TAL_EINVAL if U > max_len (the reference asserts, system.py:341). */
+int tal_embed_tokens_fwd(const int64_t* tokens, int B, int U, const float* emb, int V, int E0,
+                         const float* proj, int D, const float* pe, int max_len, float* out,
+                         void* stream);
+/* x [B, U, D] + pe[:U] (PositionalEncoding.forward called on its own). */
+int tal_add_positional_fwd(const float* x, int B, int U, int D, const float* pe, int max_len,
+                           float* out, void* stream);
+
+typedef struct tal_decoder_layer_w {
+    const float* sa_in_w;   /* self_attn.in_proj_weight       [3E, E] */
+    const float* sa_in_b;   /* self_attn.in_proj_bias         [3E]    */
+    const float* sa_out_w;  /* self_attn.out_proj.weight      [E, E]  */
+    const float* sa_out_b;  /* self_attn.out_proj.bias        [E]     */
+    const float* ca_in_w;   /* multihead_attn.in_proj_weight  [3E, E] */
+    const float* ca_in_b;   /* multihead_attn.in_proj_bias    [3E]    */
+    const float* ca_out_w;  /* multihead_attn.out_proj.weight [E, E]  */
+    const float* ca_out_b;  /* multihead_attn.out_proj.bias   [E]     */
+    const float* lin1_w;    /* linear1.weight [FF, E] */
+    const float* lin1_b;    /* linear1.bias   [FF]    */
+    const float* lin2_w;    /* linear2.weight [E, FF] */
+    const float* lin2_b;    /* linear2.bias   [E]     */
+    float resweight;        /* host scalars */
+    float resweight_src;
+} tal_decoder_layer_w;
+
+/* Cross-attention key / value projections of a fixed memory window (cacheable across
+ * decode steps: the memory does not change while the text prefix grows).
+ * mem [B, S, E] -> k [B, S, E]; vt [B, E, S4] = V^T without bias (the bias is added after
+ * P.V, exact because softmax rows sum to 1), S4 = S rounded up to a multiple of 4,
+ * pad columns zero. */
+int64_t tal_pad4(int64_t n);
+int tal_cross_kv_fwd(const tal_decoder_layer_w* w, const float* mem, int B, int S, int E,
+                     float* k, float* vt, void* stream);
+size_t tal_decoder_layer_workspace_bytes(int B, int U, int S, int E, int H, int FF);
+/* One ModRZTXDecoderLayer.forward:
+ *   tgt += rw  * self_attn(tgt, tgt, tgt, attn_mask=tgt_mask)
+ *   tgt += rws * multihead_attn(tgt, mem, mem, key_padding_mask=mem_kpm)   [weights cached]
+ *   tgt += rw  * linear2(relu(linear1(tgt)))
+ * tgt/out [B, U, E] (out may alias tgt); tgt_mask additive float [U, U] or NULL;
+ * mem_kpm uint8 [B, S] (non-zero = ignore) or NULL; either mem [B, S, E] or a
+ * (k_cache, vt_cache) pair from tal_cross_kv_fwd must be given; xattn_avg [B, U, S]
+ * (head-averaged cross-attention probabilities = layer.src_attn_weights) or NULL. */
+int tal_decoder_layer_fwd(const tal_decoder_layer_w* w, const float* tgt, int B, int U,
+                          const float* mem, int S, int E, int H, int FF, const float* tgt_mask,
+                          const uint8_t* mem_kpm, const float* k_cache, const float* vt_cache,
+                          float* out, float* xattn_avg, void* workspace, size_t workspace_bytes,
+                          void* stream);
+/* Tied factorised LM head (models.py:243-246): logits = (h . P) . Emb^T with
+ * proj_t = embedding_proj.weight^T stored [E0, D] (tal_transpose_fwd builds it once).
+ * h rows are taken at stride ldh (ldh = U*D with h pointing at the last position gives
+ * the "[:, -1]" rows system.py:124 needs without computing the other U-1).
+ * proj_t may be NULL when embed_size == 0 (then D == E0).  workspace: M*E0 floats. */
+int tal_lm_head_fwd(const float* h, int64_t M, int64_t ldh, int D, const float* proj_t, int E0,
+                    const float* emb, int V, float* logits, void* workspace, size_t workspace_bytes,
+                    void* stream);
+/* y [C, R] = x [R, C]^T */
+int tal_transpose_fwd(const float* x, int R, int Cc, float* y, void* stream);
+/* Row-wise log_softmax of [M, N] (system.py:125,366), out may alias x. */
+int tal_log_softmax_rows(const float* x, int64_t M, int N, float* out, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * GRU cell of UIS-RNN's CoreRNN, tal/diarization/uisrnn/uisrnn.py:20-39 (torch.nn.GRU,
+ * gate order r, z, n).  x [B, In], h [B, H] -> h_out [B, H] (h_out != h).
+ * w_ih [3H, In], w_hh [3H, H], b_ih / b_hh [3H].  The mean head (linear_mean1 -> ReLU ->
+ * linear_mean2) is two tal_linear_fwd calls.
+ * ------------------------------------------------------------------ */
+size_t tal_gru_cell_workspace_bytes(int B, int H);
+int tal_gru_cell_fwd(const float* x, const float* h, int B, int In, int H, const float* w_ih,
+                     const float* w_hh, const float* b_ih, const float* b_hh, float* h_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ *
  * Measurement hooks (bench.py): when enabled, every launch of the hot kernels
  * is bracketed by two hipEvents on its launch stream.  class: 0 dense-layer
  * GEMM, 1 TDSBlock grouped conv, 2 stride-2 grouped conv, 3 log-mel, 4 other.

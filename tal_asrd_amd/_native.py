@@ -28,6 +28,12 @@ class TdsDesc(C.Structure):
                 ("blocks", (TdsBlockW * TAL_MAX_DEPTH) * TAL_MAX_STAGES)]
 
 
+class DecoderLayerW(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ca_in_w", "ca_in_b",
+                                          "ca_out_w", "ca_out_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b")] + \
+               [("resweight", C.c_float), ("resweight_src", C.c_float)]
+
+
 # name -> (restype, argtypes); must list every symbol include/tal_asrd.h declares
 # (tests/test_abi.py checks header <-> table <-> library).
 _i, _i64, _sz, _f, _p = C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_void_p
@@ -50,6 +56,18 @@ SIGNATURES = {
     "tal_sd_head_workspace_bytes": (_sz, [_i64, _i]),
     "tal_sd_head_fwd": (_i, [_p, _i64, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _sz, _p]),
     "tal_argmax_rows": (_i, [_p, _i64, _i, _p, _p]),
+    "tal_embed_tokens_fwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _p]),
+    "tal_add_positional_fwd": (_i, [_p, _i, _i, _i, _p, _i, _p, _p]),
+    "tal_pad4": (_i64, [_i64]),
+    "tal_cross_kv_fwd": (_i, [C.POINTER(DecoderLayerW), _p, _i, _i, _i, _p, _p, _p]),
+    "tal_decoder_layer_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "tal_decoder_layer_fwd": (_i, [C.POINTER(DecoderLayerW), _p, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p,
+                                   _p, _sz, _p]),
+    "tal_lm_head_fwd": (_i, [_p, _i64, _i64, _i, _p, _i, _p, _i, _p, _p, _sz, _p]),
+    "tal_transpose_fwd": (_i, [_p, _i, _i, _p, _p]),
+    "tal_log_softmax_rows": (_i, [_p, _i64, _i, _p, _p]),
+    "tal_gru_cell_workspace_bytes": (_sz, [_i, _i]),
+    "tal_gru_cell_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "tal_prof_enable": (_i, [_i]),
     "tal_prof_reset": (_i, []),
     "tal_prof_collect": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

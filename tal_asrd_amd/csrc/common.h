@@ -46,6 +46,24 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// Y[z] = epilogue(A[z] . W[z]^T + bias) for z = z1 * nb2 + z2 (all strides in floats).
+struct GemmArgs {
+    const float* A;
+    const float* W;
+    const float* bias;
+    const float* res;
+    float* Y;
+    int64_t M;
+    int N, K;
+    int64_t lda, ldw, ldy, ldres;
+    int nb2;
+    int64_t a_s1, a_s2, w_s1, w_s2, y_s1, y_s2, r_s1, r_s2, bias_s2;
+    float alpha;
+    int tiles_n;  // filled by launch_gemm
+};
+// mode 0: acc+b | 1: relu(acc+b) | 2: res + alpha*(acc+b) | 3: alpha*(acc+b)
+int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s);
+
 // internal launchers shared between translation units
 int launch_linear(const float* x, const float* w, const float* b, const float* res, float alpha, int mode,
                   int64_t M, int N, int K, float* y, hipStream_t s);

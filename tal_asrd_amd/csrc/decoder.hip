@@ -1,0 +1,352 @@
+// Transformer decoder side of ASRModel (tal/asr/models.py:203-289, ModRZTXDecoderLayer
+// :488-528, torch.nn.MultiheadAttention, tal/modules.py:41-64).
+//
+// Every contraction (in/out projections, QK^T, PV, FFN, LM head) runs through the fp32-MFMA
+// dense-layer kernel (gemm_f32.hip), batched over (batch item, head) with strides so no head
+// split / merge copies exist.  V is produced already transposed (V^T = W_v . x^T is just
+// another NT product) so PV is NT as well; its bias is added after PV, which is exact
+// because softmax rows sum to one.  The only non-GEMM kernels are the token embedding, the
+// masked row softmax (which also emits the head-averaged probabilities the decode loop
+// steers by, system.py:392-408) and small row utilities.
+#include "common.h"
+
+namespace tal {
+
+static inline int64_t pad4(int64_t n) { return (n + 3) & ~(int64_t)3; }
+
+// ---- token embedding: emb[tok] -> (proj) -> + pe[u] ---------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ emb,
+                                                   const float* __restrict__ proj, const float* __restrict__ pe,
+                                                   float* __restrict__ out, int U, int V, int E0, int D) {
+    extern __shared__ float e[];
+    const int row = blockIdx.x;
+    const int u = row % U;
+    int64_t tok = tokens[row];
+    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);  // validated on the host side; never trusted for addressing
+    for (int k = threadIdx.x; k < E0; k += 256) e[k] = emb[tok * E0 + k];
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float acc;
+        if (proj) {
+            acc = 0.f;
+            const float* pr = proj + (int64_t)d * E0;
+            for (int k = 0; k < E0; ++k) acc = fmaf(e[k], pr[k], acc);
+        } else {
+            acc = e[d];
+        }
+        out[(int64_t)row * D + d] = acc + pe[(int64_t)u * D + d];
+    }
+}
+
+__global__ __launch_bounds__(256) void add_positional_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                                            float* __restrict__ out, int U, int D, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int d = (int)(i % D);
+    const int u = (int)((i / D) % U);
+    out[i] = x[i] + pe[(int64_t)u * D + d];
+}
+
+// ---- masked softmax over the key axis, one wave per (b, u), heads looped ----------------------
+// scores [B, H, U, S4] in place -> probabilities (pad columns zeroed); optional additive float
+// mask [U, S], optional key-padding mask [B, S] (non-zero -> -inf), optional head average
+// avg [B, U, S] = mean_h P (MultiheadAttention's returned weights, models.py:517-519).
+__global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ scores, const float* __restrict__ mask,
+                                                          const uint8_t* __restrict__ kpm, float* __restrict__ avg,
+                                                          int B, int H, int U, int S, int S4) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)B * U) return;
+    const int b = (int)(row / U), u = (int)(row % U);
+    const float* mrow = mask ? mask + (int64_t)u * S : nullptr;
+    const uint8_t* krow = kpm ? kpm + (int64_t)b * S : nullptr;
+    float* arow = avg ? avg + row * S : nullptr;
+    const float inv_h = 1.0f / (float)H;
+    for (int h = 0; h < H; ++h) {
+        float* p = scores + (((int64_t)b * H + h) * U + u) * S4;
+        float m = -INFINITY;
+        for (int s = lane; s < S; s += 64) {
+            float v = p[s];
+            if (mrow) v += mrow[s];
+            if (krow && krow[s]) v = -INFINITY;
+            m = fmaxf(m, v);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        float sum = 0.f;
+        for (int s = lane; s < S; s += 64) {
+            float v = p[s];
+            if (mrow) v += mrow[s];
+            if (krow && krow[s]) v = -INFINITY;
+            sum += expf(v - m);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        for (int s = lane; s < S; s += 64) {
+            float v = p[s];
+            if (mrow) v += mrow[s];
+            if (krow && krow[s]) v = -INFINITY;
+            const float pr = expf(v - m) / sum;
+            p[s] = pr;
+            if (arow) {
+                float a = (h == 0 ? 0.f : arow[s]) + pr;
+                if (h == H - 1) a *= inv_h;
+                arow[s] = a;
+            }
+        }
+        if (lane < S4 - S) p[S + lane] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, int64_t M, int N,
+                                                              float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * N;
+    float* orow = out + row * N;
+    float m = -INFINITY;
+    for (int i = lane; i < N; i += 64) m = fmaxf(m, xr[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float sum = 0.f;
+    for (int i = lane; i < N; i += 64) sum += expf(xr[i] - m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float lse = logf(sum);
+    for (int i = lane; i < N; i += 64) orow[i] = (xr[i] - m) - lse;
+}
+
+__global__ void transpose_kernel(const float* __restrict__ x, int R, int Cc, float* __restrict__ y) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        if (r < R && c < Cc) t[i][threadIdx.x] = x[(int64_t)r * Cc + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < R && c < Cc) y[(int64_t)c * R + r] = t[threadIdx.x][i];
+    }
+}
+
+// ---- multi-head attention built from batched GEMMs ------------------------------------------
+struct MhaBufs {
+    float* q;       // [B, U, E]
+    float* k;       // [B, S, E]      (unused when a cache is given)
+    float* vt;      // [B, E, S4]     (unused when a cache is given)
+    float* scores;  // [B, H, U, S4]
+    float* ctx;     // [B, U, E]
+};
+
+static int project_kv(const float* in_w, const float* in_b, const float* src, int B, int S, int E, float* k, float* vt,
+                      hipStream_t s) {
+    const int64_t S4 = pad4(S);
+    int rc = launch_linear(src, in_w + (int64_t)E * E, in_b + E, nullptr, 0.f, 0, (int64_t)B * S, E, E, k, s);
+    if (rc) return rc;
+    if (S4 != S && hipMemsetAsync(vt, 0, (size_t)B * E * S4 * sizeof(float), s) != hipSuccess) {
+        set_error("mha: memset failed");
+        return TAL_EHIP;
+    }
+    GemmArgs g = {};
+    g.A = in_w + 2 * (int64_t)E * E; g.W = src; g.Y = vt;   // V^T[b] = W_v . src_b^T  (bias added after P.V)
+    g.M = E; g.N = S; g.K = E;
+    g.lda = E; g.ldw = E; g.ldy = S4;
+    g.nb2 = 1; g.w_s1 = (int64_t)S * E; g.y_s1 = (int64_t)E * S4;
+    return launch_gemm(g, 0, B, s);
+}
+
+// out = res + alpha * out_proj(softmax(q k^T + masks) v)
+static int mha_forward(const float* in_w, const float* in_b, const float* out_w, const float* out_b, const float* xq,
+                       const float* k, const float* vt, int B, int U, int S, int E, int H, const float* attn_mask,
+                       const uint8_t* kpm, const float* res, float alpha, float* out, float* avg, const MhaBufs& bf,
+                       hipStream_t s) {
+    const int hd = E / H;
+    const int64_t S4 = pad4(S);
+    // q = (x W_q^T + b_q) * hd^-0.5   (torch scales q after the in-projection)
+    int rc = launch_linear(xq, in_w, in_b, nullptr, 1.0f / sqrtf((float)hd), 3, (int64_t)B * U, E, E, bf.q, s);
+    if (rc) return rc;
+    GemmArgs g = {};
+    g.A = bf.q; g.W = k; g.Y = bf.scores;
+    g.M = U; g.N = S; g.K = hd;
+    g.lda = E; g.ldw = E; g.ldy = S4;
+    g.nb2 = H;
+    g.a_s1 = (int64_t)U * E; g.a_s2 = hd;
+    g.w_s1 = (int64_t)S * E; g.w_s2 = hd;
+    g.y_s1 = (int64_t)H * U * S4; g.y_s2 = (int64_t)U * S4;
+    rc = launch_gemm(g, 0, B * H, s);
+    if (rc) return rc;
+    {
+        ProfScope prof(PROF_OTHER, (double)B * H * U * S * 8.0, s);
+        hipLaunchKernelGGL(attn_softmax_kernel, dim3((unsigned)cdiv((int64_t)B * U, 4)), dim3(256), 0, s, bf.scores,
+                           attn_mask, kpm, avg, B, H, U, S, (int)S4);
+    }
+    TAL_CHECK_LAUNCH("attn_softmax");
+    GemmArgs p = {};
+    p.A = bf.scores; p.W = vt; p.Y = bf.ctx; p.bias = in_b + 2 * E;
+    p.M = U; p.N = hd; p.K = (int)S4;
+    p.lda = S4; p.ldw = S4; p.ldy = E;
+    p.nb2 = H;
+    p.a_s1 = (int64_t)H * U * S4; p.a_s2 = (int64_t)U * S4;
+    p.w_s1 = (int64_t)E * S4; p.w_s2 = (int64_t)hd * S4;
+    p.y_s1 = (int64_t)U * E; p.y_s2 = hd;
+    p.bias_s2 = hd;
+    rc = launch_gemm(p, 0, B * H, s);
+    if (rc) return rc;
+    return launch_linear(bf.ctx, out_w, out_b, res, alpha, 2, (int64_t)B * U, E, E, out, s);
+}
+
+struct LayerWs {
+    MhaBufs mha;
+    float* x1;   // [B, U, E]
+    float* x2;   // [B, U, E]
+    float* ff;   // [B, U, FF]
+    size_t total_floats;
+};
+
+static LayerWs carve(float* base, int B, int U, int S, int E, int H, int FF) {
+    const int64_t L = U > S ? U : S;
+    const int64_t L4 = pad4(L);
+    auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    LayerWs w;
+    size_t o = 0;
+    auto take = [&](size_t n) { float* p = base ? base + o : nullptr; o += up(n); return p; };
+    w.mha.q = take((size_t)B * U * E);
+    w.mha.k = take((size_t)B * L * E);
+    w.mha.vt = take((size_t)B * E * L4);
+    w.mha.scores = take((size_t)B * H * U * L4);
+    w.mha.ctx = take((size_t)B * U * E);
+    w.x1 = take((size_t)B * U * E);
+    w.x2 = take((size_t)B * U * E);
+    w.ff = take((size_t)B * U * FF);
+    w.total_floats = o;
+    return w;
+}
+
+}  // namespace tal
+
+using namespace tal;
+
+extern "C" int64_t tal_pad4(int64_t n) { return pad4(n); }
+
+extern "C" int tal_embed_tokens_fwd(const int64_t* tokens, int B, int U, const float* emb, int V, int E0,
+                                    const float* proj, int D, const float* pe, int max_len, float* out,
+                                    void* stream) {
+    TAL_CHECK_ARG(tokens && emb && pe && out, "tal_embed_tokens_fwd: null pointer");
+    TAL_CHECK_ARG(B > 0 && U > 0 && V > 0 && E0 > 0 && D > 0, "tal_embed_tokens_fwd: bad shape");
+    TAL_CHECK_ARG(U <= max_len, "tal_embed_tokens_fwd: sequence length %d exceeds max_positions %d", U, max_len);
+    TAL_CHECK_ARG(proj || D == E0, "tal_embed_tokens_fwd: no projection needs D == E0");
+    TAL_CHECK_ARG(E0 <= 8192, "tal_embed_tokens_fwd: embedding width %d too large", E0);
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)(B * U)), dim3(256), (size_t)E0 * sizeof(float),
+                       (hipStream_t)stream, tokens, emb, proj, pe, out, U, V, E0, D);
+    TAL_CHECK_LAUNCH("tal_embed_tokens_fwd");
+    return TAL_OK;
+}
+
+extern "C" int tal_add_positional_fwd(const float* x, int B, int U, int D, const float* pe, int max_len, float* out,
+                                      void* stream) {
+    TAL_CHECK_ARG(x && pe && out && B > 0 && U > 0 && D > 0, "tal_add_positional_fwd: bad argument");
+    TAL_CHECK_ARG(U <= max_len, "tal_add_positional_fwd: sequence length %d exceeds max_len %d", U, max_len);
+    const int64_t total = (int64_t)B * U * D;
+    hipLaunchKernelGGL(add_positional_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       pe, out, U, D, total);
+    TAL_CHECK_LAUNCH("tal_add_positional_fwd");
+    return TAL_OK;
+}
+
+extern "C" int tal_cross_kv_fwd(const tal_decoder_layer_w* w, const float* mem, int B, int S, int E, float* k,
+                                float* vt, void* stream) {
+    TAL_CHECK_ARG(w && mem && k && vt && w->ca_in_w && w->ca_in_b, "tal_cross_kv_fwd: null pointer");
+    TAL_CHECK_ARG(B > 0 && S > 0 && E > 0 && E % 4 == 0, "tal_cross_kv_fwd: bad shape");
+    return project_kv(w->ca_in_w, w->ca_in_b, mem, B, S, E, k, vt, (hipStream_t)stream);
+}
+
+extern "C" size_t tal_decoder_layer_workspace_bytes(int B, int U, int S, int E, int H, int FF) {
+    if (B <= 0 || U <= 0 || S <= 0 || E <= 0 || H <= 0 || FF <= 0) return 0;
+    return carve(nullptr, B, U, S, E, H, FF).total_floats * sizeof(float);
+}
+
+extern "C" int tal_decoder_layer_fwd(const tal_decoder_layer_w* w, const float* tgt, int B, int U, const float* mem,
+                                     int S, int E, int H, int FF, const float* tgt_mask, const uint8_t* mem_kpm,
+                                     const float* k_cache, const float* vt_cache, float* out, float* xattn_avg,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    TAL_CHECK_ARG(w && tgt && out && workspace, "tal_decoder_layer_fwd: null pointer");
+    TAL_CHECK_ARG(w->sa_in_w && w->sa_in_b && w->sa_out_w && w->sa_out_b && w->ca_in_w && w->ca_in_b && w->ca_out_w &&
+                      w->ca_out_b && w->lin1_w && w->lin1_b && w->lin2_w && w->lin2_b,
+                  "tal_decoder_layer_fwd: null weight");
+    TAL_CHECK_ARG(B > 0 && U > 0 && S > 0 && E > 0 && H > 0 && FF > 0 && E % H == 0 && (E / H) % 4 == 0 && FF % 4 == 0,
+                  "tal_decoder_layer_fwd: bad shape B=%d U=%d S=%d E=%d H=%d FF=%d", B, U, S, E, H, FF);
+    TAL_CHECK_ARG(mem || (k_cache && vt_cache), "tal_decoder_layer_fwd: need the memory or its cached K / V^T");
+    if (workspace_bytes < tal_decoder_layer_workspace_bytes(B, U, S, E, H, FF)) {
+        set_error("tal_decoder_layer_fwd: workspace %zu < %zu bytes", workspace_bytes,
+                  tal_decoder_layer_workspace_bytes(B, U, S, E, H, FF));
+        return TAL_ENOMEM;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    LayerWs ws = carve(reinterpret_cast<float*>(workspace), B, U, S, E, H, FF);
+    // self attention over the prefix (keys = queries = tgt)
+    int rc = project_kv(w->sa_in_w, w->sa_in_b, tgt, B, U, E, ws.mha.k, ws.mha.vt, s);
+    if (rc) return rc;
+    rc = mha_forward(w->sa_in_w, w->sa_in_b, w->sa_out_w, w->sa_out_b, tgt, ws.mha.k, ws.mha.vt, B, U, U, E, H,
+                     tgt_mask, nullptr, tgt, w->resweight, ws.x1, nullptr, ws.mha, s);
+    if (rc) return rc;
+    // cross attention over the encoder window
+    const float* ck = k_cache;
+    const float* cvt = vt_cache;
+    if (!ck || !cvt) {
+        rc = project_kv(w->ca_in_w, w->ca_in_b, mem, B, S, E, ws.mha.k, ws.mha.vt, s);
+        if (rc) return rc;
+        ck = ws.mha.k;
+        cvt = ws.mha.vt;
+    }
+    rc = mha_forward(w->ca_in_w, w->ca_in_b, w->ca_out_w, w->ca_out_b, ws.x1, ck, cvt, B, U, S, E, H, nullptr, mem_kpm,
+                     ws.x1, w->resweight_src, ws.x2, xattn_avg, ws.mha, s);
+    if (rc) return rc;
+    // feed-forward
+    rc = launch_linear(ws.x2, w->lin1_w, w->lin1_b, nullptr, 0.f, 1, (int64_t)B * U, FF, E, ws.ff, s);
+    if (rc) return rc;
+    return launch_linear(ws.ff, w->lin2_w, w->lin2_b, ws.x2, w->resweight, 2, (int64_t)B * U, E, FF, out, s);
+}
+
+extern "C" int tal_lm_head_fwd(const float* h, int64_t M, int64_t ldh, int D, const float* proj_t, int E0,
+                               const float* emb, int V, float* logits, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    TAL_CHECK_ARG(h && emb && logits, "tal_lm_head_fwd: null pointer");
+    TAL_CHECK_ARG(M >= 0 && D > 0 && E0 > 0 && V > 0 && ldh >= D && ldh % 4 == 0, "tal_lm_head_fwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs g = {};
+    g.nb2 = 1;
+    if (!proj_t) {
+        TAL_CHECK_ARG(D == E0, "tal_lm_head_fwd: no projection needs D == E0");
+        g.A = h; g.W = emb; g.Y = logits; g.M = M; g.N = V; g.K = D; g.lda = ldh; g.ldw = D; g.ldy = V;
+        return launch_gemm(g, 0, 1, s);
+    }
+    TAL_CHECK_ARG(workspace, "tal_lm_head_fwd: needs a workspace of M*E0 floats");
+    if (workspace_bytes < (size_t)M * E0 * sizeof(float)) {
+        set_error("tal_lm_head_fwd: workspace %zu < %zu bytes", workspace_bytes, (size_t)M * E0 * sizeof(float));
+        return TAL_ENOMEM;
+    }
+    float* t = reinterpret_cast<float*>(workspace);
+    g.A = h; g.W = proj_t; g.Y = t; g.M = M; g.N = E0; g.K = D; g.lda = ldh; g.ldw = D; g.ldy = E0;
+    int rc = launch_gemm(g, 0, 1, s);
+    if (rc) return rc;
+    return launch_linear(t, emb, nullptr, nullptr, 0.f, 0, M, V, E0, logits, s);
+}
+
+extern "C" int tal_transpose_fwd(const float* x, int R, int Cc, float* y, void* stream) {
+    TAL_CHECK_ARG(x && y && R > 0 && Cc > 0, "tal_transpose_fwd: bad argument");
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)cdiv(Cc, 32), (unsigned)cdiv(R, 32)), dim3(32, 8), 0,
+                       (hipStream_t)stream, x, R, Cc, y);
+    TAL_CHECK_LAUNCH("tal_transpose_fwd");
+    return TAL_OK;
+}
+
+extern "C" int tal_log_softmax_rows(const float* x, int64_t M, int N, float* out, void* stream) {
+    TAL_CHECK_ARG(x && out && M >= 0 && N > 0, "tal_log_softmax_rows: bad argument");
+    if (M == 0) return TAL_OK;
+    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, M, N,
+                       out);
+    TAL_CHECK_LAUNCH("tal_log_softmax_rows");
+    return TAL_OK;
+}

@@ -164,4 +164,11 @@ def argmax_rows(x):
 
 
 def add_positional(x, pe):
-    raise N.NativeError("add_positional: decoder kernels are not built yet")
+    """x [B, U, D] + pe[:U] (PositionalEncoding.forward, tal/modules.py:63)."""
+    lib = N.lib()
+    x = _f32c(x, "add_positional")
+    B, U, D = x.shape
+    out = torch.empty_like(x)
+    N.check(lib.tal_add_positional_fwd(N.ptr(x), B, U, D, N.ptr(_f32c(pe, "pe")), pe.shape[0], N.ptr(out),
+                                       N.stream_handle()), "tal_add_positional_fwd")
+    return out

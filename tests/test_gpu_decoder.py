@@ -1,0 +1,180 @@
+"""GPU parity of the decoder side (ASRModel.decode / decode_spk, ModRZTXDecoderLayer,
+PositionalEncoding, CoreRNN) against golden vectors recorded from the reference and
+against the oracle.  pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden, has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+LOGIT_TOL = 1e-3
+ATTN_TOL = 1e-6
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _load(model, sd):
+    own = model.state_dict()
+    for k, v in sd.items():
+        assert k in own, k
+        own[k] = torch.from_numpy(np.array(v, copy=True))
+    model.load_state_dict(own)
+    return model.to(dev())
+
+
+def _fill(module, prefix):
+    from tal_asrd_amd import synth
+    sd = synth.fill_state_dict({prefix + k: tuple(v.shape) for k, v in module.state_dict().items()})
+    return _load(module, {k[len(prefix):]: v for k, v in sd.items()})
+
+
+@pytest.fixture(scope="module")
+def asr_model(asr_weights):
+    from tal_asrd_amd import ASRModel
+    return _load(ASRModel("2x", num_speakers=6008, vocab_size=10000, use_speaker_head=True), asr_weights)
+
+
+def test_positional_encoding_golden():
+    from tal_asrd_amd import PositionalEncoding
+    g = golden("posenc")
+    m = PositionalEncoding(64, max_len=32).to(dev())
+    # the buffer is evaluated by torch's CPU sin/cos/exp at construction, whose last bit depends on
+    # the host's SIMD path (AVX-512 in the build container vs the GPU box's CPU): 1e-6, not bit-exact
+    np.testing.assert_allclose(m.pe.cpu().numpy(), g["pe"], atol=2e-6, rtol=0)
+    x = torch.from_numpy(g["x"]).to(dev())
+    y = m(x)
+    np.testing.assert_array_equal(y.cpu().numpy(), (x + m.pe[:5]).cpu().numpy())   # the add itself is exact
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], atol=2e-6, rtol=0)
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 33, 64, device=dev()))
+
+
+def test_decoder_layer_small_golden():
+    """ModRZTXDecoderLayer(64, 4, 256) with the reference's [U,B,E] contract, all mask combinations."""
+    from tal_asrd_amd import ModRZTXDecoderLayer
+    from tal_asrd_amd.decoder import causal_mask
+    g = golden("declayer_small")
+    layer = _fill(ModRZTXDecoderLayer(d_model=64, nhead=4, dim_feedforward=256), "declayer.")
+    tgt, mem = torch.from_numpy(g["tgt"]).to(dev()), torch.from_numpy(g["mem"]).to(dev())
+    cm = causal_mask(7, dev())
+    kpm = torch.from_numpy(g["kpm"]).to(dev())
+    for tag, tm, km in (("plain", None, None), ("causal", cm, None), ("kpm", None, kpm), ("causal_kpm", cm, kpm)):
+        y = layer(tgt, mem, tgt_mask=tm, memory_key_padding_mask=km)
+        np.testing.assert_allclose(y.cpu().numpy(), g["y_" + tag], atol=2e-5, rtol=0, err_msg=tag)
+        np.testing.assert_allclose(layer.src_attn_weights.cpu().numpy(), g["w_" + tag], atol=ATTN_TOL, rtol=0)
+        assert abs(float(layer.src_attn_weights.sum(-1).mean()) - 1.0) < 1e-5
+
+
+def _memory(asr_model, S):
+    from tal_asrd_amd import synth
+    audio = torch.from_numpy(synth.synth_audio_batch(1, 480000, 1234)).to(dev())
+    enc = asr_model.encode(audio, torch.tensor([480000]))
+    return {"encoder_out": enc["encoder_out"][:, :S].contiguous(),
+            "speaker_out": enc["speaker_out"][:, :S].contiguous(),
+            "encoder_padding_mask": enc["encoder_padding_mask"][:, :S].contiguous()}
+
+
+def test_asr_decode_golden(asr_model):
+    """Decoder fixtures of SURVEY 8c item 4: U in {1,7,64} x S=357, causal on/off, logits first/last
+    row, per-layer src_attn_weights last row, decode_spk last row."""
+    g = golden("asr_decode")
+    mem = _memory(asr_model, int(g["S"]))
+    for U in (1, 7, 64):
+        y = torch.from_numpy(g["y_%d" % U]).to(dev())
+        for causal in (True, False):
+            tag = "U%d_%s" % (U, "causal" if causal else "full")
+            logits = asr_model.decode(y, mem, causal_mask=causal)
+            assert tuple(logits.shape) == (1, U, 10000)
+            np.testing.assert_allclose(logits[:, -1].cpu().numpy(), g["logits_last_" + tag], atol=LOGIT_TOL, rtol=0)
+            np.testing.assert_allclose(logits[:, 0].cpu().numpy(), g["logits_first_" + tag], atol=LOGIT_TOL, rtol=0)
+            attn = torch.stack([l.src_attn_weights[:, -1] for l in asr_model.decoder.layers], 0)
+            np.testing.assert_allclose(attn.cpu().numpy(), g["attn_last_" + tag], atol=ATTN_TOL, rtol=0)
+            assert int(logits[0, -1].argmax()) == int(g["logits_last_" + tag][0].argmax())
+            spk = asr_model.decode_spk(y, mem, causal_mask=causal)
+            np.testing.assert_allclose(spk[:, -1].cpu().numpy(), g["spk_last_" + tag], atol=LOGIT_TOL, rtol=0)
+
+
+def test_asr_decode_b2_kpm_golden(asr_model):
+    from tal_asrd_amd import synth
+    g = golden("asr_decode")
+    lens = [480000, 400000]
+    audio = torch.from_numpy(synth.synth_audio_batch(2, 480000, 1234, lens=lens)).to(dev())
+    enc = asr_model.encode(audio, torch.tensor(lens))
+    y = torch.from_numpy(g["y_b2"]).to(dev())
+    logits = asr_model.decode(y, enc, causal_mask=False)
+    np.testing.assert_allclose(logits[:, -1].cpu().numpy(), g["logits_last_b2"], atol=LOGIT_TOL, rtol=0)
+    attn = torch.stack([l.src_attn_weights[:, -1] for l in asr_model.decoder.layers], 0)
+    np.testing.assert_allclose(attn.cpu().numpy(), g["attn_last_b2"], atol=ATTN_TOL, rtol=0)
+    # padded memory positions get exactly zero attention
+    mask = enc["encoder_padding_mask"]
+    assert float(attn[:, 1][:, mask[1]].abs().max()) == 0.0
+    spk = asr_model.decode_spk(y, enc, causal_mask=False)
+    np.testing.assert_allclose(spk[:, -1].cpu().numpy(), g["spk_last_b2"], atol=LOGIT_TOL, rtol=0)
+
+
+def test_last_only_and_kv_cache_equivalence(asr_model):
+    """The fast forms used by the decode loops (last-position LM head, cached cross K/V) are
+    bit-identical to the full forms."""
+    from tal_asrd_amd.decoder import asr_decode, asr_decode_spk
+    g = golden("asr_decode")
+    mem = _memory(asr_model, 357)
+    y = torch.from_numpy(g["y_64"]).to(dev())
+    full = asr_model.decode(y, mem, causal_mask=False)
+    last = asr_decode(asr_model, y, mem, causal=False, last_only=True)
+    np.testing.assert_array_equal(full[:, -1].cpu().numpy(), last.cpu().numpy())
+    again = asr_decode(asr_model, y, mem, causal=False, last_only=True)   # second call hits the K/V cache
+    np.testing.assert_array_equal(last.cpu().numpy(), again.cpu().numpy())
+    s_full = asr_model.decode_spk(y, mem, causal_mask=False)
+    s_last = asr_decode_spk(asr_model, y, mem, causal=False, last_only=True)
+    np.testing.assert_array_equal(s_full[:, -1].cpu().numpy(), s_last.cpu().numpy())
+
+
+def test_forward_teacher_forced(asr_model, asr_weights):
+    """ASRModel.forward (models.py:291-295) against the oracle end to end on a short ragged batch."""
+    from oracle import tal_oracle as O
+    from tal_asrd_amd import synth
+    lens = [64000, 48000]
+    audio = synth.synth_audio_batch(2, 64000, 55, lens=lens)
+    y = np.array([[0, 17, 4021, 9999, 1], [0, 5, 6, 7, 8]], dtype=np.int64)
+    (lm, spk), enc = asr_model(torch.from_numpy(audio).to(dev()), torch.from_numpy(y).to(dev()), torch.tensor(lens))
+    with torch.no_grad():
+        oenc = O.asr_encode(audio, asr_weights, lens)
+        olm, _ = O.asr_decode(y, oenc, asr_weights, causal_mask=True)
+        ospk = O.asr_decode_spk(y, oenc, asr_weights, causal_mask=True)
+    np.testing.assert_allclose(enc["encoder_out"].cpu().numpy(), oenc["encoder_out"].numpy(), atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(lm.cpu().numpy(), olm.numpy(), atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(spk.cpu().numpy(), ospk.numpy(), atol=LOGIT_TOL, rtol=0)
+
+
+def test_log_softmax_and_argmax_rows():
+    from tal_asrd_amd import ops
+    from tal_asrd_amd.decoder import log_softmax
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 16008, generator=g) * 6
+    x[2, 100] = x[2, 9000] = x[2].max() + 1.0          # exact tie: first index must win
+    y = log_softmax(x.to(dev()))
+    np.testing.assert_allclose(y.cpu().numpy(), torch.log_softmax(x, -1).numpy(), atol=2e-5, rtol=0)
+    ids = ops.argmax_rows(x.to(dev())).cpu().numpy()
+    np.testing.assert_array_equal(ids, x.argmax(-1).numpy())
+    assert ids[2] == 100
+
+
+def test_core_rnn_golden():
+    from tal_asrd_amd.uisrnn import CoreRNN
+    g = golden("gru")
+    rnn = _fill(CoreRNN(256, 512, 1, 256), "corernn.")
+    m1, h1 = rnn(torch.from_numpy(g["x1"]).to(dev()), torch.from_numpy(g["h0"]).to(dev()))
+    np.testing.assert_allclose(m1.cpu().numpy(), g["m1"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(h1.cpu().numpy(), g["h1"], atol=2e-5, rtol=0)
+    m3, h3 = rnn(torch.from_numpy(g["x3"]).to(dev()), None)
+    np.testing.assert_allclose(m3.cpu().numpy(), g["m3"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(h3.cpu().numpy(), g["h3"], atol=2e-5, rtol=0)
+    g2 = golden("gru_depth2")
+    rnn2 = _fill(CoreRNN(256, 512, 2, 256), "corernn2.")
+    m, h = rnn2(torch.from_numpy(g2["x3"]).to(dev()), None)
+    np.testing.assert_allclose(m.cpu().numpy(), g2["m3"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(h.cpu().numpy(), g2["h3"], atol=2e-5, rtol=0)

@@ -205,6 +205,12 @@ int tal_lm_head_fwd(const float* h, int64_t M, int64_t ldh, int D, const float* 
 int tal_transpose_fwd(const float* x, int R, int Cc, float* y, void* stream);
 /* Row-wise log_softmax of [M, N] (system.py:125,366), out may alias x. */
 int tal_log_softmax_rows(const float* x, int64_t M, int N, float* out, void* stream);
+/* Beam-search candidate selection of System.generate (system.py:141-160): per batch item the
+ * top-k of (logprobs[row, v] + row_score[row]) over its cur_beam rows x V tokens, rows with
+ * row_done != 0 masked to -inf.  logprobs [B*cur_beam, V]; row_score / row_done [B*cur_beam]
+ * (may be NULL); out_val [B, k] descending; out_idx [B, k] int64 flat index beam*V + token. */
+int tal_beam_topk(const float* logprobs, const float* row_score, const uint8_t* row_done, int B,
+                  int cur_beam, int V, int k, float* out_val, int64_t* out_idx, void* stream);
 
 /* ------------------------------------------------------------------ *
  * GRU cell of UIS-RNN's CoreRNN, tal/diarization/uisrnn/uisrnn.py:20-39 (torch.nn.GRU,

@@ -54,7 +54,15 @@ def synth_tensor(name: str, shape, bound: float) -> np.ndarray:
 
 
 def rezero_value(name: str) -> float:
-    """Non-zero ReZero scalar in [0.20, 0.32], a pure function of the key."""
+    """Non-zero ReZero scalar, a pure function of the key.
+
+    Encoder blocks: [0.20, 0.32].  Decoder layers get O(1) scalars (2.0-2.4 for
+    `resweight`, 3.0-3.4 for `resweight_src`): with small ones the tied embedding
+    makes greedy decoding echo its input token forever and the cross-attention is
+    uniform, so the decode-loop fixtures would only ever exercise one branch."""
+    if "decoder.layers." in name:
+        base = 3.0 if name.endswith("resweight_src") else 2.0
+        return base + 0.1 * (name_seed(name) % 5)
     return 0.20 + 0.02 * (name_seed(name) % 7)
 
 
@@ -64,7 +72,9 @@ def rezero_value(name: str) -> float:
 _HEAD_GAIN = {
     "spk_logit_proj.weight": 24.0,
     "speaker_head.1.weight": 24.0,
-    "embedding.weight": 6.0,
+    # sharper cross-attention: the window-advance logic of generate_unaligned steers by the
+    # centre of mass of these weights (tal/asr/system.py:392-408)
+    "multihead_attn.in_proj_weight": 4.0,
 }
 
 

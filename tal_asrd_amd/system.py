@@ -1,0 +1,222 @@
+"""Decode control flow on top of the HIP model: the counterpart of `System.generate` and
+`System.generate_unaligned` (tal/asr/system.py:68-524).
+
+Same arguments, same return values, same decisions -- restated so that the per-step
+device work is what the kernels are good at:
+  * the LM / speaker heads run for the last position only (all the loops read,
+    system.py:124,355-361);
+  * the cross-attention K / V^T of the encoder window are projected once per window
+    instead of once per generated token (decoder.cross_kv);
+  * log_softmax, the beam top-k and the arg-max run as HIP kernels; the host sees one small
+    D2H copy per step (token ids / scores, and for the sliding-window decode the averaged
+    attention row it steers by), exactly where the reference synchronises too
+    (.cpu()/.tolist()/.item() at system.py:198-215,408-411).
+Text-prefix recomputation is kept: the reference decodes with causal_mask=False
+(system.py:113,350), so every earlier position attends to later tokens and a self-attention
+KV cache would change results (hard parts).
+
+Not built (not on the acoustic hot path): LM fusion (`self.lm`, system.py:127-138 -- no
+language model ships with the reference), training / validation steps, data loaders.
+The half-precision casts (`force_half`, system.py:92,285) are accepted and ignored: this
+path computes in fp32 (BASELINE.json: logits within 1e-3 of the fp32 CPU path).
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import ops
+from .decoder import asr_decode, asr_decode_spk, log_softmax
+from .util import ngram_repeat_mask
+
+
+def _beam_topk(logprobs, scores, done, B, cur_beam, k):
+    lib = N.lib()
+    V = logprobs.shape[-1]
+    dev = logprobs.device
+    vals = torch.empty(B, k, dtype=torch.float32, device=dev)
+    idx = torch.empty(B, k, dtype=torch.int64, device=dev)
+    N.check(lib.tal_beam_topk(N.ptr(logprobs), N.ptr(scores), N.ptr(done), B, cur_beam, V, k, N.ptr(vals),
+                              N.ptr(idx), N.stream_handle()), "tal_beam_topk")
+    return vals, idx
+
+
+class System:
+    """Holds the model and the decode-time arguments the reference reads from `self.args`
+    (spk_weight, lm_weight) and `self.tokenizer` (eos_token_id)."""
+
+    def __init__(self, model, spk_weight=0.0, eos_token_id=1, bos_token_id=0, pad_token_id=2):
+        self.model = model
+        self.args = SimpleNamespace(spk_weight=spk_weight, lm_weight=0.0)
+        self.tokenizer = SimpleNamespace(eos_token_id=eos_token_id, bos_token_id=bos_token_id,
+                                         pad_token_id=pad_token_id)
+        self.lm = None
+
+    # ------------------------------------------------------------------ aligned: batched beam search
+    @torch.no_grad()
+    def generate(self, audio_x, generated, audio_lens, length, beam_size=1, terminate_token=None,
+                 force_half=True, force_output=False):
+        """system.py:68-252.  Returns (output_seq, output_spk): per batch item the best
+        length-normalised finished sequence (CPU LongTensor | None) and its per-step speaker
+        logits (CPU tensor [steps, num_speakers] | None)."""
+        model = self.model
+        use_spk = self.args.spk_weight > 0
+        dev = audio_x.device
+        encoder_out = model.encode(audio_x.float(), audio_lens)
+        batch_size = generated.size(0)
+        cur_beam = 1
+        gen = generated.detach().cpu().numpy().astype(np.int64)           # [rows, len] host bookkeeping
+        scores = torch.zeros(batch_size, dtype=torch.float32, device=dev)   # one per live row
+        finished = [[] for _ in range(batch_size)]
+        done = np.zeros(batch_size * beam_size, dtype=bool)
+        spk_embeds = None
+        for _ in range(length):
+            y = torch.from_numpy(gen).to(dev)
+            logits = asr_decode(model, y, encoder_out, causal=False, last_only=True)          # [rows, V]
+            V = logits.size(-1)
+            pred_speaker = asr_decode_spk(model, y, encoder_out, causal=False, last_only=True) if use_spk else None
+            logprobs = log_softmax(logits)
+            done_dev = torch.from_numpy(done.astype(np.uint8)).to(dev) if cur_beam == beam_size else None
+            top_scores, indices = _beam_topk(logprobs, scores, done_dev, batch_size, cur_beam, beam_size)
+            idx_h = indices.cpu().numpy()
+            best_tokens = idx_h % V
+            best_beams = idx_h // V
+            if cur_beam != beam_size:
+                assert beam_size % cur_beam == 0
+                rep = beam_size // cur_beam
+                gen = np.repeat(gen, rep, axis=0)
+                # the reference mutates the caller-visible dict the same way (system.py:168-171);
+                # `speaker_out` is NOT repeated there either (latent reference bug for beams + speaker head)
+                encoder_out["encoder_out"] = encoder_out["encoder_out"].repeat_interleave(rep, dim=0)
+                encoder_out["encoder_padding_mask"] = encoder_out["encoder_padding_mask"].repeat_interleave(rep, dim=0)
+            # re-thread every beam onto the hypothesis it extends, then append its token
+            src_rows = (np.arange(batch_size)[:, None] * beam_size + best_beams).reshape(-1)
+            gen = np.concatenate([gen[src_rows], best_tokens.reshape(-1, 1)], axis=1)
+            scores = top_scores.reshape(-1)
+            if use_spk:
+                if spk_embeds is None:
+                    spk_embeds = pred_speaker.unsqueeze(1).repeat_interleave(beam_size // cur_beam, dim=0)
+                else:
+                    sel = spk_embeds.index_select(0, torch.from_numpy(src_rows).to(dev))
+                    spk_embeds = torch.cat((sel, pred_speaker.unsqueeze(1)), dim=1)
+                assert gen.shape[1] == spk_embeds.size(1) + 1
+            if terminate_token is not None:
+                scores_h = None
+                for index in np.nonzero(best_tokens.reshape(-1) == terminate_token)[0].tolist():
+                    if not done[index]:
+                        if scores_h is None:
+                            scores_h = scores.cpu()
+                        finished[index // beam_size].append(
+                            (torch.from_numpy(gen[index].copy()),
+                             spk_embeds[index].cpu() if spk_embeds is not None else None, scores_h[index]))
+                        done[index] = True
+            cur_beam = beam_size
+            if done.sum() >= batch_size * beam_size:
+                break
+        if terminate_token is None or force_output:
+            scores_h = scores.cpu().view(batch_size, beam_size)
+            for b in range(batch_size):
+                for j in range(beam_size):
+                    row = b * beam_size + j
+                    finished[b].append((torch.from_numpy(gen[row].copy()),
+                                        spk_embeds[row].cpu() if spk_embeds is not None else None,
+                                        scores_h[b, j].item()))
+        finished = [[(cand, spk, score / len(cand)) for cand, spk, score in batch] for batch in finished]
+        output_seq = [max(batch, key=lambda x: x[-1])[0] if len(batch) > 0 else None for batch in finished]
+        output_spk = [max(batch, key=lambda x: x[-1])[1] if len(batch) > 0 else None for batch in finished]
+        return output_seq, output_spk
+
+    # ------------------------------------------------------------------ unaligned: sliding window greedy decode
+    @torch.no_grad()
+    def generate_unaligned(self, audio_x, generated, audio_lens, chunk_size=357, max_iters=1000000,
+                           max_positions=None, thresh_prct=0.5, shift_prct=0.25, stall_patience=25, rep_n=5,
+                           skip_prct=0.1):
+        """system.py:254-524 (designed for batch 1: it calls .item() on per-batch tensors).
+        Returns (generated [1, N] LongTensor on the input device, alignments: list of
+        (chunk_start LongTensor[1], attention [1, S] CPU tensor) per generated token)."""
+        model = self.model
+        if generated.size(0) != 1:
+            raise ValueError("generate_unaligned handles one episode at a time (system.py:331,411 call .item())")
+        dev = audio_x.device
+        max_positions = model.max_positions if max_positions is None else max_positions
+        encoder_out = model.encode(audio_x.float(), audio_lens)
+        enc, mask = encoder_out["encoder_out"], encoder_out["encoder_padding_mask"]
+        encoder_len = int((~mask).sum(dim=-1).cpu().item())
+        eos = self.tokenizer.eos_token_id
+        gen = generated.detach().cpu().numpy().astype(np.int64)[0].tolist()
+        alignments = []            # (chunk_start as recorded by the reference, attention row)
+        chunk_start = 0
+        history_start = 0
+        highest_progress = 0
+        num_no_improve = 0
+        window_time = 0
+        window_key, window = None, None
+        layers = model.decoder.layers
+        for it in range(max_iters):
+            history = gen[history_start:]
+            assert len(history) <= max_positions, "Cannot exceed max context length"
+            # encoder window [chunk_start, chunk_start + chunk_size) -- python slice semantics as in the
+            # reference's slice_tensor; re-materialised only when the window moves so that the
+            # cross-attention K / V^T cache of every layer keeps hitting
+            if window_key != chunk_start:
+                sl = slice(chunk_start, chunk_start + chunk_size)
+                window = {"encoder_out": enc[:, sl].contiguous(), "encoder_padding_mask": mask[:, sl].contiguous()}
+                window_key = chunk_start
+            y = torch.tensor([history], dtype=torch.int64, device=dev)
+            logits = asr_decode(model, y, window, causal=False, last_only=True)      # [1, V]
+            if it == 0 and bool(torch.isnan(logits).any()):
+                raise Exception("Logits contain nans!")
+            logprobs = log_softmax(logits)
+            token = int(ops.argmax_rows(logprobs).cpu().item())
+            gen.append(token)
+            # attention of the new token, averaged over layers (heads are already averaged by the kernel)
+            rows = torch.stack([l.src_attn_weights[0, -1] for l in layers], dim=0).cpu().numpy()
+            attn = rows.astype(np.float32).sum(axis=0, dtype=np.float32) / np.float32(len(layers))
+            record = [chunk_start, torch.from_numpy(attn.copy()).unsqueeze(0)]
+            alignments.append(record)
+            assert len(alignments) == len(gen) - 1
+            S = attn.shape[0]
+            attn_range = (np.arange(S, dtype=np.float32) / np.float32(S)).astype(np.float32)
+            prct_progress = float(np.sum(attn * attn_range, dtype=np.float32))
+            if prct_progress > highest_progress:
+                num_no_improve = 0
+                if window_time > 5:
+                    highest_progress = prct_progress
+            else:
+                num_no_improve += 1
+            is_stalling = num_no_improve >= stall_patience
+            rep_count = int(ngram_repeat_mask([history], rep_n).sum())
+            is_repeating = rep_count > rep_n * 2
+            is_last_chunk = encoder_len - chunk_start <= chunk_size
+            reset_window = is_stalling or is_repeating
+            if not is_last_chunk:
+                if reset_window:
+                    chunk_start += int(chunk_size * skip_prct)
+                    if is_repeating:
+                        rollback = 2 * rep_n
+                        gen = gen[:-(rollback - 1)]
+                        alignments = alignments[:-(rollback - 1)]
+                    gen[-1] = eos
+                    history_start = len(gen) - 1
+                    highest_progress = 0
+                    window_time = 0
+                elif prct_progress > thresh_prct:
+                    history_size = len(gen) - history_start
+                    chunk_start += int(chunk_size * shift_prct)
+                    history_start += int(np.floor(np.float32(shift_prct / thresh_prct) * np.float32(history_size - 1)))
+                    highest_progress = 0
+                    window_time = 0
+            # The reference stores the chunk_start *tensor object* in `alignments` and then advances it in
+            # place (system.py:400,441,468), so the recorded value is the post-advance, pre-clamp one.
+            record[0] = chunk_start
+            chunk_start = min(chunk_start, encoder_len - chunk_size)
+            history_start = max(history_start, max(len(gen) - max_positions, 0))
+            assert history_start < len(gen), ("Invalid history start index", history_start, len(gen))
+            assert len(gen) - history_start <= max_positions, ("Exceed max positions", history_start, len(gen))
+            window_time += 1
+            if reset_window and is_last_chunk:
+                break
+        out = torch.tensor([gen], dtype=torch.int64, device=dev)
+        return out, [(torch.tensor([c], dtype=torch.int64), a) for c, a in alignments]

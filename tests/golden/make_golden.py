@@ -219,22 +219,32 @@ def sec_flow(ns):
     # --- aligned beam search, B=2 ragged, beam 1 and 3, with the speaker head (spk_weight>0)
     lens = [160000, 120000]
     audio = synth.synth_audio_batch(2, 160000, 77, lens=lens)
+    term = None
     for beam, spkw in ((1, 1.0), (3, 0.0)):
         me = types.SimpleNamespace(model=model, lm=None, tokenizer=tok,
                                    args=types.SimpleNamespace(spk_weight=spkw, lm_weight=0.0))
+        # beam 1: never terminates (EOS is one token in 10000 with synthetic weights) -> force_output.
+        # beam 3: the reference cannot force_output without the speaker head (system.py:232 zips None)
+        # and cannot use the speaker head with beams (speaker_out is not repeated, :168-171), so it is
+        # run with a terminate token the greedy pass is known to emit, to exercise the finished/done logic.
         seqs, spks = System.generate(me, torch.from_numpy(audio), torch.full((2, 1), BOS, dtype=torch.long),
-                                     torch.tensor(lens), length=24, beam_size=beam, terminate_token=EOS,
-                                     force_half=False, force_output=True)
-        out = {"audio_seed": 77, "audio_lens": np.asarray(lens), "length": 24, "beam": beam}
-        for i, s in enumerate(seqs):
-            out["seq_%d" % i] = s.numpy()
+                                     torch.tensor(lens), length=24, beam_size=beam,
+                                     terminate_token=EOS if beam == 1 else term,
+                                     force_half=False, force_output=(beam == 1))
+        out = {"audio_seed": 77, "audio_lens": np.asarray(lens), "length": 24, "beam": beam,
+               "terminate_token": EOS if beam == 1 else term}
+        for i, sq in enumerate(seqs):
+            out["seq_%d" % i] = sq.numpy() if sq is not None else np.zeros(0, dtype=np.int64)
             if spks[i] is not None:
-                out["spk_%d" % i] = spks[i].numpy()
+                out["spk_argmax_%d" % i] = spks[i].argmax(-1).numpy()
+                out["spk_sample_%d" % i] = spks[i][:, ::200].numpy()
+        if beam == 1:
+            term = int(seqs[0][9])
         save("flow_generate_beam%d" % beam, **out)
 
-    # --- unaligned sliding-window decode on a 60 s clip (audio pre-rounded to the
+    # --- unaligned sliding-window decode on a 150 s clip (audio pre-rounded to the
     # fp16 grid because system.py:285 casts to half before encode)
-    L = 960000
+    L = 2400000
     audio = synth.synth_audio_batch(1, L, 4321)
     audio = audio.astype(np.float16).astype(np.float32)
     me = types.SimpleNamespace(model=model, lm=None, tokenizer=tok,

@@ -1,0 +1,26 @@
+"""CPU tests of the host-side decode helpers and of the multi-GPU sharding logic."""
+import numpy as np
+
+from oracle import tal_oracle as O
+from tal_asrd_amd.util import ngram_repeat_mask, split_speaker_turns
+
+
+def test_ngram_repeat_mask_matches_oracle():
+    rng = np.random.RandomState(0)
+    for _ in range(20):
+        xs = rng.randint(0, 4, size=(2, rng.randint(3, 40)))
+        np.testing.assert_array_equal(ngram_repeat_mask(xs, 3), O.ngram_repeat_mask(xs, 3))
+    xs = np.array([[1, 2, 3, 1, 2, 3, 1, 2, 3, 9]])
+    np.testing.assert_array_equal(ngram_repeat_mask(xs, 3), [[0, 0, 0, 1, 1, 1, 1, 1, 1, 0]])
+    assert ngram_repeat_mask(np.zeros((1, 4), dtype=np.int64), 5).sum() == 0
+
+
+def test_split_speaker_turns():
+    V = 100
+    toks = [0, 5, 6, 1, 1, 103, 7, 8, 1, 9]
+    turns, splits = split_speaker_turns(toks, V)
+    assert turns == [([5, 6], None), ([7, 8], 3), ([9], None)]
+    assert splits == [3, 8, 9]
+    turns, splits = split_speaker_turns(toks, V, add_last=False)
+    assert splits == [3, 8]
+    assert split_speaker_turns([], V) == ([], [])

@@ -61,8 +61,8 @@ def rezero_value(name: str) -> float:
     makes greedy decoding echo its input token forever and the cross-attention is
     uniform, so the decode-loop fixtures would only ever exercise one branch."""
     if "decoder.layers." in name:
-        base = 3.0 if name.endswith("resweight_src") else 2.0
-        return base + 0.1 * (name_seed(name) % 5)
+        base = 2.5 if name.endswith("resweight_src") else 1.5
+        return base + 0.05 * (name_seed(name) % 5)
     return 0.20 + 0.02 * (name_seed(name) % 7)
 
 
@@ -74,7 +74,12 @@ _HEAD_GAIN = {
     "speaker_head.1.weight": 24.0,
     # sharper cross-attention: the window-advance logic of generate_unaligned steers by the
     # centre of mass of these weights (tal/asr/system.py:392-408)
-    "multihead_attn.in_proj_weight": 4.0,
+    "multihead_attn.in_proj_weight": 3.0,
+    # tied embedding / LM head: small enough that greedy decoding does not just echo its input
+    # token (the e.W^T.W.e' self-term scales with gain^2), large enough for a clear arg-max.
+    # These gains were chosen so that fp32 and fp64 evaluations of the decoder agree to ~3e-5
+    # on the logits (a better-conditioned problem than gain 4 / resweight 2-3: 7e-4).
+    "embedding.weight": 0.5,
 }
 
 

@@ -10,7 +10,7 @@ from tests.conftest import golden, has_gpu
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
 
 LOGIT_TOL = 1e-3
-ATTN_TOL = 1e-6
+ATTN_TOL = 1e-4   # probabilities; the synthetic decoder has |scores| ~ 1e2-1e3, so fp32 softmax inputs carry ~1e-4 relative noise on any platform (CPU oracle vs CPU reference: 5e-6 abs)
 
 
 def dev():

@@ -75,7 +75,7 @@ def test_generate_unaligned_trajectory(asr_model):
     np.testing.assert_array_equal(gen.cpu().numpy(), g["generated"])
     np.testing.assert_array_equal(np.array([int(c[0]) for c, _ in align]), g["chunk_start"])
     got_attn = np.stack([a.numpy()[0] for _, a in align])
-    np.testing.assert_allclose(got_attn, g["attn"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(got_attn, g["attn"], atol=1e-4, rtol=0)
     # speaker-change (EOS) indices are a pure function of the token stream -> identical
     want_turns = split_speaker_turns(g["generated"][0].tolist(), 10000)
     got_turns = split_speaker_turns(gen[0].cpu().tolist(), 10000)

@@ -144,7 +144,7 @@ def test_asr_decode(asr_weights):
                 np.testing.assert_allclose(logits[:, -1].numpy(), g["logits_last_" + tag], atol=1e-3, rtol=0)
                 np.testing.assert_allclose(logits[:, 0].numpy(), g["logits_first_" + tag], atol=1e-3, rtol=0)
                 a = torch.stack([w[:, -1] for w in attn], 0).numpy()
-                np.testing.assert_allclose(a, g["attn_last_" + tag], atol=1e-6, rtol=0)
+                np.testing.assert_allclose(a, g["attn_last_" + tag], atol=2e-5, rtol=2e-3)
                 spk = O.asr_decode_spk(g["y_%d" % U], mem, asr_weights, causal_mask=causal)
                 np.testing.assert_allclose(spk[:, -1].numpy(), g["spk_last_" + tag], atol=1e-3, rtol=0)
         lens = [480000, 400000]
@@ -153,7 +153,7 @@ def test_asr_decode(asr_weights):
         logits, attn = O.asr_decode(g["y_b2"], enc2, asr_weights, causal_mask=False)
         np.testing.assert_allclose(logits[:, -1].numpy(), g["logits_last_b2"], atol=1e-3, rtol=0)
         a = torch.stack([w[:, -1] for w in attn], 0).numpy()
-        np.testing.assert_allclose(a, g["attn_last_b2"], atol=1e-6, rtol=0)
+        np.testing.assert_allclose(a, g["attn_last_b2"], atol=2e-5, rtol=2e-3)
         spk = O.asr_decode_spk(g["y_b2"], enc2, asr_weights, causal_mask=False)
         np.testing.assert_allclose(spk[:, -1].numpy(), g["spk_last_b2"], atol=1e-3, rtol=0)
 

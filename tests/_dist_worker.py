@@ -1,0 +1,70 @@
+"""Worker for tests/test_distributed_cpu.py: run under torch.distributed.run with
+world_size 2 on CPU (gloo).  Exercises the N>1 sharding / broadcast / gather / mean
+all-reduce logic of tal_asrd_amd.distributed with a stand-in for the per-segment GPU work."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tal_asrd_amd import distributed as D  # noqa: E402
+
+
+def fake_segment_result(i, length):
+    """Deterministic stand-in for (ids, feat) of segment i with `length` encoder frames."""
+    g = torch.Generator().manual_seed(100 + i)
+    return torch.randint(0, 6008, (length,), generator=g, dtype=torch.int32), torch.randn(length, 8, generator=g)
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert world == 2
+
+    # 1) weight broadcast: rank 1 starts with garbage, ends with rank 0's values
+    lin = torch.nn.Linear(4, 3)
+    with torch.no_grad():
+        lin.weight.fill_(float(rank + 1))
+        lin.bias.fill_(float(rank + 1))
+    D.broadcast_module(lin, src=0)
+    assert float(lin.weight.min()) == 1.0 and float(lin.bias.max()) == 1.0
+
+    # 2) sharding: disjoint cover, deterministic, length-balanced
+    lengths = [3733, 358, 3733, 1200, 44983, 90, 358, 2000]
+    n = len(lengths)
+    mine = D.shard_indices(n, rank, world, weights=lengths)
+    other = D.shard_indices(n, 1 - rank, world, weights=lengths)
+    assert sorted(mine + other) == list(range(n)) and not set(mine) & set(other)
+    assert D.shard_indices(5, rank, world) == list(range(rank, 5, world))
+    loads = [sum(lengths[i] for i in D.shard_indices(n, r, world, weights=lengths)) for r in range(world)]
+    assert max(loads) <= max(lengths) + min(loads)
+
+    # 3) variable-length gather of per-segment outputs to rank 0, item order restored
+    ids_local = {i: fake_segment_result(i, lengths[i])[0] for i in mine}
+    feat_local = {i: fake_segment_result(i, lengths[i])[1] for i in mine}
+    ids = D.gather_segments(ids_local, n, dst=0)
+    feat = D.gather_segments(feat_local, n, dst=0)
+    if rank == 0:
+        for i in range(n):
+            want_ids, want_feat = fake_segment_result(i, lengths[i])
+            assert torch.equal(ids[i], want_ids), i
+            assert torch.equal(feat[i], want_feat), i
+    else:
+        assert ids is None and feat is None
+
+    # 4) one reference "call" split across ranks: the global log-mel mean via (sum, count)
+    full = torch.arange(24, dtype=torch.float64).reshape(2, 3, 4)   # the [B, T, 80]-like tensor of one call
+    part = full[rank]
+    stats = torch.tensor([float(part.sum()), float(part.numel())], dtype=torch.float64)
+    mean = D.allreduce_logmel_stats(stats)
+    assert abs(float(mean) - float(full.mean())) < 1e-6
+
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok" % rank)
+
+
+if __name__ == "__main__":
+    main()

@@ -77,23 +77,19 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs g) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
-    // K tail (K % 32 != 0): out-of-range 16-byte columns read as zero (branch-free: load from a
-    // clamped, always valid offset, then select).  K % 4 == 0 is required by the caller.
+    // K tail (K % 32 != 0): out-of-range 16-byte columns are replaced by zeros when the staged
+    // registers are written to LDS (not at load time: a select right behind the loads would make
+    // every K step wait for its own global loads).  The loads themselves always use a clamped,
+    // valid offset.  K % 4 == 0 is required by the caller.
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 ra[A_LOADS], rb[B_LOADS];
+    bool in_cur = lc4 * 4 < K;
     {
-        const bool in = lc4 * 4 < K;
-        const int ko = in ? 0 : -lc4 * 4;
+        const int ko = in_cur ? 0 : -lc4 * 4;
 #pragma unroll
-        for (int p = 0; p < A_LOADS; ++p) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(At + ko + a_off[p]);
-            ra[p] = in ? v : zero4;
-        }
+        for (int p = 0; p < A_LOADS; ++p) ra[p] = *reinterpret_cast<const f32x4*>(At + ko + a_off[p]);
 #pragma unroll
-        for (int p = 0; p < B_LOADS; ++p) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(Wt + ko + b_off[p]);
-            rb[p] = in ? v : zero4;
-        }
+        for (int p = 0; p < B_LOADS; ++p) rb[p] = *reinterpret_cast<const f32x4*>(Wt + ko + b_off[p]);
     }
 
     const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
@@ -101,24 +97,18 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
         for (int p = 0; p < A_LOADS; ++p)
-            *reinterpret_cast<f32x4*>(&As[(lrow + 32 * p) * LDS_LD + lc4 * 4]) = ra[p];
+            *reinterpret_cast<f32x4*>(&As[(lrow + 32 * p) * LDS_LD + lc4 * 4]) = in_cur ? ra[p] : zero4;
 #pragma unroll
         for (int p = 0; p < B_LOADS; ++p)
-            *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * p) * LDS_LD + lc4 * 4]) = rb[p];
+            *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * p) * LDS_LD + lc4 * 4]) = in_cur ? rb[p] : zero4;
         __syncthreads();
         if (kt + 1 < nk) {
-            const bool in = (kt + 1) * BK + lc4 * 4 < K;
-            const int ko = in ? (kt + 1) * BK : -lc4 * 4;
+            in_cur = (kt + 1) * BK + lc4 * 4 < K;
+            const int ko = in_cur ? (kt + 1) * BK : -lc4 * 4;
 #pragma unroll
-            for (int p = 0; p < A_LOADS; ++p) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(At + ko + a_off[p]);
-                ra[p] = in ? v : zero4;
-            }
+            for (int p = 0; p < A_LOADS; ++p) ra[p] = *reinterpret_cast<const f32x4*>(At + ko + a_off[p]);
 #pragma unroll
-            for (int p = 0; p < B_LOADS; ++p) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(Wt + ko + b_off[p]);
-                rb[p] = in ? v : zero4;
-            }
+            for (int p = 0; p < B_LOADS; ++p) rb[p] = *reinterpret_cast<const f32x4*>(Wt + ko + b_off[p]);
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
@@ -136,24 +126,77 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs g) {
         __syncthreads();
     }
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // ---- epilogue ---------------------------------------------------------------------------
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
     const int colb = lane & 31;
     const int rowb = 4 * (lane >> 5);
     const float alpha = g.alpha;
+    constexpr int CW = 32 * NSUB;  // columns owned by one wave
+    const bool vec_ok = (g.ldy % 4 == 0) && (MODE != 2 || g.ldres % 4 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) &&
+                        (MODE != 2 || (reinterpret_cast<uintptr_t>(res) & 15) == 0);
+    if (vec_ok) {
+        // Stage the wave's tile through LDS (the operand buffers are dead after the last barrier),
+        // 16 rows at a time, and write whole rows with 16-byte stores: a wave-wide store covers
+        // 1 KB of (nearly) contiguous output instead of two 128-byte row segments, and the ReZero
+        // residual is read the same way.  Each wave only touches its own LDS slice, so no barrier.
+        float* stage = lds + w * (16 * CW);
+        const int n_base = n0 + wn * CW;
 #pragma unroll
-    for (int j = 0; j < NSUB; ++j) {
-        const int col = n0 + (wn * NSUB + j) * 32 + colb;
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
+        for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t row = m0 + wm * 32 + rowb + (e & 3) + 8 * (e >> 2);
-            if (row < M) {
-                float v = acc[j][e] + bv;
-                if (MODE == 1) v = fmaxf(v, 0.f);
-                if (MODE == 2) v = res[row * g.ldres + col] + alpha * v;
-                if (MODE == 3) v = alpha * v;
-                Y[row * g.ldy + col] = v;
+            for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = half * 8 + e8;
+                    const int r = rowb + (e8 & 3) + 8 * (e8 >> 2);  // 0..15 inside this half
+                    stage[r * CW + j * 32 + colb] = acc[j][e];
+                }
+#pragma unroll
+            for (int t = 0; t < 2 * NSUB; ++t) {
+                const int i = lane + 64 * t;
+                const int r = i / (CW / 4);
+                const int c = (i - r * (CW / 4)) * 4;
+                const int64_t row = m0 + wm * 32 + half * 16 + r;
+                const int col = n_base + c;
+                if (row < M && col < N) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&stage[r * CW + c]);
+                    if (col + 3 < N) {
+                        if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+                        if (MODE == 1) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                        if (MODE == 2) v = *reinterpret_cast<const f32x4*>(res + row * g.ldres + col) + alpha * v;
+                        if (MODE == 3) v = alpha * v;
+                        *reinterpret_cast<f32x4*>(Y + row * g.ldy + col) = v;
+                    } else {
+                        for (int q = 0; q < 4 && col + q < N; ++q) {
+                            float x = v[q] + (bias ? bias[col + q] : 0.f);
+                            if (MODE == 1) x = fmaxf(x, 0.f);
+                            if (MODE == 2) x = res[row * g.ldres + col + q] + alpha * x;
+                            if (MODE == 3) x = alpha * x;
+                            Y[row * g.ldy + col + q] = x;
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+            const int col = n0 + (wn * NSUB + j) * 32 + colb;
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = m0 + wm * 32 + rowb + (e & 3) + 8 * (e >> 2);
+                if (row < M) {
+                    float v = acc[j][e] + bv;
+                    if (MODE == 1) v = fmaxf(v, 0.f);
+                    if (MODE == 2) v = res[row * g.ldres + col] + alpha * v;
+                    if (MODE == 3) v = alpha * v;
+                    Y[row * g.ldy + col] = v;
+                }
             }
         }
     }

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtal_asrd_hip.so")
+LIB_PATH = os.environ.get("TAL_ASRD_LIB", os.path.join(_HERE, "libtal_asrd_hip.so"))  # override: kernel ablation builds only
 
 TAL_MAX_STAGES = 4
 TAL_MAX_DEPTH = 8

@@ -8,21 +8,251 @@
 //
 // Arithmetic: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate; bit-for-bit an fmaf chain),
 // so results stay inside the 1e-3 fp32 logit tolerance of BASELINE.json without any
-// reduced-precision trick.  Roofline: 157.3 TFLOP/s (fp32 matrix peak of MI355X).
+// reduced-precision trick.  Roofline: 157.3 TFLOP/s (fp32 matrix peak of MI355X; a pure-MFMA
+// loop reaches 155 on this chip, scripts/ubench/mfma_peak.hip).
 //
-// Two tilings of the same kernel (4 waves, each wave owns 32 rows x 32*NSUB columns):
-//   big   128(M) x 160(N) x 32(K): waves stacked along M, 5 accumulators per wave.  160 divides
-//         every TDS width (800 = 5*160, 1120 = 7*160, 1440 = 9*160): no N-tail waste.
-//   small  32(M) x 128(N) x 32(K): waves side by side along N, for the decoder's short
-//         (M = batch x prefix <= a few hundred rows) problems where a 128-row tile idles.
-// LDS rows are padded to 36 floats: ds_read_b128 of 16 rows x 4 floats is conflict-free.
+// Three kernels, all 4 waves x (32 rows x 32*NSUB columns) of 32x32 accumulators:
+//   gemm_glds_kernel    128(M) x 160(N) x 32(K), the hot one (M > 512, K % 32 == 0).  Operand
+//       tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write),
+//       double-buffered, ONE barrier per K step; the LDS image is lane-linear, so bank conflicts
+//       are removed by an XOR swizzle applied to the per-lane SOURCE address and again on the
+//       fragment read.  160 divides every TDS width (800/1120/1440): no N-tail waste.
+//   gemm_nt_f32_kernel<.,4,5>  same tile, register-staged, single LDS buffer: K tails
+//       (K % 32 != 0; only small test models).
+//   gemm_nt_f32_kernel<.,1,1>  32(M) x 128(N): the decoder's short problems (M <= 512 rows).
+// Epilogue (shared): the wave's tile is staged through LDS 16 rows at a time and written as
+// whole rows with 16-byte stores; bias / ReLU / ReZero-residual / scale are fused; all bias and
+// residual loads of a half tile are issued before any of them is consumed.
 #include "common.h"
 
 namespace tal {
 
 constexpr int BK = 32;
-constexpr int LDS_LD = 36;
+constexpr int LDS_LD = 36;  // padded pitch of the register-staged kernels
 
+// ---------------------------------------------------------------------------------------------
+// shared epilogue
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int NSUB>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[NSUB], float* lds, float* Y,
+                                              const float* bias, const float* res, int64_t m0, int n0, int lane,
+                                              int w, int wm, int wn) {
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    const int64_t M = g.M;
+    const int N = g.N;
+    const int colb = lane & 31;
+    const int rowb = 4 * (lane >> 5);
+    const float alpha = g.alpha;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int CW = 32 * NSUB;  // columns owned by one wave
+    const bool vec_ok = (g.ldy % 4 == 0) && (MODE != 2 || g.ldres % 4 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) &&
+                        (MODE != 2 || (reinterpret_cast<uintptr_t>(res) & 15) == 0);
+    if (vec_ok) {
+        // Each wave only touches its own LDS slice, so no barrier inside the epilogue.
+        float* stage = lds + w * (16 * CW);
+        const int n_base = n0 + wn * CW;
+        const bool cols_full = n_base + CW <= N;  // wave-uniform
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = half * 8 + e8;
+                    const int r = rowb + (e8 & 3) + 8 * (e8 >> 2);  // 0..15 inside this half
+                    stage[r * CW + j * 32 + colb] = acc[j][e];
+                }
+            if (cols_full) {
+                // Interior fast path: loads first (clamped rows, no branch in front of a load, so
+                // they overlap instead of costing one round trip each); only stores are predicated.
+                f32x4 rv[2 * NSUB], bv[2 * NSUB];
+                int64_t rowv[2 * NSUB];
+                int colv[2 * NSUB], ldsv[2 * NSUB];
+#pragma unroll
+                for (int t = 0; t < 2 * NSUB; ++t) {
+                    const int i = lane + 64 * t;
+                    const int r = i / (CW / 4);
+                    const int c = (i - r * (CW / 4)) * 4;
+                    rowv[t] = m0 + wm * 32 + half * 16 + r;
+                    colv[t] = n_base + c;
+                    ldsv[t] = r * CW + c;
+                    const int64_t rc = rowv[t] < M ? rowv[t] : M - 1;
+                    if (MODE == 2) rv[t] = *reinterpret_cast<const f32x4*>(res + rc * g.ldres + colv[t]);
+                    bv[t] = bias ? *reinterpret_cast<const f32x4*>(bias + colv[t]) : zero4;
+                }
+#pragma unroll
+                for (int t = 0; t < 2 * NSUB; ++t) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&stage[ldsv[t]]) + bv[t];
+                    if (MODE == 1) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    if (MODE == 2) v = rv[t] + alpha * v;
+                    if (MODE == 3) v = alpha * v;
+                    if (rowv[t] < M) *reinterpret_cast<f32x4*>(Y + rowv[t] * g.ldy + colv[t]) = v;
+                }
+                continue;
+            }
+#pragma unroll
+            for (int t = 0; t < 2 * NSUB; ++t) {
+                const int i = lane + 64 * t;
+                const int r = i / (CW / 4);
+                const int c = (i - r * (CW / 4)) * 4;
+                const int64_t row = m0 + wm * 32 + half * 16 + r;
+                const int col = n_base + c;
+                if (row < M && col < N) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&stage[r * CW + c]);
+                    if (col + 3 < N) {
+                        if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+                        if (MODE == 1) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                        if (MODE == 2) v = *reinterpret_cast<const f32x4*>(res + row * g.ldres + col) + alpha * v;
+                        if (MODE == 3) v = alpha * v;
+                        *reinterpret_cast<f32x4*>(Y + row * g.ldy + col) = v;
+                    } else {
+                        for (int q = 0; q < 4 && col + q < N; ++q) {
+                            float x = v[q] + (bias ? bias[col + q] : 0.f);
+                            if (MODE == 1) x = fmaxf(x, 0.f);
+                            if (MODE == 2) x = res[row * g.ldres + col + q] + alpha * x;
+                            if (MODE == 3) x = alpha * x;
+                            Y[row * g.ldy + col + q] = x;
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+            const int col = n0 + (wn * NSUB + j) * 32 + colb;
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = m0 + wm * 32 + rowb + (e & 3) + 8 * (e >> 2);
+                if (row < M) {
+                    float v = acc[j][e] + bv;
+                    if (MODE == 1) v = fmaxf(v, 0.f);
+                    if (MODE == 2) v = res[row * g.ldres + col] + alpha * v;
+                    if (MODE == 3) v = alpha * v;
+                    Y[row * g.ldy + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// XCD-aware bijective remap: XCD x (= blockIdx % 8) walks a contiguous range of logical tiles,
+// N-tiles of one M-tile first, so the A panel is re-read from that XCD's L2.
+__device__ __forceinline__ unsigned logical_tile() {
+    const unsigned nb = gridDim.x, bid = blockIdx.x;
+    const unsigned xcd = bid & 7u, q = nb >> 3, r = nb & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// hot kernel: direct-to-LDS operand loads, double buffer, one barrier per K step
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
+    constexpr int NSUB = 5, BM = 128, BN = 160;
+    constexpr int ROWS = BM + BN;                 // 288 operand rows of 32 floats (128 B) per K step
+    constexpr int CHUNKS = ROWS / 8;              // 36 wave-loads of 1 KB (8 rows) each
+    constexpr int PER_WAVE = CHUNKS / 4;          // 9: t < 4 -> A rows, t >= 4 -> W rows
+    __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * 32];  // 73,728 B -> 2 workgroups / CU
+
+    const unsigned logical = logical_tile();
+    const int64_t m0 = (int64_t)(logical / (unsigned)g.tiles_n) * BM;
+    const int n0 = (int)(logical % (unsigned)g.tiles_n) * BN;
+    const int64_t M = g.M;
+    const int N = g.N, K = g.K;
+    const int z1 = (int)blockIdx.y / g.nb2, z2 = (int)blockIdx.y % g.nb2;
+    const float* A = g.A + z1 * g.a_s1 + z2 * g.a_s2;
+    const float* W = g.W + z1 * g.w_s1 + z2 * g.w_s2;
+    float* Y = g.Y + z1 * g.y_s1 + z2 * g.y_s2;
+    const float* bias = g.bias ? g.bias + z2 * g.bias_s2 : nullptr;
+    const float* res = g.res ? g.res + z1 * g.r_s1 + z2 * g.r_s2 : nullptr;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = wave_id();
+    const int wm = w, wn = 0;
+
+    // Wave w loads chunks i = w + 4t.  A chunk is 8 rows x 128 B; lane l lands at LDS byte
+    // i*1024 + l*16 = row (8i + l/8), 16-byte slot (l%8).  Slot s of row r holds the row's logical
+    // 16-byte column s ^ (r & 7) (= s ^ (l >> 3), a per-lane constant): the swizzle is applied to
+    // the global source address, the LDS destination stays linear as the instruction requires.
+    const int sub = lane >> 3;                    // row inside the chunk == row & 7
+    const int srccol = ((lane & 7) ^ sub) * 4;    // logical float column this lane fetches
+    const int a_rows = (int)((M - m0) < BM ? (M - m0) : BM) - 1;
+    const int b_rows = ((N - n0) < BN ? (N - n0) : BN) - 1;
+    const float* src[PER_WAVE];
+#pragma unroll
+    for (int t = 0; t < PER_WAVE; ++t) {
+        const int row = 8 * (w + 4 * t) + sub;    // 0..287
+        if (t < 4)
+            src[t] = A + (m0 + min(row, a_rows)) * g.lda + srccol;
+        else
+            src[t] = W + (int64_t)(n0 + min(row - BM, b_rows)) * g.ldw + srccol;
+    }
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int t = 0; t < PER_WAVE; ++t) {
+            float* dst = lds + buf * (ROWS * 32) + (w + 4 * t) * 256;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[NSUB];
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    // fragment read: row (l & 31) of a 32-row block, logical 16-byte column 2*kk + (l >> 5)
+    const int frow = lane & 31;
+    const int fsw = frow & 7;
+    const int fhalf = lane >> 5;
+    const int nk = K / BK;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed (vmcnt(0) is part of the barrier while LDS-DMA is in flight) and every
+        // wave is done reading the other buffer (it finished step kt-1 before arriving here)
+        __syncthreads();
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const float* As = lds + (kt & 1) * (ROWS * 32) + (wm * 32 + frow) * 32;
+        const float* Bs = lds + (kt & 1) * (ROWS * 32) + (BM + frow) * 32;
+        f32x4 fa[2], fb[2][NSUB];
+        fa[0] = *reinterpret_cast<const f32x4*>(As + ((fhalf) ^ fsw) * 4);
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * 32 + ((fhalf) ^ fsw) * 4);
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 8) {
+                const int sl = ((2 * (kk + 1) + fhalf) ^ fsw) * 4;
+                fa[nxt] = *reinterpret_cast<const f32x4*>(As + sl);
+#pragma unroll
+                for (int j = 0; j < NSUB; ++j) fb[nxt][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * 32 + sl);
+            }
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur][j].x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur][j].y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].z, fb[cur][j].z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].w, fb[cur][j].w, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();  // all waves done with the operand buffers before they become the store stage
+    gemm_epilogue<MODE, NSUB>(g, acc, lds, Y, bias, res, m0, n0, lane, w, wm, wn);
+}
+
+// ---------------------------------------------------------------------------------------------
+// register-staged kernels (K tails, and the small tile)
+// ---------------------------------------------------------------------------------------------
 template <int MODE, int WAVES_M, int NSUB>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs g) {
     constexpr int WAVES_N = 4 / WAVES_M;
@@ -34,12 +264,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs g) {
     float* As = lds;
     float* Bs = lds + BM * LDS_LD;
 
-    // XCD-aware bijective remap: XCD x (= blockIdx % 8) walks a contiguous range of logical
-    // tiles, N-tiles of one M-tile first, so the A panel is re-read from that XCD's L2.
-    const unsigned nb = gridDim.x;
-    const unsigned bid = blockIdx.x;
-    const unsigned xcd = bid & 7u, q = nb >> 3, r = nb & 7u;
-    const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const unsigned logical = logical_tile();
     const int64_t m0 = (int64_t)(logical / (unsigned)g.tiles_n) * BM;
     const int n0 = (int)(logical % (unsigned)g.tiles_n) * BN;
     const int64_t M = g.M;
@@ -110,96 +335,34 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs g) {
 #pragma unroll
             for (int p = 0; p < B_LOADS; ++p) rb[p] = *reinterpret_cast<const f32x4*>(Wt + ko + b_off[p]);
         }
+        // Fragments of k-slice kk+1 are fetched from LDS (into a second register set) before the
+        // MFMAs of slice kk issue.
+        f32x4 fa[2], fb[2][NSUB];
+        fa[0] = *reinterpret_cast<const f32x4*>(&As[wm * 32 * LDS_LD + frag_off]);
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j)
+            fb[0][j] = *reinterpret_cast<const f32x4*>(&Bs[(wn * NSUB + j) * 32 * LDS_LD + frag_off]);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[wm * 32 * LDS_LD + frag_off + kk * 8]);
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 8) {
+                fa[nxt] = *reinterpret_cast<const f32x4*>(&As[wm * 32 * LDS_LD + frag_off + (kk + 1) * 8]);
+#pragma unroll
+                for (int j = 0; j < NSUB; ++j)
+                    fb[nxt][j] = *reinterpret_cast<const f32x4*>(
+                        &Bs[(wn * NSUB + j) * 32 * LDS_LD + frag_off + (kk + 1) * 8]);
+            }
 #pragma unroll
             for (int j = 0; j < NSUB; ++j) {
-                const f32x4 b =
-                    *reinterpret_cast<const f32x4*>(&Bs[(wn * NSUB + j) * 32 * LDS_LD + frag_off + kk * 8]);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur][j].x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur][j].y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].z, fb[cur][j].z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].w, fb[cur][j].w, acc[j], 0, 0, 0);
             }
         }
         __syncthreads();
     }
-
-    // ---- epilogue ---------------------------------------------------------------------------
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-    const int colb = lane & 31;
-    const int rowb = 4 * (lane >> 5);
-    const float alpha = g.alpha;
-    constexpr int CW = 32 * NSUB;  // columns owned by one wave
-    const bool vec_ok = (g.ldy % 4 == 0) && (MODE != 2 || g.ldres % 4 == 0) &&
-                        ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) &&
-                        (MODE != 2 || (reinterpret_cast<uintptr_t>(res) & 15) == 0);
-    if (vec_ok) {
-        // Stage the wave's tile through LDS (the operand buffers are dead after the last barrier),
-        // 16 rows at a time, and write whole rows with 16-byte stores: a wave-wide store covers
-        // 1 KB of (nearly) contiguous output instead of two 128-byte row segments, and the ReZero
-        // residual is read the same way.  Each wave only touches its own LDS slice, so no barrier.
-        float* stage = lds + w * (16 * CW);
-        const int n_base = n0 + wn * CW;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-#pragma unroll
-            for (int j = 0; j < NSUB; ++j)
-#pragma unroll
-                for (int e8 = 0; e8 < 8; ++e8) {
-                    const int e = half * 8 + e8;
-                    const int r = rowb + (e8 & 3) + 8 * (e8 >> 2);  // 0..15 inside this half
-                    stage[r * CW + j * 32 + colb] = acc[j][e];
-                }
-#pragma unroll
-            for (int t = 0; t < 2 * NSUB; ++t) {
-                const int i = lane + 64 * t;
-                const int r = i / (CW / 4);
-                const int c = (i - r * (CW / 4)) * 4;
-                const int64_t row = m0 + wm * 32 + half * 16 + r;
-                const int col = n_base + c;
-                if (row < M && col < N) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(&stage[r * CW + c]);
-                    if (col + 3 < N) {
-                        if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
-                        if (MODE == 1) {
-                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                        }
-                        if (MODE == 2) v = *reinterpret_cast<const f32x4*>(res + row * g.ldres + col) + alpha * v;
-                        if (MODE == 3) v = alpha * v;
-                        *reinterpret_cast<f32x4*>(Y + row * g.ldy + col) = v;
-                    } else {
-                        for (int q = 0; q < 4 && col + q < N; ++q) {
-                            float x = v[q] + (bias ? bias[col + q] : 0.f);
-                            if (MODE == 1) x = fmaxf(x, 0.f);
-                            if (MODE == 2) x = res[row * g.ldres + col + q] + alpha * x;
-                            if (MODE == 3) x = alpha * x;
-                            Y[row * g.ldy + col + q] = x;
-                        }
-                    }
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NSUB; ++j) {
-            const int col = n0 + (wn * NSUB + j) * 32 + colb;
-            if (col >= N) continue;
-            const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t row = m0 + wm * 32 + rowb + (e & 3) + 8 * (e >> 2);
-                if (row < M) {
-                    float v = acc[j][e] + bv;
-                    if (MODE == 1) v = fmaxf(v, 0.f);
-                    if (MODE == 2) v = res[row * g.ldres + col] + alpha * v;
-                    if (MODE == 3) v = alpha * v;
-                    Y[row * g.ldy + col] = v;
-                }
-            }
-        }
-    }
+    gemm_epilogue<MODE, NSUB>(g, acc, lds, Y, bias, res, m0, n0, lane, w, wm, wn);
 }
 
 template <int WAVES_M, int NSUB>
@@ -209,6 +372,15 @@ static void launch_tile(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
         case 1: hipLaunchKernelGGL((gemm_nt_f32_kernel<1, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
         case 2: hipLaunchKernelGGL((gemm_nt_f32_kernel<2, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
         default: hipLaunchKernelGGL((gemm_nt_f32_kernel<3, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
+    }
+}
+
+static void launch_glds(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(gemm_glds_kernel<0>, grid, dim3(256), 0, s, g); break;
+        case 1: hipLaunchKernelGGL(gemm_glds_kernel<1>, grid, dim3(256), 0, s, g); break;
+        case 2: hipLaunchKernelGGL(gemm_glds_kernel<2>, grid, dim3(256), 0, s, g); break;
+        default: hipLaunchKernelGGL(gemm_glds_kernel<3>, grid, dim3(256), 0, s, g); break;
     }
 }
 
@@ -227,8 +399,11 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
     TAL_CHECK_ARG(nb < (1ll << 31), "gemm: grid too large");
     dim3 grid((unsigned)nb, (unsigned)nbatch);
     ProfScope prof(PROF_GEMM, 2.0 * (double)g.M * (double)g.N * (double)g.K * nbatch, s);
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) == 0;
     if (small)
         launch_tile<1, 1>(g, mode, grid, s);
+    else if (g.K % BK == 0 && aligned16 && !getenv("TAL_GEMM_NO_GLDS"))
+        launch_glds(g, mode, grid, s);
     else
         launch_tile<4, 5>(g, mode, grid, s);
     TAL_CHECK_LAUNCH("gemm");

@@ -38,13 +38,35 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float* __restrict__ x,
 
     const float* xb = x + (int64_t)b * T_in * C_in + g0 * CIG;
     const int64_t tin0 = t0 * STRIDE - PAD;
-    for (int idx = tid; idx < TIN * CH; idx += 256) {
-        const int ti = idx / CH;
-        const int c = idx - ti * CH;
-        const int64_t t = tin0 + ti;
-        float v = 0.f;
-        if (t >= 0 && t < T_in) v = xb[t * C_in + c];
-        xs[c * TINP + ti] = v;
+    // Slab load: 16-byte global loads (the CH channels of a time step are contiguous and 16-byte
+    // aligned), four in flight per thread with clamped addresses + select (no branch in front of a
+    // load), then the transposing scalar LDS stores.
+    static_assert(CH % 4 == 0, "a group slab must be a whole number of 16-byte columns");
+    constexpr int CH4 = CH / 4;
+    constexpr int NV = TIN * CH4;
+    constexpr int UNR = 4;
+    for (int base = 0; base < NV; base += 256 * UNR) {
+        f32x4 v[UNR];
+        int tiv[UNR], cv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = base + u * 256 + tid;
+            const int ti = idx / CH4;
+            tiv[u] = idx < NV ? ti : -1;
+            cv[u] = (idx - ti * CH4) * 4;
+            const int64_t t = tin0 + ti;
+            const bool in = idx < NV && t >= 0 && t < T_in;
+            const int64_t tc = in ? t : (T_in - 1 < 0 ? 0 : (t < 0 ? 0 : T_in - 1));
+            const f32x4 ld = *reinterpret_cast<const f32x4*>(xb + tc * C_in + (idx < NV ? cv[u] : 0));
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            v[u] = in ? ld : z;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (tiv[u] >= 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xs[(cv[u] + q) * TINP + tiv[u]] = v[u][q];
+            }
     }
     __syncthreads();
 

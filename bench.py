@@ -93,19 +93,30 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    # TAL_BENCH_BACKEND=gloo is a plumbing self-test only (N ranks sharing the visible GPUs, results
+    # staged through host memory); real runs use RCCL ("nccl") with one GPU per rank.
+    backend = os.environ.get("TAL_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     model, sd = build_model(dev)
     if dist is not None:
         # weights come from rank 0 over RCCL/xGMI (one flat broadcast per tensor, start-up only)
         for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, src=0)
+            if backend == "nccl":
+                dist.broadcast(t.data, src=0)
+            else:
+                h = t.data.cpu()
+                dist.broadcast(h, src=0)
+                t.data.copy_(h)
 
     L = int(args.seconds * 16000)
     frames = 1 + L // 160
@@ -123,6 +134,8 @@ def main():
         if dist is not None:
             feat = torch.cat([o[0].reshape(-1, o[0].shape[-1]) for o in outs])
             ids = torch.cat([o[1].reshape(-1) for o in outs])
+            if backend != "nccl":
+                feat, ids = feat.cpu(), ids.cpu()
             dist.gather(feat, gather_feat if rank == 0 else None, dst=0)
             dist.gather(ids, gather_ids if rank == 0 else None, dst=0)
         return outs
@@ -131,8 +144,9 @@ def main():
         if dist is not None and rank == 0:
             f0, i0 = model.speaker_ids(clips[0])
             n_rows = f0.shape[-2] * args.segments
-            gather_feat = [torch.empty(n_rows, f0.shape[-1], device=dev) for _ in range(world)]
-            gather_ids = [torch.empty(n_rows, dtype=torch.int32, device=dev) for _ in range(world)]
+            gdev = dev if backend == "nccl" else torch.device("cpu")
+            gather_feat = [torch.empty(n_rows, f0.shape[-1], device=gdev) for _ in range(world)]
+            gather_ids = [torch.empty(n_rows, dtype=torch.int32, device=gdev) for _ in range(world)]
         for _ in range(args.warmup):
             step()
         lib = _native.lib()
@@ -156,7 +170,7 @@ def main():
             lib.tal_prof_enable(0)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -25,7 +25,13 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float* __restrict__ x,
     constexpr int PAD = RESID ? KS / 2 : 0;
     constexpr int TIN = (TT - 1) * STRIDE + KS;
     constexpr int TINP = TIN | 1;
-    constexpr int R = TT / 64;
+    // GB >= 4: wave w walks groups w, w+4, ... over the whole time tile.  GB < 4: 4/GB waves share a
+    // group and split the time tile (smaller LDS slab per workgroup -> more workgroups per CU, so
+    // one workgroup's slab load overlaps another's FMA phase).
+    constexpr int WPG = GB >= 4 ? 1 : 4 / GB;      // waves per group
+    constexpr int TW = TT / WPG;                   // time steps per wave
+    constexpr int R = TW / 64;
+    static_assert(TW % 64 == 0 && R >= 1, "time tile per wave must be a multiple of 64");
     constexpr int CH = GB * CIG;
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [CH][TINP]
 
@@ -70,7 +76,9 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float* __restrict__ x,
     }
     __syncthreads();
 
-    for (int gl = w; gl < GB; gl += 4) {
+    const int part = w % WPG;                      // which slice of the time tile this wave owns
+    const int tl0 = part * TW + lane;              // first local time step of this lane
+    for (int gl = w / WPG; gl < GB; gl += 4 / WPG) {
         const int g = g0 + gl;
         float acc[R][COG];
 #pragma unroll
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float* __restrict__ x,
             for (int r = 0; r < R; ++r) acc[r][co] = bv;
         }
         const float* wg = wp + (int64_t)g * (CIG * KS * COG);
-        const float* xl = xs + gl * CIG * TINP + lane * STRIDE;
+        const float* xl = xs + gl * CIG * TINP + tl0 * STRIDE;
 #pragma unroll 1
         for (int ci = 0; ci < CIG; ++ci) {
             const float* wc = wg + ci * (KS * COG);
@@ -101,13 +109,13 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float* __restrict__ x,
         float* yb = y + (int64_t)b * T_out * C_out + g * COG;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int64_t t = t0 + lane + 64 * r;
+            const int64_t t = t0 + tl0 + 64 * r;
             if (t < T_out) {
 #pragma unroll
                 for (int co = 0; co < COG; ++co) {
                     float v = acc[r][co];
                     if (RESID) {
-                        const float xin = xs[(gl * CIG + co) * TINP + lane + 64 * r + PAD];
+                        const float xin = xs[(gl * CIG + co) * TINP + tl0 + 64 * r + PAD];
                         v = xin + alpha * fmaxf(v, 0.f);
                     }
                     yb[t * C_out + co] = v;
@@ -187,6 +195,7 @@ int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, i
     const int cig = C_in / groups, cog = C_out / groups;
     if (cig == 1 && cog == 10 && groups % 16 == 0)
         return launch_spec<1, 10, 2, 16, 128, false>(x, wp, bias, 0.f, y, B, T_in, T_out, C_in, C_out, groups, s);
+    // (4 groups x 128 outputs beats 2 x 256 here: 72 / 54 vs 67 / 46 TFLOP/s on the 1-hour shapes)
     if (cig == 10 && cog == 14 && groups % 4 == 0)
         return launch_spec<10, 14, 2, 4, 128, false>(x, wp, bias, 0.f, y, B, T_in, T_out, C_in, C_out, groups, s);
     if (cig == 14 && cog == 18 && groups % 4 == 0)
@@ -201,12 +210,14 @@ int launch_gconv_res(const float* x, const float* wp, const float* bias, float a
     TAL_CHECK_ARG(groups > 0 && C % groups == 0, "tal_gconv_res_fwd: C=%d not divisible by groups %d", C, groups);
     TAL_CHECK_ARG(B > 0 && T > 0, "tal_gconv_res_fwd: bad shape");
     const int cg = C / groups;
-    if (cg == 10 && groups % 4 == 0)
-        return launch_spec<10, 10, 1, 4, 256, true>(x, wp, bias, alpha, y, B, T, T, C, C, groups, s);
-    if (cg == 14 && groups % 4 == 0)
-        return launch_spec<14, 14, 1, 4, 256, true>(x, wp, bias, alpha, y, B, T, T, C, C, groups, s);
-    if (cg == 18 && groups % 4 == 0)
-        return launch_spec<18, 18, 1, 4, 256, true>(x, wp, bias, alpha, y, B, T, T, C, C, groups, s);
+    // 2 groups x 256 time steps per workgroup (2 waves per group): 22-40 KB slabs, 4+ workgroups
+    // per CU.  Measured on the 1-hour shapes: 66 / 85 / 85 TFLOP/s vs 61 / 67 / 70 with 4 groups.
+    if (cg == 10 && groups % 2 == 0)
+        return launch_spec<10, 10, 1, 2, 256, true>(x, wp, bias, alpha, y, B, T, T, C, C, groups, s);
+    if (cg == 14 && groups % 2 == 0)
+        return launch_spec<14, 14, 1, 2, 256, true>(x, wp, bias, alpha, y, B, T, T, C, C, groups, s);
+    if (cg == 18 && groups % 2 == 0)
+        return launch_spec<18, 18, 1, 2, 256, true>(x, wp, bias, alpha, y, B, T, T, C, C, groups, s);
     return launch_generic<true>(x, wp, bias, alpha, y, B, T, T, C, C, groups, 1, s);
 }
 

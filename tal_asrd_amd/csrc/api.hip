@@ -68,6 +68,24 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
     if (lane == 0) ids[row] = bi == 0x7fffffff ? 0 : bi;
 }
 
+// final reduction of the fused arg-max partials (ascending column slices; strict '>' keeps the lowest index)
+__global__ __launch_bounds__(256) void argmax_partials_kernel(const float* __restrict__ pv,
+                                                             const int32_t* __restrict__ pi, int64_t M, int P, int ld,
+                                                             int32_t* __restrict__ ids) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    float best = -INFINITY;
+    int bi = 0;
+    for (int p = 0; p < P; ++p) {
+        const float v = pv[row * ld + p];
+        if (v > best) {
+            best = v;
+            bi = pi[row * ld + p];
+        }
+    }
+    ids[row] = bi;
+}
+
 int launch_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, hipStream_t s) {
     TAL_CHECK_ARG(x && ids && N > 0 && M >= 0, "tal_argmax_rows: bad argument");
     if (M == 0) return TAL_OK;
@@ -231,11 +249,9 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
 // ---------------------------------------------------------------------------------------
 // Diarization head
 // ---------------------------------------------------------------------------------------
-static const int64_t SD_CHUNK = 16384;
-
 extern "C" size_t tal_sd_head_workspace_bytes(int64_t M, int S) {
-    const int64_t rows = M < SD_CHUNK ? M : SD_CHUNK;
-    return (size_t)(rows > 0 ? rows : 1) * (size_t)S * sizeof(float);
+    // (value, index) partials of the fused arg-max: one pair per row and per 32 columns at most
+    return (size_t)(M > 0 ? M : 1) * (size_t)cdiv(S, 32) * 8;
 }
 
 extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_embed, const float* b_embed, int E,
@@ -257,13 +273,24 @@ extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_
         set_error("tal_sd_head_fwd: workspace %zu < %zu bytes", workspace_bytes, tal_sd_head_workspace_bytes(M, S));
         return TAL_ENOMEM;
     }
-    float* tmp = reinterpret_cast<float*>(workspace);
-    for (int64_t r0 = 0; r0 < M; r0 += SD_CHUNK) {
-        const int64_t rows = M - r0 < SD_CHUNK ? M - r0 : SD_CHUNK;
-        rc = launch_linear(feat + r0 * E, w_logit, b_logit, nullptr, 0.f, 0, rows, S, E, tmp, s);
-        if (rc) return rc;
-        rc = launch_argmax_rows(tmp, rows, S, ids + r0, s);
-        if (rc) return rc;
+    if (M == 0) return TAL_OK;
+    // logits are never materialised: the dense layer's epilogue reduces each row of its tile to a
+    // (max, arg-max) pair, a tiny second kernel merges the pairs of a row's column tiles
+    const int ld = (int)cdiv(S, 32);
+    GemmArgs g = {};
+    g.A = feat; g.W = w_logit; g.bias = b_logit;
+    g.M = M; g.N = S; g.K = E;
+    g.lda = E; g.ldw = E; g.ldy = S; g.nb2 = 1;
+    g.part_val = reinterpret_cast<float*>(workspace);
+    g.part_idx = reinterpret_cast<int32_t*>(g.part_val + (size_t)M * ld);
+    g.part_ld = ld;
+    rc = launch_gemm(g, 4, 1, s);
+    if (rc) return rc;
+    {
+        ProfScope prof(PROF_OTHER, (double)M * ld * 8.0, s);
+        hipLaunchKernelGGL(argmax_partials_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, g.part_val, g.part_idx, M,
+                           gemm_mode4_partials(M, S), ld, ids);
     }
+    TAL_CHECK_LAUNCH("tal_sd_head_fwd(argmax)");
     return TAL_OK;
 }

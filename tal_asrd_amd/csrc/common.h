@@ -61,9 +61,15 @@ struct GemmArgs {
     int64_t a_s1, a_s2, w_s1, w_s2, y_s1, y_s2, r_s1, r_s2, bias_s2;
     float alpha;
     int tiles_n;  // filled by launch_gemm
+    // mode 4 (row arg-max instead of a store): per row and per 32*NSUB-column wave slice the best
+    // (value, column) goes to part_val / part_idx [M, part_ld]; Y is not written.
+    float* part_val;
+    int32_t* part_idx;
+    int part_ld;
 };
-// mode 0: acc+b | 1: relu(acc+b) | 2: res + alpha*(acc+b) | 3: alpha*(acc+b)
+// mode 0: acc+b | 1: relu(acc+b) | 2: res + alpha*(acc+b) | 3: alpha*(acc+b) | 4: row arg-max partials of acc+b
 int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s);
+int gemm_mode4_partials(int64_t M, int N);
 
 // internal launchers shared between translation units
 int launch_linear(const float* x, const float* w, const float* b, const float* res, float alpha, int mode,

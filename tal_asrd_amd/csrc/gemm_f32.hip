@@ -45,6 +45,48 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
     const float alpha = g.alpha;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     constexpr int CW = 32 * NSUB;  // columns owned by one wave
+    if (MODE == 4) {
+        // Fused arg-max over this wave's CW columns (the [M, 6008] speaker logits are never written,
+        // tal/baseline/reconcile.py:84).  For a fixed accumulator element e the 32 lanes of a half
+        // wave hold 32 columns of one row; columns are visited in ascending order and a strict '>'
+        // keeps the lowest index on ties, as torch.argmax does.
+        float bcol[NSUB];
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+            const int col = n0 + (wn * NSUB + j) * 32 + colb;
+            bcol[j] = (bias && col < N) ? bias[col] : 0.f;
+        }
+        const int pcol = (n0 / CW) + wn;   // n0 is a multiple of BN = CW * WAVES_N
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) {
+                const int col = n0 + (wn * NSUB + j) * 32 + colb;
+                const float v = acc[j][e] + bcol[j];
+                if (col < N && v > best) {
+                    best = v;
+                    bi = col;
+                }
+            }
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(best, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (ov > best || (ov == best && oi < bi)) {
+                    best = ov;
+                    bi = oi;
+                }
+            }
+            const int64_t row = m0 + wm * 32 + rowb + (e & 3) + 8 * (e >> 2);
+            if (colb == 0 && row < M) {
+                g.part_val[row * g.part_ld + pcol] = best;
+                g.part_idx[row * g.part_ld + pcol] = bi;
+            }
+        }
+        return;
+    }
     const bool vec_ok = (g.ldy % 4 == 0) && (MODE != 2 || g.ldres % 4 == 0) &&
                         ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) &&
                         (MODE != 2 || (reinterpret_cast<uintptr_t>(res) & 15) == 0);
@@ -371,7 +413,8 @@ static void launch_tile(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
         case 0: hipLaunchKernelGGL((gemm_nt_f32_kernel<0, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
         case 1: hipLaunchKernelGGL((gemm_nt_f32_kernel<1, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
         case 2: hipLaunchKernelGGL((gemm_nt_f32_kernel<2, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
-        default: hipLaunchKernelGGL((gemm_nt_f32_kernel<3, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
+        case 3: hipLaunchKernelGGL((gemm_nt_f32_kernel<3, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_nt_f32_kernel<4, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
     }
 }
 
@@ -380,15 +423,17 @@ static void launch_glds(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
         case 0: hipLaunchKernelGGL(gemm_glds_kernel<0>, grid, dim3(256), 0, s, g); break;
         case 1: hipLaunchKernelGGL(gemm_glds_kernel<1>, grid, dim3(256), 0, s, g); break;
         case 2: hipLaunchKernelGGL(gemm_glds_kernel<2>, grid, dim3(256), 0, s, g); break;
-        default: hipLaunchKernelGGL(gemm_glds_kernel<3>, grid, dim3(256), 0, s, g); break;
+        case 3: hipLaunchKernelGGL(gemm_glds_kernel<3>, grid, dim3(256), 0, s, g); break;
+        default: hipLaunchKernelGGL(gemm_glds_kernel<4>, grid, dim3(256), 0, s, g); break;
     }
 }
 
 int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
-    TAL_CHECK_ARG(g.A && g.W && g.Y, "gemm: null pointer");
+    TAL_CHECK_ARG(g.A && g.W && (g.Y || mode == 4), "gemm: null pointer");
+    TAL_CHECK_ARG(mode != 4 || (g.part_val && g.part_idx && g.part_ld >= (int)cdiv(g.N, 32)), "gemm: mode 4 needs partial buffers");
     TAL_CHECK_ARG(g.M >= 0 && g.N > 0 && g.K > 0, "gemm: bad shape M=%lld N=%d K=%d", (long long)g.M, g.N, g.K);
     TAL_CHECK_ARG(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0, "gemm: K=%d lda=%lld ldw=%lld must be multiples of 4", g.K, (long long)g.lda, (long long)g.ldw);
-    TAL_CHECK_ARG(mode >= 0 && mode <= 3, "gemm: mode %d", mode);
+    TAL_CHECK_ARG(mode >= 0 && mode <= 4, "gemm: mode %d", mode);
     TAL_CHECK_ARG(mode != 2 || g.res, "gemm: mode 2 needs a residual");
     TAL_CHECK_ARG(nbatch >= 1 && nbatch <= 65535 && g.nb2 >= 1, "gemm: batch %d", nbatch);
     if (g.M == 0) return TAL_OK;
@@ -409,6 +454,9 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
     TAL_CHECK_LAUNCH("gemm");
     return TAL_OK;
 }
+
+// number of (value, index) partials per row a mode-4 launch of this shape produces
+int gemm_mode4_partials(int64_t M, int N) { return M <= 512 ? (int)cdiv(N, 128) * 4 : (int)cdiv(N, 160); }
 
 int launch_linear(const float* x, const float* w, const float* b, const float* res, float alpha, int mode, int64_t M,
                   int N, int K, float* y, hipStream_t s) {

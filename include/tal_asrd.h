@@ -213,6 +213,20 @@ int tal_beam_topk(const float* logprobs, const float* row_score, const uint8_t* 
                   int cur_beam, int V, int k, float* out_val, int64_t* out_idx, void* stream);
 
 /* ------------------------------------------------------------------ *
+ * Attention-weighted pooling of diarization features per generated token,
+ * tal/utils/aligned_to_wder_format.py:150-178,203-214 (consumes the `attention` and
+ * `chunkStart` alignments of generate_unaligned together with SDModel features / ids).
+ *   attn [N, S], chunk_start int64 [N], feat [T, E], ids int32 [T]
+ *   pool: out[n] = sum_s attn[n,s] * feat[chunk_start[n] + s]   (s truncated at T, as aw[:len(chunk)])
+ *   vote: out_id[n] = speaker id with the largest summed attention inside the window
+ *         (out_weight [N] = that sum, may be NULL)
+ * ------------------------------------------------------------------ */
+int tal_attn_pool_fwd(const float* attn, const int64_t* chunk_start, const float* feat, int64_t T,
+                      int E, int N, int S, float* out, void* stream);
+int tal_attn_vote_fwd(const float* attn, const int64_t* chunk_start, const int32_t* ids, int64_t T,
+                      int N, int S, int32_t* out_id, float* out_weight, void* stream);
+
+/* ------------------------------------------------------------------ *
  * GRU cell of UIS-RNN's CoreRNN, tal/diarization/uisrnn/uisrnn.py:20-39 (torch.nn.GRU,
  * gate order r, z, n).  x [B, In], h [B, H] -> h_out [B, H] (h_out != h).
  * w_ih [3H, In], w_hh [3H, H], b_ih / b_hh [3H].  The mean head (linear_mean1 -> ReLU ->

@@ -15,6 +15,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_library():
+    """Build (or refresh) tal_asrd_amd/libtal_asrd_hip.so before any test touches it."""
+    import __graft_entry__ as g
+    g.build()
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

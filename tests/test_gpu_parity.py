@@ -240,3 +240,27 @@ def test_batch_items_independent(sd_model):
     full = sd_model.encoder.forward_time_major(mel)
     one = sd_model.encoder.forward_time_major(mel[1:2].contiguous())
     np.testing.assert_array_equal(full[1].cpu().numpy(), one[0].cpu().numpy())
+
+
+# ------------------------------------------------------------------ full-size (1 hour) properties
+def test_one_hour_prefix_consistency_and_determinism(sd_model):
+    """BASELINE.json's full size (360,001 mel frames): encoder frames whose receptive field
+    (mel frames [8c-640, 8c+780]) lies inside a 5-minute prefix must equal the 5-minute run, and
+    two runs of the 1-hour call are bit-identical (no atomics / order-dependent reductions)."""
+    g = torch.Generator().manual_seed(8)
+    mel = torch.randn(1, 360001, 80, generator=g).to(dev())
+    a = sd_model.encoder.forward_time_major(mel)
+    assert a.shape[1] == 44983
+    b = sd_model.encoder.forward_time_major(mel)
+    assert torch.equal(a, b)
+    p = sd_model.encoder.forward_time_major(mel[:, :30001].contiguous())
+    np.testing.assert_allclose(a[0, :3600].cpu().numpy(), p[0, :3600].cpu().numpy(), atol=1e-5, rtol=0)
+    feat, ids = None, None
+    from tal_asrd_amd import ops
+    f1, l1, i1 = ops.sd_head(a[:, :4096].contiguous(), sd_model.spk_embed_proj.weight, sd_model.spk_embed_proj.bias,
+                             sd_model.spk_logit_proj.weight, sd_model.spk_logit_proj.bias, True, True)
+    f2, _, i2 = ops.sd_head(a, sd_model.spk_embed_proj.weight, sd_model.spk_embed_proj.bias,
+                            sd_model.spk_logit_proj.weight, sd_model.spk_logit_proj.bias, False, True)
+    # fused arg-max (no logits) == arg-max of materialised logits, at full size
+    np.testing.assert_array_equal(i1[0].cpu().numpy(), i2[0, :4096].cpu().numpy())
+    np.testing.assert_array_equal(l1.argmax(-1).cpu().numpy(), i1.cpu().numpy())

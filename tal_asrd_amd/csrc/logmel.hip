@@ -30,13 +30,16 @@ constexpr int NBIN = 201;
 constexpr int NMEL = 80;
 constexpr int FB = 32;                         // frames per workgroup
 constexpr int NTILE = 13;                      // 13 x 16 = 208 >= 201 bins
-constexpr int NS = (FB - 1) * HOP + NFFT;      // 5360 samples per workgroup
+constexpr int NS = (FB - 1) * HOP + NFFT + 1;  // 5361 samples per workgroup (+1: the folded DFT touches x[400])
 constexpr int NSP = NS + NS / HOP + 2;         // + one pad word per hop
+constexpr int NFOLD = 204;                     // folded DFT length: n = 0..200, padded to a multiple of 4
 constexpr int PLD = NTILE * 16 + 1;            // power tile pitch (209)
 constexpr int MAXW = 48;                       // max mel filter support in bins
 
 struct LogmelPlan {
-    double basis[NTILE * NFFT * 2 * 16];  // [tile][n][re|im][16 bins], Hann folded in
+    double basis[NTILE * NFFT * 2 * 16];   // [tile][n][re|im][16 bins], Hann folded in
+    double fbasis[NTILE * NFOLD * 2 * 16]; // symmetric-window form: re rows act on x[n]+x[400-n], im rows on x[n]-x[400-n]
+    int folded;                            // 1 if the window is symmetric (w[n] == w[400-n], w[0] == 0): use fbasis
     int mel_lo[NMEL];
     int mel_cnt[NMEL];
     float mel_w[NMEL * MAXW];
@@ -71,23 +74,47 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelPlan* __restric
     const int kq = lane >> 4;  // which of the 4 k's of a 16x16x4 step
     for (int j = w; j < NTILE; j += 4) {
         f64x4 re0 = {0., 0., 0., 0.}, im0 = re0, re1 = re0, im1 = re0;
-        const double* bp = plan->basis + ((int64_t)j * NFFT + kq) * 32 + fi;
-        const float* sp0 = samp + fi * (HOP + 1) + kq;
-        const float* sp1 = sp0 + 16 * (HOP + 1);
+        if (plan->folded) {
+            // Symmetric window: cos(2 pi k (400-n)/400) = cos(2 pi k n/400), sin flips sign, so
+            //   Re X[k] =  sum_{n=0}^{200} c_n w[n] cos(.) (x[n] + x[400-n])
+            //   Im X[k] = -sum_{n=1}^{199}     w[n] sin(.) (x[n] - x[400-n])
+            // (c_200 = 1/2; the n = 0 row is w[0] = 0): half the fp64 MFMAs of the direct form.
+            const double* fq = plan->fbasis + ((int64_t)j * NFOLD + kq) * 32 + fi;
+            const float* s0 = samp + fi * (HOP + 1);
+            const float* s1 = s0 + 16 * (HOP + 1);
+#pragma unroll 3
+            for (int k = 0; k < NFOLD; k += 4) {
+                const int n = k + kq, m = NFFT - n;
+                const int on = n + (n >= HOP ? 1 : 0);            // + pad words crossed (n <= 203)
+                const int om = m + (m >= 2 * HOP ? 2 : 1);        // 197 <= m <= 400
+                const double x0n = (double)s0[on], x0m = (double)s0[om];
+                const double x1n = (double)s1[on], x1m = (double)s1[om];
+                const double br = fq[k * 32];
+                const double bi = fq[k * 32 + 16];
+                re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0n + x0m, br, re0, 0, 0, 0);
+                im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0n - x0m, bi, im0, 0, 0, 0);
+                re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1n + x1m, br, re1, 0, 0, 0);
+                im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1n - x1m, bi, im1, 0, 0, 0);
+            }
+        } else {
+            const double* bp = plan->basis + ((int64_t)j * NFFT + kq) * 32 + fi;
+            const float* sp0 = samp + fi * (HOP + 1) + kq;
+            const float* sp1 = sp0 + 16 * (HOP + 1);
 #pragma unroll 1
-        for (int k0 = 0; k0 < NFFT; k0 += 40) {       // 40 | HOP: a chunk never straddles a pad word
-            const int base = k0 + k0 / HOP;           // (k + kq) / HOP == k0 / HOP inside the chunk
-            const double* bq = bp + k0 * 32;
+            for (int k0 = 0; k0 < NFFT; k0 += 40) {       // 40 | HOP: a chunk never straddles a pad word
+                const int base = k0 + k0 / HOP;           // (k + kq) / HOP == k0 / HOP inside the chunk
+                const double* bq = bp + k0 * 32;
 #pragma unroll
-            for (int kk = 0; kk < 40; kk += 4) {
-                const double a0 = (double)sp0[base + kk];
-                const double a1 = (double)sp1[base + kk];
-                const double br = bq[kk * 32];
-                const double bi = bq[kk * 32 + 16];
-                re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, br, re0, 0, 0, 0);
-                im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bi, im0, 0, 0, 0);
-                re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, br, re1, 0, 0, 0);
-                im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bi, im1, 0, 0, 0);
+                for (int kk = 0; kk < 40; kk += 4) {
+                    const double a0 = (double)sp0[base + kk];
+                    const double a1 = (double)sp1[base + kk];
+                    const double br = bq[kk * 32];
+                    const double bi = bq[kk * 32 + 16];
+                    re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, br, re0, 0, 0, 0);
+                    im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bi, im0, 0, 0, 0);
+                    re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, br, re1, 0, 0, 0);
+                    im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bi, im1, 0, 0, 0);
+                }
             }
         }
         // f64 16x16 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -204,6 +231,33 @@ extern "C" int tal_logmel_plan_init(const float* window, const float* fb, void* 
                 }
                 hp->basis[((j * NFFT + n) * 2 + 0) * 16 + c] = re;
                 hp->basis[((j * NFFT + n) * 2 + 1) * 16 + c] = im;
+            }
+    // Folded form for a symmetric window.  torch.hann_window evaluates w[n] and w[400-n] separately
+    // in float32, so they may differ in the last bit; their mean is used and the asymmetric part
+    // (|w[n] - w[400-n]| / 2 <= 4e-7 max|w| required, i.e. below fp32 epsilon of the product) is
+    // dropped.  Any other window (or w[0] != 0) keeps the direct 400-term form.
+    double wmax = 0.0, asym = 0.0;
+    for (int n = 0; n < NFFT; ++n) wmax = fabs((double)hwin[n]) > wmax ? fabs((double)hwin[n]) : wmax;
+    for (int n = 1; n < NFFT / 2; ++n) {
+        const double d = fabs((double)hwin[n] - (double)hwin[NFFT - n]) * 0.5;
+        asym = d > asym ? d : asym;
+    }
+    hp->folded = (hwin[0] == 0.f && asym <= 4e-7 * wmax && !getenv("TAL_LOGMEL_NO_FOLD")) ? 1 : 0;
+    for (int j = 0; j < NTILE; ++j)
+        for (int n = 0; n < NFOLD; ++n)
+            for (int c = 0; c < 16; ++c) {
+                const int bin = j * 16 + c;
+                double re = 0.0, im = 0.0;
+                if (bin < NBIN && n >= 1 && n <= NFFT / 2) {
+                    const int ph = (int)(((int64_t)bin * n) % NFFT);
+                    const double ang = two_pi * (double)ph / (double)NFFT;
+                    const double ws = n == NFFT / 2 ? 0.5 * (double)hwin[n]
+                                                    : 0.5 * ((double)hwin[n] + (double)hwin[NFFT - n]);
+                    re = ws * cos(ang);
+                    im = n == NFFT / 2 ? 0.0 : -ws * sin(ang);
+                }
+                hp->fbasis[((j * NFOLD + n) * 2 + 0) * 16 + c] = re;
+                hp->fbasis[((j * NFOLD + n) * 2 + 1) * 16 + c] = im;
             }
     for (int m = 0; m < NMEL; ++m) {
         int lo = -1, hi = -1;

@@ -193,6 +193,15 @@ int tal_decoder_layer_fwd(const tal_decoder_layer_w* w, const float* tgt, int B,
                           const uint8_t* mem_kpm, const float* k_cache, const float* vt_cache,
                           float* out, float* xattn_avg, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* n_layers consecutive tal_decoder_layer_fwd calls (nn.TransformerDecoder.forward, norm=None) in
+ * one entry point: `layers` is an array of n_layers structs; k_cache / vt_cache are arrays of
+ * n_layers device pointers (or NULL: project the memory in every layer); xattn_avg
+ * [n_layers, B, U, S] or NULL; workspace as for one layer. */
+int tal_decoder_stack_fwd(const tal_decoder_layer_w* layers, int n_layers, const float* tgt, int B,
+                          int U, const float* mem, int S, int E, int H, int FF, const float* tgt_mask,
+                          const uint8_t* mem_kpm, const float* const* k_cache,
+                          const float* const* vt_cache, float* out, float* xattn_avg, void* workspace,
+                          size_t workspace_bytes, void* stream);
 /* Tied factorised LM head (models.py:243-246): logits = (h . P) . Emb^T with
  * proj_t = embedding_proj.weight^T stored [E0, D] (tal_transpose_fwd builds it once).
  * h rows are taken at stride ldh (ldh = U*D with h pointing at the last position gives

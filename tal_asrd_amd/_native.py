@@ -63,6 +63,7 @@ SIGNATURES = {
     "tal_decoder_layer_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "tal_decoder_layer_fwd": (_i, [C.POINTER(DecoderLayerW), _p, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p,
                                    _p, _sz, _p]),
+    "tal_decoder_stack_fwd": (_i, [_p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "tal_lm_head_fwd": (_i, [_p, _i64, _i64, _i, _p, _i, _p, _i, _p, _p, _sz, _p]),
     "tal_transpose_fwd": (_i, [_p, _i, _i, _p, _p]),
     "tal_log_softmax_rows": (_i, [_p, _i64, _i, _p, _p]),

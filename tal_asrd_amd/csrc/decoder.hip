@@ -309,6 +309,27 @@ extern "C" int tal_decoder_layer_fwd(const tal_decoder_layer_w* w, const float* 
     return launch_linear(ws.ff, w->lin2_w, w->lin2_b, ws.x2, w->resweight, 2, (int64_t)B * U, E, FF, out, s);
 }
 
+// Whole decoder stack in one call (nn.TransformerDecoder.forward of torch 1.4 = a loop over the
+// layers, norm=None): saves the per-layer host round trips of the decode loops, which launch a
+// few hundred microseconds of GPU work per generated token.
+extern "C" int tal_decoder_stack_fwd(const tal_decoder_layer_w* layers, int n_layers, const float* tgt, int B, int U,
+                                     const float* mem, int S, int E, int H, int FF, const float* tgt_mask,
+                                     const uint8_t* mem_kpm, const float* const* k_cache,
+                                     const float* const* vt_cache, float* out, float* xattn_avg, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    TAL_CHECK_ARG(layers && n_layers >= 1 && tgt && out, "tal_decoder_stack_fwd: bad argument");
+    const float* cur = tgt;
+    for (int l = 0; l < n_layers; ++l) {
+        float* avg = xattn_avg ? xattn_avg + (size_t)l * B * U * S : nullptr;
+        const int rc = tal_decoder_layer_fwd(&layers[l], cur, B, U, mem, S, E, H, FF, tgt_mask, mem_kpm,
+                                             k_cache ? k_cache[l] : nullptr, vt_cache ? vt_cache[l] : nullptr, out,
+                                             avg, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        cur = out;  // layers l >= 1 run in place (tal_decoder_layer_fwd allows out == tgt)
+    }
+    return TAL_OK;
+}
+
 extern "C" int tal_lm_head_fwd(const float* h, int64_t M, int64_t ldh, int D, const float* proj_t, int E0,
                                const float* emb, int V, float* logits, void* workspace, size_t workspace_bytes,
                                void* stream) {

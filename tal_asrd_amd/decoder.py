@@ -120,7 +120,7 @@ def decoder_layer_forward(layer, tgt, memory, tgt_mask=None, memory_mask=None, t
     return out.permute(1, 0, 2).contiguous()
 
 
-def _embed(model, y_prev):
+def _embed(model, y_prev, check_tokens=True):
     """embedding -> embedding_proj -> + pe (models.py:218-223) in one kernel."""
     lib = N.lib()
     N.require_cuda(y_prev, "ASRModel.decode(y_prev)")
@@ -131,7 +131,9 @@ def _embed(model, y_prev):
     proj = model.embedding_proj.weight if model.embed_size else None
     D = proj.shape[0] if proj is not None else E0
     pe = model.pos_dec_encoder.pe
-    if int(y.min()) < 0 or int(y.max()) >= V:
+    # nn.Embedding raises on out-of-range ids; the kernel clamps (never reads out of bounds) and the
+    # range is checked here unless the caller already knows it (decode loops: ids come from an arg-max)
+    if check_tokens and (int(y.min()) < 0 or int(y.max()) >= V):
         raise IndexError("token id out of range [0, %d)" % V)
     out = torch.empty(B, U, D, dtype=torch.float32, device=y.device)
     N.check(lib.tal_embed_tokens_fwd(N.ptr(y), B, U, N.ptr(emb), V, E0, N.ptr(proj), D, N.ptr(pe), pe.shape[0],
@@ -145,16 +147,62 @@ def causal_mask(n, device):
     return m.masked_fill(m == 1, float("-inf")).to(device)
 
 
-def _run_stack(model, stack, y_prev, memory, mask, causal):
-    h = _embed(model, y_prev)
+def _stack_structs(stack):
+    """Contiguous array of tal_decoder_layer_w for a whole stack (cached; rebuilt when any parameter changes)."""
+    key = tuple((p.data_ptr(), p._version) for p in stack.parameters())
+    cached = getattr(stack, "_tal_stack", None)
+    if cached is None or cached[0] != key:
+        arr = (N.DecoderLayerW * len(stack.layers))()
+        for i, layer in enumerate(stack.layers):
+            arr[i] = layer_weights(layer)
+        cached = (key, arr)
+        stack._tal_stack = cached
+    return cached[1]
+
+
+def _stack_kv(stack, memory):
+    """Per-layer cached cross-attention K / V^T pointer arrays for `memory`."""
+    key = (memory.data_ptr(), memory._version, tuple(memory.shape))
+    cached = getattr(stack, "_tal_stack_kv", None)
+    if cached is None or cached[0] != key:
+        ks, vts = [], []
+        for layer in stack.layers:
+            k, vt = cross_kv(layer, memory)
+            ks.append(k)
+            vts.append(vt)
+        n = len(ks)
+        karr = (C.c_void_p * n)(*[k.data_ptr() for k in ks])
+        varr = (C.c_void_p * n)(*[v.data_ptr() for v in vts])
+        cached = (key, karr, varr, ks, vts, memory)
+        stack._tal_stack_kv = cached
+    return cached[1], cached[2]
+
+
+def _run_stack(model, stack, y_prev, memory, mask, causal, check_tokens=True):
+    """embedding -> all decoder layers (one C call) -> hidden [B,U,E]; sets layer.src_attn_weights."""
+    lib = N.lib()
+    h = _embed(model, y_prev, check_tokens)
     memory = ops._f32c(memory, "decode(memory)")
-    B, S = memory.shape[0], memory.shape[1]
+    B, U, E = h.shape
+    S = memory.shape[1]
     kpm = _kpm_u8(mask, B, S, h.device)
-    tm = causal_mask(h.shape[1], h.device) if causal else None
-    for layer in stack.layers:
-        h, avg = run_layer(layer, h, memory, tm, kpm, want_weights=True, cache_kv=True)
-        layer.src_attn_weights = avg
-    return h
+    tm = causal_mask(U, h.device) if causal else None
+    layers = stack.layers
+    n = len(layers)
+    H, FF = layers[0].nhead, layers[0].linear1.out_features
+    arr = _stack_structs(stack)
+    karr, varr = _stack_kv(stack, memory)
+    out = torch.empty_like(h)
+    avg = torch.empty(n, B, U, S, dtype=torch.float32, device=h.device)
+    nws = lib.tal_decoder_layer_workspace_bytes(B, U, S, E, H, FF)
+    ws = ops._ws(nws, h.device)
+    N.check(lib.tal_decoder_stack_fwd(arr, n, N.ptr(h), B, U, N.ptr(memory), S, E, H, FF, N.ptr(tm), N.ptr(kpm),
+                                      karr, varr, N.ptr(out), N.ptr(avg), N.ptr(ws), nws, N.stream_handle()),
+            "tal_decoder_stack_fwd")
+    for i, layer in enumerate(layers):
+        layer.src_attn_weights = avg[i]
+    stack.src_attn_weights_all = avg   # [n_layers, B, U, S], one tensor for the decode loops
+    return out
 
 
 def _proj_t(model):
@@ -193,11 +241,11 @@ def lm_head(model, h, last_only=False):
 
 
 @torch.no_grad()
-def asr_decode(model, y_prev, encoder_out, causal=True, last_only=False):
+def asr_decode(model, y_prev, encoder_out, causal=True, last_only=False, check_tokens=True):
     """ASRModel.decode (models.py:203-247).  last_only=True computes the LM head for the
     final position only (all the reference's decode loops read, system.py:124,355-361)."""
     h = _run_stack(model, model.decoder, y_prev, encoder_out["encoder_out"], encoder_out["encoder_padding_mask"],
-                   causal)
+                   causal, check_tokens)
     return lm_head(model, h, last_only)
 
 

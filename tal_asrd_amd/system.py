@@ -165,14 +165,14 @@ class System:
                 window = {"encoder_out": enc[:, sl].contiguous(), "encoder_padding_mask": mask[:, sl].contiguous()}
                 window_key = chunk_start
             y = torch.tensor([history], dtype=torch.int64, device=dev)
-            logits = asr_decode(model, y, window, causal=False, last_only=True)      # [1, V]
+            logits = asr_decode(model, y, window, causal=False, last_only=True, check_tokens=(it == 0))  # [1, V]
             if it == 0 and bool(torch.isnan(logits).any()):
                 raise Exception("Logits contain nans!")
             logprobs = log_softmax(logits)
             token = int(ops.argmax_rows(logprobs).cpu().item())
             gen.append(token)
             # attention of the new token, averaged over layers (heads are already averaged by the kernel)
-            rows = torch.stack([l.src_attn_weights[0, -1] for l in layers], dim=0).cpu().numpy()
+            rows = model.decoder.src_attn_weights_all[:, 0, -1].cpu().numpy()          # [n_layers, S]
             attn = rows.astype(np.float32).sum(axis=0, dtype=np.float32) / np.float32(len(layers))
             record = [chunk_start, torch.from_numpy(attn.copy()).unsqueeze(0)]
             alignments.append(record)

@@ -208,9 +208,15 @@ def main():
                 kern[name] = {"ms_total": ms.value, "launches": n.value, "work": work.value}
             gm = kern["gemm_nt_f32"]
             achieved = gm["work"] / (gm["ms_total"] * 1e-3) / 1e12 if gm["ms_total"] > 0 else 0.0
-            line["roofline"] = {"bound": "mfma", "kernel": "tal::gemm_nt_f32_kernel (fp32 MFMA dense layer)",
+            traffic = None
+            try:   # HBM-side bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
+                with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+                    traffic = json.load(f)["hbm_bytes_per_launch"]
+            except Exception:
+                pass
+            line["roofline"] = {"bound": "mfma", "kernel": "tal::gemm_glds_kernel (fp32 MFMA dense layer, all epilogues)",
                                 "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
                                 "avg_launch_ms": gm["ms_total"] / max(gm["launches"], 1),
                                 "launches": gm["launches"],
                                 "algorithmic_flops_per_launch": gm["work"] / max(gm["launches"], 1)}

@@ -86,11 +86,54 @@ __global__ __launch_bounds__(256) void argmax_partials_kernel(const float* __res
     ids[row] = bi;
 }
 
+// one workgroup per row (few long rows: the arg-max of a decode step's [1, V] logits)
+__global__ __launch_bounds__(256) void argmax_row_block_kernel(const float* __restrict__ x, int N,
+                                                              int32_t* __restrict__ ids) {
+    __shared__ float bv[4];
+    __shared__ int bix[4];
+    const float* xr = x + (int64_t)blockIdx.x * N;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float v = xr[i];
+        if (v > best || (v == best && i < bi)) {
+            best = v;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        bv[w] = best;
+        bix[w] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 4; ++q)
+            if (bv[q] > best || (bv[q] == best && bix[q] < bi)) {
+                best = bv[q];
+                bi = bix[q];
+            }
+        ids[blockIdx.x] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+
 int launch_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, hipStream_t s) {
     TAL_CHECK_ARG(x && ids && N > 0 && M >= 0, "tal_argmax_rows: bad argument");
     if (M == 0) return TAL_OK;
     ProfScope prof(PROF_OTHER, (double)M * N * 4.0, s);
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, x, M, N, ids);
+    if (M <= 512 && N >= 2048)
+        hipLaunchKernelGGL(argmax_row_block_kernel, dim3((unsigned)M), dim3(256), 0, s, x, N, ids);
+    else
+        hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, x, M, N, ids);
     TAL_CHECK_LAUNCH("tal_argmax_rows");
     return TAL_OK;
 }

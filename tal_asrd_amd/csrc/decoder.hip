@@ -98,6 +98,91 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ s
     }
 }
 
+// Latency-oriented variant for the decode loops (S <= 512, H <= 8): one workgroup per (b, u), wave h
+// owns head h and keeps its row in registers (one global read, one write); the head average goes
+// through LDS and is summed in head order, exactly like the kernel above.
+constexpr int SM_NR = 8;
+__global__ __launch_bounds__(512) void attn_softmax_small_kernel(float* __restrict__ scores,
+                                                                const float* __restrict__ mask,
+                                                                const uint8_t* __restrict__ kpm,
+                                                                float* __restrict__ avg, int H, int U, int S, int S4) {
+    extern __shared__ float ph[];  // [H][S]
+    const int lane = threadIdx.x & 63;
+    const int h = threadIdx.x >> 6;
+    const int64_t row = blockIdx.x;
+    const int b = (int)(row / U), u = (int)(row % U);
+    float* p = scores + (((int64_t)b * H + h) * U + u) * S4;
+    float v[SM_NR];
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < SM_NR; ++r) {
+        const int s = lane + 64 * r;
+        float x = -INFINITY;
+        if (s < S) {
+            x = p[s];
+            if (mask) x += mask[(int64_t)u * S + s];
+            if (kpm && kpm[(int64_t)b * S + s]) x = -INFINITY;
+        }
+        v[r] = x;
+        m = fmaxf(m, x);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < SM_NR; ++r) {
+        const int s = lane + 64 * r;
+        v[r] = s < S ? expf(v[r] - m) : 0.f;
+        sum += v[r];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+#pragma unroll
+    for (int r = 0; r < SM_NR; ++r) {
+        const int s = lane + 64 * r;
+        if (s < S) {
+            const float pr = v[r] / sum;
+            p[s] = pr;
+            if (avg) ph[h * S + s] = pr;
+        }
+    }
+    if (lane < S4 - S) p[S + lane] = 0.f;
+    if (avg) {
+        __syncthreads();
+        const float inv_h = 1.0f / (float)H;
+        for (int s = threadIdx.x; s < S; s += blockDim.x) {
+            float a = 0.f;
+            for (int q = 0; q < H; ++q) a += ph[q * S + s];
+            avg[row * S + s] = a * inv_h;
+        }
+    }
+}
+
+// one workgroup per row: the M = 1 rows of the greedy / beam loops would otherwise run on one wave
+__global__ __launch_bounds__(256) void log_softmax_row_block_kernel(const float* __restrict__ x, int N,
+                                                                   float* __restrict__ out) {
+    __shared__ float red[4];
+    const float* xr = x + (int64_t)blockIdx.x * N;
+    float* orow = out + (int64_t)blockIdx.x * N;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < N; i += 256) m = fmaxf(m, xr[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256) sum += expf(xr[i] - m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) red[w] = sum;
+    __syncthreads();
+    const float lse = logf((red[0] + red[1]) + (red[2] + red[3]));
+    for (int i = threadIdx.x; i < N; i += 256) orow[i] = (xr[i] - m) - lse;
+}
+
 __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, int64_t M, int N,
                                                               float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -179,8 +264,13 @@ static int mha_forward(const float* in_w, const float* in_b, const float* out_w,
     if (rc) return rc;
     {
         ProfScope prof(PROF_OTHER, (double)B * H * U * S * 8.0, s);
-        hipLaunchKernelGGL(attn_softmax_kernel, dim3((unsigned)cdiv((int64_t)B * U, 4)), dim3(256), 0, s, bf.scores,
-                           attn_mask, kpm, avg, B, H, U, S, (int)S4);
+        if (S <= 64 * SM_NR && H <= 8)
+            hipLaunchKernelGGL(attn_softmax_small_kernel, dim3((unsigned)(B * U)), dim3(64 * H),
+                               avg ? (size_t)H * S * sizeof(float) : 0, s, bf.scores, attn_mask, kpm, avg, H, U, S,
+                               (int)S4);
+        else
+            hipLaunchKernelGGL(attn_softmax_kernel, dim3((unsigned)cdiv((int64_t)B * U, 4)), dim3(256), 0, s, bf.scores,
+                               attn_mask, kpm, avg, B, H, U, S, (int)S4);
     }
     TAL_CHECK_LAUNCH("attn_softmax");
     GemmArgs p = {};
@@ -366,8 +456,11 @@ extern "C" int tal_transpose_fwd(const float* x, int R, int Cc, float* y, void* 
 extern "C" int tal_log_softmax_rows(const float* x, int64_t M, int N, float* out, void* stream) {
     TAL_CHECK_ARG(x && out && M >= 0 && N > 0, "tal_log_softmax_rows: bad argument");
     if (M == 0) return TAL_OK;
-    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, M, N,
-                       out);
+    if (M <= 512)
+        hipLaunchKernelGGL(log_softmax_row_block_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, x, N, out);
+    else
+        hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, M,
+                           N, out);
     TAL_CHECK_LAUNCH("tal_log_softmax_rows");
     return TAL_OK;
 }

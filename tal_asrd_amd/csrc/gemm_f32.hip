@@ -28,7 +28,6 @@
 namespace tal {
 
 constexpr int BK = 32;
-constexpr int LDS_LD = 36;  // padded pitch of the register-staged kernels
 
 // ---------------------------------------------------------------------------------------------
 // shared epilogue
@@ -295,13 +294,16 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
 // ---------------------------------------------------------------------------------------------
 // register-staged kernels (K tails, and the small tile)
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int WAVES_M, int NSUB>
+template <int MODE, int WAVES_M, int NSUB, int BKT>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs g) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int BM = 32 * WAVES_M;
     constexpr int BN = 32 * NSUB * WAVES_N;
-    constexpr int A_LOADS = BM / 32;
-    constexpr int B_LOADS = BN / 32;
+    constexpr int LDS_LD = BKT + 4;            // padded pitch: conflict-free ds_read_b128 of 16 rows x 4 floats
+    constexpr int C4 = BKT / 4;                // 16-byte columns per K slab
+    constexpr int RPP = 256 / C4;              // rows covered by one pass of the 256 threads
+    constexpr int A_LOADS = BM / RPP;
+    constexpr int B_LOADS = BN / RPP;
     __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_LD];
     float* As = lds;
     float* Bs = lds + BM * LDS_LD;
@@ -324,8 +326,8 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs g) {
     const int lane = tid & 63;
     const int w = wave_id();
     const int wm = w / WAVES_N, wn = w % WAVES_N;
-    const int lrow = tid >> 3;  // 0..31
-    const int lc4 = tid & 7;    // 16-byte column inside the 32-wide K slab
+    const int lrow = tid / C4;  // row inside a pass
+    const int lc4 = tid % C4;   // 16-byte column inside the K slab
 
     // tile-relative offsets (rows past the end are clamped; their results are never stored)
     const float* At = A + m0 * g.lda + lc4 * 4;
@@ -334,9 +336,9 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs g) {
     const int b_rows = ((N - n0) < BN ? (N - n0) : BN) - 1;
     int64_t a_off[A_LOADS], b_off[B_LOADS];
 #pragma unroll
-    for (int p = 0; p < A_LOADS; ++p) a_off[p] = min(lrow + 32 * p, a_rows) * g.lda;
+    for (int p = 0; p < A_LOADS; ++p) a_off[p] = min(lrow + RPP * p, a_rows) * g.lda;
 #pragma unroll
-    for (int p = 0; p < B_LOADS; ++p) b_off[p] = min(lrow + 32 * p, b_rows) * g.ldw;
+    for (int p = 0; p < B_LOADS; ++p) b_off[p] = min(lrow + RPP * p, b_rows) * g.ldw;
 
     f32x16 acc[NSUB];
 #pragma unroll
@@ -360,18 +362,18 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs g) {
     }
 
     const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
-    const int nk = (K + BK - 1) / BK;
+    const int nk = (K + BKT - 1) / BKT;
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
         for (int p = 0; p < A_LOADS; ++p)
-            *reinterpret_cast<f32x4*>(&As[(lrow + 32 * p) * LDS_LD + lc4 * 4]) = in_cur ? ra[p] : zero4;
+            *reinterpret_cast<f32x4*>(&As[(lrow + RPP * p) * LDS_LD + lc4 * 4]) = in_cur ? ra[p] : zero4;
 #pragma unroll
         for (int p = 0; p < B_LOADS; ++p)
-            *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * p) * LDS_LD + lc4 * 4]) = in_cur ? rb[p] : zero4;
+            *reinterpret_cast<f32x4*>(&Bs[(lrow + RPP * p) * LDS_LD + lc4 * 4]) = in_cur ? rb[p] : zero4;
         __syncthreads();
         if (kt + 1 < nk) {
-            in_cur = (kt + 1) * BK + lc4 * 4 < K;
-            const int ko = in_cur ? (kt + 1) * BK : -lc4 * 4;
+            in_cur = (kt + 1) * BKT + lc4 * 4 < K;
+            const int ko = in_cur ? (kt + 1) * BKT : -lc4 * 4;
 #pragma unroll
             for (int p = 0; p < A_LOADS; ++p) ra[p] = *reinterpret_cast<const f32x4*>(At + ko + a_off[p]);
 #pragma unroll
@@ -385,9 +387,9 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs g) {
         for (int j = 0; j < NSUB; ++j)
             fb[0][j] = *reinterpret_cast<const f32x4*>(&Bs[(wn * NSUB + j) * 32 * LDS_LD + frag_off]);
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
+        for (int kk = 0; kk < BKT / 8; ++kk) {
             const int cur = kk & 1, nxt = cur ^ 1;
-            if (kk + 1 < BK / 8) {
+            if (kk + 1 < BKT / 8) {
                 fa[nxt] = *reinterpret_cast<const f32x4*>(&As[wm * 32 * LDS_LD + frag_off + (kk + 1) * 8]);
 #pragma unroll
                 for (int j = 0; j < NSUB; ++j)
@@ -407,14 +409,14 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs g) {
     gemm_epilogue<MODE, NSUB>(g, acc, lds, Y, bias, res, m0, n0, lane, w, wm, wn);
 }
 
-template <int WAVES_M, int NSUB>
+template <int WAVES_M, int NSUB, int BKT>
 static void launch_tile(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
     switch (mode) {
-        case 0: hipLaunchKernelGGL((gemm_nt_f32_kernel<0, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
-        case 1: hipLaunchKernelGGL((gemm_nt_f32_kernel<1, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
-        case 2: hipLaunchKernelGGL((gemm_nt_f32_kernel<2, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
-        case 3: hipLaunchKernelGGL((gemm_nt_f32_kernel<3, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
-        default: hipLaunchKernelGGL((gemm_nt_f32_kernel<4, WAVES_M, NSUB>), grid, dim3(256), 0, s, g); break;
+        case 0: hipLaunchKernelGGL((gemm_nt_f32_kernel<0, WAVES_M, NSUB, BKT>), grid, dim3(256), 0, s, g); break;
+        case 1: hipLaunchKernelGGL((gemm_nt_f32_kernel<1, WAVES_M, NSUB, BKT>), grid, dim3(256), 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_nt_f32_kernel<2, WAVES_M, NSUB, BKT>), grid, dim3(256), 0, s, g); break;
+        case 3: hipLaunchKernelGGL((gemm_nt_f32_kernel<3, WAVES_M, NSUB, BKT>), grid, dim3(256), 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_nt_f32_kernel<4, WAVES_M, NSUB, BKT>), grid, dim3(256), 0, s, g); break;
     }
 }
 
@@ -445,12 +447,16 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
     dim3 grid((unsigned)nb, (unsigned)nbatch);
     ProfScope prof(PROF_GEMM, 2.0 * (double)g.M * (double)g.N * (double)g.K * nbatch, s);
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) == 0;
-    if (small)
-        launch_tile<1, 1>(g, mode, grid, s);
+    // small problems are latency-bound (a K step costs one L2 round trip, not its 16 MFMAs): a
+    // 128-deep K slab quarters the number of dependent round trips
+    if (small && g.K >= 256 && !getenv("TAL_GEMM_SMALL_BK32"))
+        launch_tile<1, 1, 128>(g, mode, grid, s);
+    else if (small)
+        launch_tile<1, 1, 32>(g, mode, grid, s);
     else if (g.K % BK == 0 && aligned16 && !getenv("TAL_GEMM_NO_GLDS"))
         launch_glds(g, mode, grid, s);
     else
-        launch_tile<4, 5>(g, mode, grid, s);
+        launch_tile<4, 5, 32>(g, mode, grid, s);
     TAL_CHECK_LAUNCH("gemm");
     return TAL_OK;
 }

@@ -420,6 +420,109 @@ static void launch_tile(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// latency kernel for the decoder's short problems (M <= 512): 32 x 32 output tile per workgroup,
+// the four waves split K between them (intra-workgroup split-K, reduced through LDS in a fixed
+// order -> deterministic), operands stream HBM/L2 -> registers with every load of a wave's K range
+// in flight at once.  A decode step is ~60 dependent launches of this size: what matters is the
+// length of the dependent chain inside a launch (here: one memory round trip + K/8 MFMAs), and
+// how many CUs share the weight stream ((M/32) x (N/32) workgroups instead of (M/32) x (N/128)).
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_splitk4_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float part[4 * 32 * 32];
+    const int tiles_n = g.tiles_n;
+    const int64_t m0 = (int64_t)(blockIdx.x / (unsigned)tiles_n) * 32;
+    const int n0 = (int)(blockIdx.x % (unsigned)tiles_n) * 32;
+    const int64_t M = g.M;
+    const int N = g.N, K = g.K;
+    const int z1 = (int)blockIdx.y / g.nb2, z2 = (int)blockIdx.y % g.nb2;
+    const float* A = g.A + z1 * g.a_s1 + z2 * g.a_s2;
+    const float* W = g.W + z1 * g.w_s1 + z2 * g.w_s2;
+    float* Y = g.Y + z1 * g.y_s1 + z2 * g.y_s2;
+    const float* bias = g.bias ? g.bias + z2 * g.bias_s2 : nullptr;
+    const float* res = g.res ? g.res + z1 * g.r_s1 + z2 * g.r_s2 : nullptr;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
+    const int r32 = lane & 31, kh = lane >> 5;
+    const int64_t arow = (m0 + r32 < M) ? m0 + r32 : M - 1;
+    const int wrow = (n0 + r32 < N) ? n0 + r32 : N - 1;
+    const float* ap = A + arow * g.lda + 4 * kh;
+    const float* wp = W + (int64_t)wrow * g.ldw + 4 * kh;
+
+    const int steps = (K + 7) / 8;                 // one step = 8 consecutive k (two 16-byte halves)
+    const int per = (steps + 3) / 4;
+    const int s0 = w * per;
+    const int s1 = (s0 + per < steps) ? s0 + per : steps;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int UN = 8;                          // loads in flight per operand
+    for (int sb = s0; sb < s1; sb += UN) {
+        f32x4 fa[UN], fb[UN];
+        // all loads of the batch first (clamped, always valid addresses; no select in between, so
+        // they are in flight together), then the zero-select for K tails and the MFMAs
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = (sb + u) * 8;
+            const bool in = (sb + u) < s1 && k + 4 * kh < K;
+            const int kc = in ? k : 0;
+            fa[u] = *reinterpret_cast<const f32x4*>(ap + kc);
+            fb[u] = *reinterpret_cast<const f32x4*>(wp + kc);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = (sb + u) * 8;
+            const bool in = (sb + u) < s1 && k + 4 * kh < K;
+            const f32x4 a = in ? fa[u] : zero4;
+            const f32x4 b = in ? fb[u] : zero4;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    }
+    // partial tiles -> LDS as [wave][row][col]; C/D layout: col = lane & 31, row = (e&3)+8*(e>>2)+4*(lane>>5)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[w * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * kh) * 32 + r32] = acc[e];
+    __syncthreads();
+    const int row = tid >> 3, c = (tid & 7) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&part[row * 32 + c]);
+#pragma unroll
+    for (int q = 1; q < 4; ++q) v += *reinterpret_cast<const f32x4*>(&part[q * 1024 + row * 32 + c]);  // waves 0,1,2,3 in order
+    const int64_t gr = m0 + row;
+    const int gc = n0 + c;
+    if (gr >= M || gc >= N) return;
+    const float alpha = g.alpha;
+    const bool vec = gc + 3 < N && (g.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) &&
+                     (MODE != 2 || (g.ldres % 4 == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0));
+    if (vec) {
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + gc);
+        if (MODE == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (MODE == 2) v = *reinterpret_cast<const f32x4*>(res + gr * g.ldres + gc) + alpha * v;
+        if (MODE == 3) v = alpha * v;
+        *reinterpret_cast<f32x4*>(Y + gr * g.ldy + gc) = v;
+    } else {
+        for (int q = 0; q < 4 && gc + q < N; ++q) {
+            float x = v[q] + (bias ? bias[gc + q] : 0.f);
+            if (MODE == 1) x = fmaxf(x, 0.f);
+            if (MODE == 2) x = res[gr * g.ldres + gc + q] + alpha * x;
+            if (MODE == 3) x = alpha * x;
+            Y[gr * g.ldy + gc + q] = x;
+        }
+    }
+}
+
+static void launch_splitk4(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(gemm_splitk4_kernel<0>, grid, dim3(256), 0, s, g); break;
+        case 1: hipLaunchKernelGGL(gemm_splitk4_kernel<1>, grid, dim3(256), 0, s, g); break;
+        case 2: hipLaunchKernelGGL(gemm_splitk4_kernel<2>, grid, dim3(256), 0, s, g); break;
+        default: hipLaunchKernelGGL(gemm_splitk4_kernel<3>, grid, dim3(256), 0, s, g); break;
+    }
+}
+
 static void launch_glds(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
     switch (mode) {
         case 0: hipLaunchKernelGGL(gemm_glds_kernel<0>, grid, dim3(256), 0, s, g); break;
@@ -449,7 +552,13 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) == 0;
     // small problems are latency-bound (a K step costs one L2 round trip, not its 16 MFMAs): a
     // 128-deep K slab quarters the number of dependent round trips
-    if (small && g.K >= 256 && !getenv("TAL_GEMM_SMALL_BK32"))
+    if (small && mode != 4 && aligned16 && !getenv("TAL_GEMM_NO_SPLITK4")) {
+        GemmArgs h = g;
+        h.tiles_n = (int)cdiv(g.N, 32);
+        const int64_t nb2 = cdiv(g.M, 32) * h.tiles_n;
+        TAL_CHECK_ARG(nb2 < (1ll << 31), "gemm: grid too large");
+        launch_splitk4(h, mode, dim3((unsigned)nb2, (unsigned)nbatch), s);
+    } else if (small && g.K >= 256)
         launch_tile<1, 1, 128>(g, mode, grid, s);
     else if (small)
         launch_tile<1, 1, 32>(g, mode, grid, s);

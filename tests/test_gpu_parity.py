@@ -239,7 +239,9 @@ def test_batch_items_independent(sd_model):
     mel = torch.randn(3, 2000, 80, generator=g).to(dev())
     full = sd_model.encoder.forward_time_major(mel)
     one = sd_model.encoder.forward_time_major(mel[1:2].contiguous())
-    np.testing.assert_array_equal(full[1].cpu().numpy(), one[0].cpu().numpy())
+    # kernel selection depends on the row count (M <= 512 rows take the split-K latency kernel, whose
+    # summation order differs), so equality is to fp32 round-off, not bitwise
+    np.testing.assert_allclose(full[1].cpu().numpy(), one[0].cpu().numpy(), atol=1e-5, rtol=0)
 
 
 # ------------------------------------------------------------------ full-size (1 hour) properties

@@ -233,7 +233,7 @@ static size_t tds_buf_floats(const tal_tds_desc* d, int B, int64_t T) {
 
 extern "C" size_t tal_tds_workspace_bytes(const tal_tds_desc* d, int B, int64_t T) {
     if (!d || B <= 0 || T <= 0) return 0;
-    return 3 * tds_buf_floats(d, B, T) * sizeof(float);
+    return 3 * tds_buf_floats(d, B, T) * sizeof(float) + gemm_splitk_ws_bytes();
 }
 
 extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t T, float* y, void* workspace,
@@ -250,6 +250,7 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
     const size_t nf = tds_buf_floats(d, B, T);
     float* buf[3] = {reinterpret_cast<float*>(workspace), reinterpret_cast<float*>(workspace) + nf,
                      reinterpret_cast<float*>(workspace) + 2 * nf};
+    float* skws = reinterpret_cast<float*>(workspace) + 3 * nf;   // split-K scratch of the dense layers
     // three rotating buffers; `ia` = index of the buffer holding the live activations (-1: caller's x).
     // No launch ever reads and writes the same buffer (workgroups read halos of their neighbours).
     const float* cur = x;
@@ -275,11 +276,12 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
             rc = launch_gconv_res(a, bw.conv_w, bw.conv_b, bw.resweight, B, To, c, d->groups, x1, s);
             if (rc) return rc;
             // h = relu(fc0(x1))                        : x1 -> h
-            rc = launch_linear(x1, bw.fc0_w, bw.fc0_b, nullptr, 0.f, 1, M, c, c, h, s);
+            rc = launch_linear_ws(x1, bw.fc0_w, bw.fc0_b, nullptr, 0.f, 1, M, c, c, h, skws, gemm_splitk_ws_bytes(), s);
             if (rc) return rc;
             // x2 = x1 + rw * fc3(h)                    : h (+res x1) -> a's buffer (dead since the gconv)
             float* outp = (last_stage && j == d->depths[i] - 1) ? y : buf[ia];
-            rc = launch_linear(h, bw.fc3_w, bw.fc3_b, x1, bw.resweight, 2, M, c, c, outp, s);
+            rc = launch_linear_ws(h, bw.fc3_w, bw.fc3_b, x1, bw.resweight, 2, M, c, c, outp, skws,
+                                  gemm_splitk_ws_bytes(), s);
             if (rc) return rc;
             a = outp;
         }

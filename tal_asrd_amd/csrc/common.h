@@ -66,6 +66,12 @@ struct GemmArgs {
     float* part_val;
     int32_t* part_idx;
     int part_ld;
+    // split-K tail (stream-K-lite, filled by launch_gemm): the tiles of the partial last scheduling
+    // round are cut into `split` K slices that write raw accumulators to `splitk_ws`; a fix-up kernel
+    // adds the slices in order and applies the epilogue.  tile_base offsets the logical tile index.
+    int tile_base, split, tail_tiles;
+    float* splitk_ws;
+    size_t splitk_ws_bytes;
 };
 // mode 0: acc+b | 1: relu(acc+b) | 2: res + alpha*(acc+b) | 3: alpha*(acc+b) | 4: row arg-max partials of acc+b
 int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s);
@@ -74,6 +80,10 @@ int gemm_mode4_partials(int64_t M, int N);
 // internal launchers shared between translation units
 int launch_linear(const float* x, const float* w, const float* b, const float* res, float alpha, int mode,
                   int64_t M, int N, int K, float* y, hipStream_t s);
+// same, with a scratch buffer that enables the split-K treatment of the last partial round
+int launch_linear_ws(const float* x, const float* w, const float* b, const float* res, float alpha, int mode,
+                     int64_t M, int N, int K, float* y, float* ws, size_t ws_bytes, hipStream_t s);
+size_t gemm_splitk_ws_bytes();
 int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, int64_t T_in, int C_in, int C_out,
                     int groups, float* y, hipStream_t s);
 int launch_gconv_res(const float* x, const float* wp, const float* bias, float alpha, int B, int64_t T, int C,

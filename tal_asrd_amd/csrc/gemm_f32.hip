@@ -195,7 +195,7 @@ __device__ __forceinline__ unsigned logical_tile() {
 // ---------------------------------------------------------------------------------------------
 // hot kernel: direct-to-LDS operand loads, double buffer, one barrier per K step
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int NSUB>
+template <int MODE, int NSUB, bool SPLITK>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
     constexpr int BM = 128, BN = 32 * NSUB;
     constexpr int ROWS = BM + BN;                 // 288 operand rows of 32 floats (128 B) per K step
@@ -203,7 +203,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
     constexpr int PER_WAVE = CHUNKS / 4;          // 9: t < 4 -> A rows, t >= 4 -> W rows
     __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * 32];  // 73,728 B -> 2 workgroups / CU
 
-    const unsigned logical = logical_tile();
+    // main launch: XCD-remapped tile index; split-K tail launch (g.split > 1): block -> (tile, K slice)
+    const int slice = SPLITK ? (int)(blockIdx.x / (unsigned)g.tail_tiles) : 0;
+    const unsigned logical = SPLITK ? (unsigned)g.tile_base + blockIdx.x % (unsigned)g.tail_tiles
+                                    : (unsigned)g.tile_base + logical_tile();
     const int64_t m0 = (int64_t)(logical / (unsigned)g.tiles_n) * BM;
     const int n0 = (int)(logical % (unsigned)g.tiles_n) * BN;
     const int64_t M = g.M;
@@ -256,9 +259,11 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
     const int frow = lane & 31;
     const int fsw = frow & 7;
     const int fhalf = lane >> 5;
-    const int nk = K / BK;
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nk_all = K / BK;
+    const int kt0 = SPLITK ? (int)((int64_t)slice * nk_all / g.split) : 0;
+    const int nk = SPLITK ? (int)((int64_t)(slice + 1) * nk_all / g.split) : nk_all;
+    issue(kt0, kt0 & 1);
+    for (int kt = kt0; kt < nk; ++kt) {
         // tile kt has landed (vmcnt(0) is part of the barrier while LDS-DMA is in flight) and every
         // wave is done reading the other buffer (it finished step kt-1 before arriving here)
         __syncthreads();
@@ -288,7 +293,18 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
         }
     }
     __syncthreads();  // all waves done with the operand buffers before they become the store stage
-    gemm_epilogue<MODE, NSUB>(g, acc, lds, Y, bias, res, m0, n0, lane, w, wm, wn);
+    if (SPLITK) {
+        // raw accumulators of this K slice -> scratch tile [(tile, slice)][128][BN]; the fix-up kernel
+        // adds the slices in a fixed order and applies bias / activation / residual
+        GemmArgs gp = g;
+        gp.M = m0 + BM;
+        gp.N = n0 + BN;
+        gp.ldy = BN;
+        float* tile_ws = g.splitk_ws + ((size_t)(logical - g.tile_base) * g.split + slice) * (BM * BN);
+        gemm_epilogue<0, NSUB>(gp, acc, lds, tile_ws - (m0 * BN + n0), nullptr, nullptr, m0, n0, lane, w, wm, wn);
+    } else {
+        gemm_epilogue<MODE, NSUB>(g, acc, lds, Y, bias, res, m0, n0, lane, w, wm, wn);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -523,14 +539,67 @@ static void launch_splitk4(const GemmArgs& g, int mode, dim3 grid, hipStream_t s
     }
 }
 
+// fix-up of the split-K tail: one workgroup per tail tile, slices added in ascending order
+template <int MODE, int NSUB>
+__global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(const GemmArgs g) {
+    constexpr int BM = 128, BN = 32 * NSUB;
+    const unsigned logical = (unsigned)g.tile_base + blockIdx.x;
+    const int64_t m0 = (int64_t)(logical / (unsigned)g.tiles_n) * BM;
+    const int n0 = (int)(logical % (unsigned)g.tiles_n) * BN;
+    const float* base = g.splitk_ws + (size_t)blockIdx.x * g.split * (BM * BN);
+    for (int i = threadIdx.x; i < BM * BN / 4; i += 256) {
+        const int r = i / (BN / 4), c = (i - r * (BN / 4)) * 4;
+        const int64_t row = m0 + r;
+        const int col = n0 + c;
+        if (row >= g.M || col >= g.N) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(base + r * BN + c);
+        for (int q = 1; q < g.split; ++q) v += *reinterpret_cast<const f32x4*>(base + (size_t)q * (BM * BN) + r * BN + c);
+        for (int e = 0; e < 4 && col + e < g.N; ++e) {
+            float x = v[e] + (g.bias ? g.bias[col + e] : 0.f);
+            if (MODE == 1) x = fmaxf(x, 0.f);
+            if (MODE == 2) x = g.res[row * g.ldres + col + e] + g.alpha * x;
+            if (MODE == 3) x = g.alpha * x;
+            g.Y[row * g.ldy + col + e] = x;
+        }
+    }
+}
+
+template <int NSUB>
+static void launch_fixup(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((gemm_splitk_fixup_kernel<0, NSUB>), grid, dim3(256), 0, s, g); break;
+        case 1: hipLaunchKernelGGL((gemm_splitk_fixup_kernel<1, NSUB>), grid, dim3(256), 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_splitk_fixup_kernel<2, NSUB>), grid, dim3(256), 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_splitk_fixup_kernel<3, NSUB>), grid, dim3(256), 0, s, g); break;
+    }
+}
+
+static int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+constexpr int SPLITK_MAX_SLICES = 512;   // tail tiles x slices
+size_t gemm_splitk_ws_bytes() { return (size_t)SPLITK_MAX_SLICES * 128 * 160 * sizeof(float); }
+
 template <int NSUB>
 static void launch_glds(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
+    if (g.split > 1) {   // K-slice launch of the split-K tail: raw accumulators, no epilogue variant
+        hipLaunchKernelGGL((gemm_glds_kernel<0, NSUB, true>), grid, dim3(256), 0, s, g);
+        return;
+    }
     switch (mode) {
-        case 0: hipLaunchKernelGGL((gemm_glds_kernel<0, NSUB>), grid, dim3(256), 0, s, g); break;
-        case 1: hipLaunchKernelGGL((gemm_glds_kernel<1, NSUB>), grid, dim3(256), 0, s, g); break;
-        case 2: hipLaunchKernelGGL((gemm_glds_kernel<2, NSUB>), grid, dim3(256), 0, s, g); break;
-        case 3: hipLaunchKernelGGL((gemm_glds_kernel<3, NSUB>), grid, dim3(256), 0, s, g); break;
-        default: hipLaunchKernelGGL((gemm_glds_kernel<4, NSUB>), grid, dim3(256), 0, s, g); break;
+        case 0: hipLaunchKernelGGL((gemm_glds_kernel<0, NSUB, false>), grid, dim3(256), 0, s, g); break;
+        case 1: hipLaunchKernelGGL((gemm_glds_kernel<1, NSUB, false>), grid, dim3(256), 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_glds_kernel<2, NSUB, false>), grid, dim3(256), 0, s, g); break;
+        case 3: hipLaunchKernelGGL((gemm_glds_kernel<3, NSUB, false>), grid, dim3(256), 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_glds_kernel<4, NSUB, false>), grid, dim3(256), 0, s, g); break;
     }
 }
 
@@ -566,12 +635,49 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
     else if (g.K % BK == 0 && aligned16 && !getenv("TAL_GEMM_NO_GLDS")) {
         // (a 128 x 96 tile -- 10.3 instead of 6.2 rounds on the 1-hour stage-3 shape -- was measured at
         //  +2 %, inside run-to-run noise: the 160-wide tile stays)
-        launch_glds<5>(g, mode, grid, s);
+        // Stream-K-lite: 2 workgroups per CU are resident, so a launch proceeds in rounds of 2*CUs
+        // tiles; when the last round is less than half full and the K loop is long, that remainder is
+        // cut along K so it occupies the whole chip for a fraction of a round instead of a few CUs for a
+        // whole one (1-hour stage-3 shape: 3168 tiles = 6.19 rounds).
+        const int64_t slots = 2 * (int64_t)device_cus();
+        const int64_t rem = nb % slots, full = nb - rem;
+        const int nk = g.K / BK;
+        int split = rem > 0 ? (int)(slots / rem) : 0;
+        if (split > 8) split = 8;
+        if (split > nk / 4) split = nk / 4;
+        const bool can_split = nbatch == 1 && mode <= 3 && g.splitk_ws && full > 0 && split >= 2 &&
+                               (size_t)rem * split * 128 * 160 * sizeof(float) <= g.splitk_ws_bytes &&
+                               !getenv("TAL_GEMM_NO_SPLITK_TAIL");
+        if (!can_split) {
+            launch_glds<5>(g, mode, grid, s);
+        } else {
+            GemmArgs h = g;
+            launch_glds<5>(h, mode, dim3((unsigned)full), s);          // whole rounds, normal epilogue
+            h.tile_base = (int)full;
+            h.split = split;
+            h.tail_tiles = (int)rem;
+            launch_glds<5>(h, mode, dim3((unsigned)(rem * split)), s);   // K slices of the remainder -> scratch
+            launch_fixup<5>(h, mode, dim3((unsigned)rem), s);            // ordered sum + epilogue
+        }
     }
     else
         launch_tile<4, 5, 32>(g, mode, grid, s);
     TAL_CHECK_LAUNCH("gemm");
     return TAL_OK;
+}
+
+int launch_linear_ws(const float* x, const float* w, const float* b, const float* res, float alpha, int mode, int64_t M,
+                     int N, int K, float* y, float* ws, size_t ws_bytes, hipStream_t s) {
+    TAL_CHECK_ARG(x && w && y, "tal_linear_fwd: null pointer");
+    GemmArgs g = {};
+    g.A = x; g.W = w; g.bias = b; g.res = res; g.Y = y;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldy = N; g.ldres = N;
+    g.nb2 = 1;
+    g.alpha = alpha;
+    g.splitk_ws = ws;
+    g.splitk_ws_bytes = ws_bytes;
+    return launch_gemm(g, mode, 1, s);
 }
 
 // number of (value, index) partials per row a mode-4 launch of this shape produces

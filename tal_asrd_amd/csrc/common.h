@@ -60,6 +60,7 @@ struct GemmArgs {
     int nb2;
     int64_t a_s1, a_s2, w_s1, w_s2, y_s1, y_s2, r_s1, r_s2, bias_s2;
     float alpha;
+    int scale_cols;  // mode 3: alpha applies to columns < scale_cols only (0 = all; must be a multiple of 4)
     int tiles_n;  // filled by launch_gemm
     // mode 4 (row arg-max instead of a store): per row and per 32*NSUB-column wave slice the best
     // (value, column) goes to part_val / part_idx [M, part_ld]; Y is not written.

@@ -53,11 +53,14 @@ __global__ __launch_bounds__(256) void add_positional_kernel(const float* __rest
 // avg [B, U, S] = mean_h P (MultiheadAttention's returned weights, models.py:517-519).
 __global__ __launch_bounds__(256) void attn_softmax_kernel(float* __restrict__ scores, const float* __restrict__ mask,
                                                           const uint8_t* __restrict__ kpm, float* __restrict__ avg,
-                                                          int B, int H, int U, int S, int S4) {
+                                                          int B, int H, int U, int S, int S4, float* __restrict__ vt_pad,
+                                                          int E) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (int64_t)B * U) return;
     const int b = (int)(row / U), u = (int)(row % U);
+    if (vt_pad && u == 0)   // pad columns of this batch item's V^T (consumed by the P.V product that follows)
+        for (int i = lane; i < E * (S4 - S); i += 64) vt_pad[((int64_t)b * E + i / (S4 - S)) * S4 + S + i % (S4 - S)] = 0.f;
     const float* mrow = mask ? mask + (int64_t)u * S : nullptr;
     const uint8_t* krow = kpm ? kpm + (int64_t)b * S : nullptr;
     float* arow = avg ? avg + row * S : nullptr;
@@ -105,12 +108,16 @@ constexpr int SM_NR = 8;
 __global__ __launch_bounds__(512) void attn_softmax_small_kernel(float* __restrict__ scores,
                                                                 const float* __restrict__ mask,
                                                                 const uint8_t* __restrict__ kpm,
-                                                                float* __restrict__ avg, int H, int U, int S, int S4) {
+                                                                float* __restrict__ avg, int H, int U, int S, int S4,
+                                                                float* __restrict__ vt_pad, int E) {
     extern __shared__ float ph[];  // [H][S]
     const int lane = threadIdx.x & 63;
     const int h = threadIdx.x >> 6;
     const int64_t row = blockIdx.x;
     const int b = (int)(row / U), u = (int)(row % U);
+    if (vt_pad && u == 0)   // pad columns of this batch item's V^T (consumed by the P.V product that follows)
+        for (int i = threadIdx.x; i < E * (S4 - S); i += blockDim.x)
+            vt_pad[((int64_t)b * E + i / (S4 - S)) * S4 + S + i % (S4 - S)] = 0.f;
     float* p = scores + (((int64_t)b * H + h) * U + u) * S4;
     float v[SM_NR];
     float m = -INFINITY;
@@ -225,52 +232,56 @@ struct MhaBufs {
     float* ctx;     // [B, U, E]
 };
 
+// K = x W_k^T + b_k and V^T = W_v . x^T (bias of V added after P.V) of `src` [B, S, E]
 static int project_kv(const float* in_w, const float* in_b, const float* src, int B, int S, int E, float* k, float* vt,
-                      hipStream_t s) {
+                      bool zero_pad, hipStream_t s) {
     const int64_t S4 = pad4(S);
-    int rc = launch_linear(src, in_w + (int64_t)E * E, in_b + E, nullptr, 0.f, 0, (int64_t)B * S, E, E, k, s);
-    if (rc) return rc;
-    if (S4 != S && hipMemsetAsync(vt, 0, (size_t)B * E * S4 * sizeof(float), s) != hipSuccess) {
+    int rc = 0;
+    if (k) {
+        rc = launch_linear(src, in_w + (int64_t)E * E, in_b + E, nullptr, 0.f, 0, (int64_t)B * S, E, E, k, s);
+        if (rc) return rc;
+    }
+    if (zero_pad && S4 != S && hipMemsetAsync(vt, 0, (size_t)B * E * S4 * sizeof(float), s) != hipSuccess) {
         set_error("mha: memset failed");
         return TAL_EHIP;
     }
     GemmArgs g = {};
-    g.A = in_w + 2 * (int64_t)E * E; g.W = src; g.Y = vt;   // V^T[b] = W_v . src_b^T  (bias added after P.V)
+    g.A = in_w + 2 * (int64_t)E * E; g.W = src; g.Y = vt;   // V^T[b] = W_v . src_b^T
     g.M = E; g.N = S; g.K = E;
     g.lda = E; g.ldw = E; g.ldy = S4;
     g.nb2 = 1; g.w_s1 = (int64_t)S * E; g.y_s1 = (int64_t)E * S4;
     return launch_gemm(g, 0, B, s);
 }
 
-// out = res + alpha * out_proj(softmax(q k^T + masks) v)
-static int mha_forward(const float* in_w, const float* in_b, const float* out_w, const float* out_b, const float* xq,
-                       const float* k, const float* vt, int B, int U, int S, int E, int H, const float* attn_mask,
-                       const uint8_t* kpm, const float* res, float alpha, float* out, float* avg, const MhaBufs& bf,
-                       hipStream_t s) {
+// out = res + alpha * out_proj(softmax(q k^T + masks) v) given projected q [B,U,*] (row pitch ldq, already
+// scaled), k [B,S,*] (pitch ldk) and V^T [B,E,S4].  vt_pad != NULL: the softmax kernel also zeroes the pad
+// columns of V^T (saves a memset launch per layer and step).
+static int mha_core(const float* in_b, const float* out_w, const float* out_b, const float* q, int64_t ldq,
+                    const float* k, int64_t ldk, const float* vt, float* vt_pad, int B, int U, int S, int E, int H,
+                    const float* attn_mask, const uint8_t* kpm, const float* res, float alpha, float* out, float* avg,
+                    const MhaBufs& bf, hipStream_t s) {
     const int hd = E / H;
     const int64_t S4 = pad4(S);
-    // q = (x W_q^T + b_q) * hd^-0.5   (torch scales q after the in-projection)
-    int rc = launch_linear(xq, in_w, in_b, nullptr, 1.0f / sqrtf((float)hd), 3, (int64_t)B * U, E, E, bf.q, s);
-    if (rc) return rc;
     GemmArgs g = {};
-    g.A = bf.q; g.W = k; g.Y = bf.scores;
+    g.A = q; g.W = k; g.Y = bf.scores;
     g.M = U; g.N = S; g.K = hd;
-    g.lda = E; g.ldw = E; g.ldy = S4;
+    g.lda = ldq; g.ldw = ldk; g.ldy = S4;
     g.nb2 = H;
-    g.a_s1 = (int64_t)U * E; g.a_s2 = hd;
-    g.w_s1 = (int64_t)S * E; g.w_s2 = hd;
+    g.a_s1 = (int64_t)U * ldq; g.a_s2 = hd;
+    g.w_s1 = (int64_t)S * ldk; g.w_s2 = hd;
     g.y_s1 = (int64_t)H * U * S4; g.y_s2 = (int64_t)U * S4;
-    rc = launch_gemm(g, 0, B * H, s);
+    int rc = launch_gemm(g, 0, B * H, s);
     if (rc) return rc;
+    if (S4 == S) vt_pad = nullptr;
     {
         ProfScope prof(PROF_OTHER, (double)B * H * U * S * 8.0, s);
         if (S <= 64 * SM_NR && H <= 8)
             hipLaunchKernelGGL(attn_softmax_small_kernel, dim3((unsigned)(B * U)), dim3(64 * H),
                                avg ? (size_t)H * S * sizeof(float) : 0, s, bf.scores, attn_mask, kpm, avg, H, U, S,
-                               (int)S4);
+                               (int)S4, vt_pad, E);
         else
             hipLaunchKernelGGL(attn_softmax_kernel, dim3((unsigned)cdiv((int64_t)B * U, 4)), dim3(256), 0, s, bf.scores,
-                               attn_mask, kpm, avg, B, H, U, S, (int)S4);
+                               attn_mask, kpm, avg, B, H, U, S, (int)S4, vt_pad, E);
     }
     TAL_CHECK_LAUNCH("attn_softmax");
     GemmArgs p = {};
@@ -285,6 +296,20 @@ static int mha_forward(const float* in_w, const float* in_b, const float* out_w,
     rc = launch_gemm(p, 0, B * H, s);
     if (rc) return rc;
     return launch_linear(bf.ctx, out_w, out_b, res, alpha, 2, (int64_t)B * U, E, E, out, s);
+}
+
+// q (scaled by hd^-0.5, as torch scales q after the in-projection) [and k] in ONE launch: rows 0..n*E of the
+// packed in-projection; alpha applies to the first E columns only.  dst [M, n*E].
+static int project_q_or_qk(const float* in_w, const float* in_b, const float* x, int64_t M, int E, int H, int n,
+                           float* dst, hipStream_t s) {
+    GemmArgs g = {};
+    g.A = x; g.W = in_w; g.bias = in_b; g.Y = dst;
+    g.M = M; g.N = n * E; g.K = E;
+    g.lda = E; g.ldw = E; g.ldy = n * E;
+    g.nb2 = 1;
+    g.alpha = 1.0f / sqrtf((float)(E / H));
+    g.scale_cols = n > 1 ? E : 0;
+    return launch_gemm(g, 3, 1, s);
 }
 
 struct LayerWs {
@@ -302,7 +327,7 @@ static LayerWs carve(float* base, int B, int U, int S, int E, int H, int FF) {
     LayerWs w;
     size_t o = 0;
     auto take = [&](size_t n) { float* p = base ? base + o : nullptr; o += up(n); return p; };
-    w.mha.q = take((size_t)B * U * E);
+    w.mha.q = take((size_t)B * U * 2 * E);   // q | k of the self-attention in one buffer
     w.mha.k = take((size_t)B * L * E);
     w.mha.vt = take((size_t)B * E * L4);
     w.mha.scores = take((size_t)B * H * U * L4);
@@ -349,7 +374,7 @@ extern "C" int tal_cross_kv_fwd(const tal_decoder_layer_w* w, const float* mem, 
                                 float* vt, void* stream) {
     TAL_CHECK_ARG(w && mem && k && vt && w->ca_in_w && w->ca_in_b, "tal_cross_kv_fwd: null pointer");
     TAL_CHECK_ARG(B > 0 && S > 0 && E > 0 && E % 4 == 0, "tal_cross_kv_fwd: bad shape");
-    return project_kv(w->ca_in_w, w->ca_in_b, mem, B, S, E, k, vt, (hipStream_t)stream);
+    return project_kv(w->ca_in_w, w->ca_in_b, mem, B, S, E, k, vt, true, (hipStream_t)stream);
 }
 
 extern "C" size_t tal_decoder_layer_workspace_bytes(int B, int U, int S, int E, int H, int FF) {
@@ -375,23 +400,29 @@ extern "C" int tal_decoder_layer_fwd(const tal_decoder_layer_w* w, const float* 
     }
     hipStream_t s = (hipStream_t)stream;
     LayerWs ws = carve(reinterpret_cast<float*>(workspace), B, U, S, E, H, FF);
-    // self attention over the prefix (keys = queries = tgt)
-    int rc = project_kv(w->sa_in_w, w->sa_in_b, tgt, B, U, E, ws.mha.k, ws.mha.vt, s);
+    // self attention over the prefix: q|k in one launch, V^T, scores/softmax/PV, out-proj + ReZero
+    int rc = project_q_or_qk(w->sa_in_w, w->sa_in_b, tgt, (int64_t)B * U, E, H, 2, ws.mha.q, s);
     if (rc) return rc;
-    rc = mha_forward(w->sa_in_w, w->sa_in_b, w->sa_out_w, w->sa_out_b, tgt, ws.mha.k, ws.mha.vt, B, U, U, E, H,
-                     tgt_mask, nullptr, tgt, w->resweight, ws.x1, nullptr, ws.mha, s);
+    rc = project_kv(w->sa_in_w, w->sa_in_b, tgt, B, U, E, nullptr, ws.mha.vt, false, s);
+    if (rc) return rc;
+    rc = mha_core(w->sa_in_b, w->sa_out_w, w->sa_out_b, ws.mha.q, 2 * E, ws.mha.q + E, 2 * E, ws.mha.vt, ws.mha.vt, B,
+                  U, U, E, H, tgt_mask, nullptr, tgt, w->resweight, ws.x1, nullptr, ws.mha, s);
     if (rc) return rc;
     // cross attention over the encoder window
     const float* ck = k_cache;
     const float* cvt = vt_cache;
+    float* pad = nullptr;
     if (!ck || !cvt) {
-        rc = project_kv(w->ca_in_w, w->ca_in_b, mem, B, S, E, ws.mha.k, ws.mha.vt, s);
+        rc = project_kv(w->ca_in_w, w->ca_in_b, mem, B, S, E, ws.mha.k, ws.mha.vt, false, s);
         if (rc) return rc;
         ck = ws.mha.k;
         cvt = ws.mha.vt;
+        pad = ws.mha.vt;
     }
-    rc = mha_forward(w->ca_in_w, w->ca_in_b, w->ca_out_w, w->ca_out_b, ws.x1, ck, cvt, B, U, S, E, H, nullptr, mem_kpm,
-                     ws.x1, w->resweight_src, ws.x2, xattn_avg, ws.mha, s);
+    rc = project_q_or_qk(w->ca_in_w, w->ca_in_b, ws.x1, (int64_t)B * U, E, H, 1, ws.mha.q, s);
+    if (rc) return rc;
+    rc = mha_core(w->ca_in_b, w->ca_out_w, w->ca_out_b, ws.mha.q, E, ck, E, cvt, pad, B, U, S, E, H, nullptr, mem_kpm,
+                  ws.x1, w->resweight_src, ws.x2, xattn_avg, ws.mha, s);
     if (rc) return rc;
     // feed-forward
     rc = launch_linear(ws.x2, w->lin1_w, w->lin1_b, nullptr, 0.f, 1, (int64_t)B * U, FF, E, ws.ff, s);

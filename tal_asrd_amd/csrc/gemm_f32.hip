@@ -129,7 +129,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
                     if (MODE == 2) v = rv[t] + alpha * v;
-                    if (MODE == 3) v = alpha * v;
+                    if (MODE == 3 && (g.scale_cols == 0 || colv[t] < g.scale_cols)) v = alpha * v;
                     if (rowv[t] < M) *reinterpret_cast<f32x4*>(Y + rowv[t] * g.ldy + colv[t]) = v;
                 }
                 continue;
@@ -149,14 +149,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                         }
                         if (MODE == 2) v = *reinterpret_cast<const f32x4*>(res + row * g.ldres + col) + alpha * v;
-                        if (MODE == 3) v = alpha * v;
+                        if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) v = alpha * v;
                         *reinterpret_cast<f32x4*>(Y + row * g.ldy + col) = v;
                     } else {
                         for (int q = 0; q < 4 && col + q < N; ++q) {
                             float x = v[q] + (bias ? bias[col + q] : 0.f);
                             if (MODE == 1) x = fmaxf(x, 0.f);
                             if (MODE == 2) x = res[row * g.ldres + col + q] + alpha * x;
-                            if (MODE == 3) x = alpha * x;
+                            if (MODE == 3 && (g.scale_cols == 0 || col + q < g.scale_cols)) x = alpha * x;
                             Y[row * g.ldy + col + q] = x;
                         }
                     }
@@ -176,7 +176,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                     float v = acc[j][e] + bv;
                     if (MODE == 1) v = fmaxf(v, 0.f);
                     if (MODE == 2) v = res[row * g.ldres + col] + alpha * v;
-                    if (MODE == 3) v = alpha * v;
+                    if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) v = alpha * v;
                     Y[row * g.ldy + col] = v;
                 }
             }
@@ -517,14 +517,14 @@ __global__ __launch_bounds__(256) void gemm_splitk4_kernel(const GemmArgs g) {
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + gc);
         if (MODE == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (MODE == 2) v = *reinterpret_cast<const f32x4*>(res + gr * g.ldres + gc) + alpha * v;
-        if (MODE == 3) v = alpha * v;
+        if (MODE == 3 && (g.scale_cols == 0 || gc < g.scale_cols)) v = alpha * v;
         *reinterpret_cast<f32x4*>(Y + gr * g.ldy + gc) = v;
     } else {
         for (int q = 0; q < 4 && gc + q < N; ++q) {
             float x = v[q] + (bias ? bias[gc + q] : 0.f);
             if (MODE == 1) x = fmaxf(x, 0.f);
             if (MODE == 2) x = res[gr * g.ldres + gc + q] + alpha * x;
-            if (MODE == 3) x = alpha * x;
+            if (MODE == 3 && (g.scale_cols == 0 || gc + q < g.scale_cols)) x = alpha * x;
             Y[gr * g.ldy + gc + q] = x;
         }
     }
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(const GemmArgs g
             float x = v[e] + (g.bias ? g.bias[col + e] : 0.f);
             if (MODE == 1) x = fmaxf(x, 0.f);
             if (MODE == 2) x = g.res[row * g.ldres + col + e] + g.alpha * x;
-            if (MODE == 3) x = g.alpha * x;
+            if (MODE == 3 && (g.scale_cols == 0 || col + e < g.scale_cols)) x = g.alpha * x;
             g.Y[row * g.ldy + col + e] = x;
         }
     }
@@ -610,6 +610,7 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
     TAL_CHECK_ARG(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0, "gemm: K=%d lda=%lld ldw=%lld must be multiples of 4", g.K, (long long)g.lda, (long long)g.ldw);
     TAL_CHECK_ARG(mode >= 0 && mode <= 4, "gemm: mode %d", mode);
     TAL_CHECK_ARG(mode != 2 || g.res, "gemm: mode 2 needs a residual");
+    TAL_CHECK_ARG(g.scale_cols % 4 == 0, "gemm: scale_cols must be a multiple of 4");
     TAL_CHECK_ARG(nbatch >= 1 && nbatch <= 65535 && g.nb2 >= 1, "gemm: batch %d", nbatch);
     if (g.M == 0) return TAL_OK;
     const bool small = g.M <= 512;

@@ -266,3 +266,24 @@ def test_one_hour_prefix_consistency_and_determinism(sd_model):
     # fused arg-max (no logits) == arg-max of materialised logits, at full size
     np.testing.assert_array_equal(i1[0].cpu().numpy(), i2[0, :4096].cpu().numpy())
     np.testing.assert_array_equal(l1.argmax(-1).cpu().numpy(), i1.cpu().numpy())
+
+
+def test_config3_batch_shape_items_match_single_calls(sd_model):
+    """BASELINE.json configs[3] shape on one GPU: a batch of 64 five-minute segments through the
+    encoder + fused head in ONE call; any item must equal its own B=1 call (round-off only: the
+    per-item zero padding keeps items independent, kernel selection may differ with the row count)."""
+    from tal_asrd_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    mel = torch.randn(64, 30001, 80, generator=g, device=dev())
+    enc = sd_model.encoder.forward_time_major(mel)
+    assert tuple(enc.shape) == (64, 3733, 1440)
+    feat, _, ids = ops.sd_head(enc, sd_model.spk_embed_proj.weight, sd_model.spk_embed_proj.bias,
+                               sd_model.spk_logit_proj.weight, sd_model.spk_logit_proj.bias, False, True)
+    for i in (0, 17, 63):
+        one = sd_model.encoder.forward_time_major(mel[i:i + 1].contiguous())
+        np.testing.assert_allclose(enc[i].cpu().numpy(), one[0].cpu().numpy(), atol=1e-5, rtol=0)
+        f1, l1, i1 = ops.sd_head(one, sd_model.spk_embed_proj.weight, sd_model.spk_embed_proj.bias,
+                                 sd_model.spk_logit_proj.weight, sd_model.spk_logit_proj.bias, True, True)
+        top2 = torch.topk(l1[0], 2, dim=-1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-3
+        assert bool((ids[i][safe] == i1[0][safe]).all())

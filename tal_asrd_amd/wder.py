@@ -95,6 +95,47 @@ def calculate_wder(ref, hyp):
     return dist / len(ref_words), dist, len(ref_words), 1.0 - acc, ref_labels, hyp_labels
 
 
+def convert_to_wder_format(speaker_utterances, tokenizer=str.split):
+    """[(utterance, speaker id | (embedding, id) | None)] -> ([(word, relative speaker index)], n_speakers).
+    tal/wder.py:82-147 without the HDBSCAN branch (clustering searches are out of scope, hdbscan is
+    absent).  Two behaviours of the reference are kept on purpose: speakers are numbered in order of first
+    appearance, and a `None` speaker stays a label of its own -- the reference computes a forward-filled
+    list (`s_u_filled`, :107-122) but builds its output from the unfilled one (:137-146).  The reference
+    tokenises with nltk's `word_tokenize` (absent here); the default below splits on whitespace."""
+    if not speaker_utterances:
+        raise ValueError("no utterances")
+    if isinstance(speaker_utterances[0][-1], tuple):
+        speaker_utterances = [(u, spk_id) for u, (_, spk_id) in speaker_utterances]
+    seen, out = [], []
+    for utt, spk in speaker_utterances:
+        if spk not in seen:
+            seen.append(spk)
+        k = seen.index(spk)
+        out.extend((w, k) for w in tokenizer(utt))
+    return out, len(seen)
+
+
+def wder_segment(ref_utts, hyp_utts, tokenizer=str.split):
+    """tal/wder.py:236-256 -> ([distance, n_ref], [ref_labels, hyp_labels], wder)."""
+    ref, _ = convert_to_wder_format(ref_utts, tokenizer)
+    hyp, _ = convert_to_wder_format(hyp_utts, tokenizer)
+    _, dist, n_ref, wder, rl, hl = calculate_wder(ref, hyp)
+    return [dist, n_ref], [rl, hl], wder
+
+
+def corpus_wder(paired_results, tokenizer=str.split):
+    """tal/wder.py:259-288 over the pickle schema [(ref_utts, hyp_utts)] (:313-352): pairs with an empty
+    side are skipped, overall WDER = mean of per-segment WDERs, overall WER = sum(distances) / sum(n_ref).
+    -> (overall_wder, overall_wer, per-segment wders)."""
+    res = [wder_segment(r, h, tokenizer) for r, h in paired_results if r and h]
+    if not res:
+        raise ValueError("no scorable (reference, hypothesis) pair")
+    wders = [w for _, _, w in res]
+    dist = sum(c[0] for c, _, _ in res)
+    n = sum(c[1] for c, _, _ in res)
+    return float(np.mean(wders)), dist / n, wders
+
+
 def tokens_to_words(tokens, vocab_size, bos_token_id=0, eos_token_id=1):
     """Turn a generated token stream into (token, turn-index) 'words': each EOS closes a speaker
     turn (tal/asr/tokenizers/__init__.py:103-138).  With the sentencepiece model absent, token ids

@@ -49,3 +49,15 @@ def test_identical_token_streams_give_zero_error():
     hyp[10] = (hyp[10][0] + 1, hyp[10][1])
     wer2, dist2, _, wder2, _, _ = W.calculate_wder(words, hyp)
     assert dist2 == 1 and wder2 == 0.0
+
+
+def test_corpus_wder_schema_and_none_quirk():
+    ref = [("hello there", "jack"), ("general kenobi", "margaret"), ("you are bold", "jack")]
+    hyp = [("hello there", (np.zeros(4), 5)), ("general kenobi", (np.ones(4), 9)), ("you are old", (np.zeros(4), 5))]
+    words, n = W.convert_to_wder_format(hyp)
+    assert n == 2 and words[0] == ("hello", 0) and words[2] == ("general", 1) and words[-1] == ("old", 0)
+    # a None speaker stays its own label (reference builds its output from the unfilled list)
+    words, n = W.convert_to_wder_format([("a b", None), ("c", 3), ("d", None)])
+    assert n == 2 and [s for _, s in words] == [0, 0, 1, 0]
+    owder, ower, wders = W.corpus_wder([(ref, hyp), (ref, []), (ref, hyp)])
+    assert len(wders) == 2 and owder == 0.0 and abs(ower - 1 / 7) < 1e-12

@@ -166,3 +166,40 @@ def synth_audio_batch(batch: int, num_samples: int, seed: int = 1234, lens=None)
         li = num_samples if lens is None else int(lens[i])
         x[i, :li] = synth_audio(li, seed + i)
     return x
+
+
+def uisrnn_echo_state_dict(obs_dim: int = 256, hidden: int = 512, noise: float = 0.01, tag: str = "uis-echo") -> dict:
+    """CoreRNN(obs_dim, hidden, 1, obs_dim) weights (keys of tal/diarization/uisrnn/uisrnn.py:20-32) for
+    which the predicted mean roughly echoes the last observation of a cluster, so that the CRP beam
+    search revisits clusters the way a trained model does -- random weights only ever open new
+    clusters.  Construction: update gate held near 0 (bias -4), candidate state tanh(0.5 x) in the
+    first obs_dim hidden units, mean head 2 * (relu(+h) - relu(-h)); every tensor also carries
+    deterministic noise so no term of the cell is exercised with exact zeros."""
+    assert hidden >= 2 * obs_dim
+    D, H = obs_dim, hidden
+    sd = {}
+    for name, shape in (("gru.weight_ih_l0", (3 * H, D)), ("gru.weight_hh_l0", (3 * H, H)), ("gru.bias_ih_l0", (3 * H,)),
+                        ("gru.bias_hh_l0", (3 * H,)), ("linear_mean1.weight", (H, H)), ("linear_mean1.bias", (H,)),
+                        ("linear_mean2.weight", (D, H)), ("linear_mean2.bias", (D,))):
+        sd[name] = synth_tensor(tag + "/" + name, shape, noise)
+    eye = np.eye(D, dtype=np.float32)
+    sd["gru.bias_ih_l0"][H:2 * H] -= 4.0                      # z ~ 0.02: h' ~ n
+    sd["gru.weight_ih_l0"][2 * H:2 * H + D, :] += 0.5 * eye   # n[:D] = tanh(0.5 x + ...)
+    sd["linear_mean1.weight"][:D, :D] += eye
+    sd["linear_mean1.weight"][D:2 * D, :D] -= eye
+    sd["linear_mean2.weight"][:, :D] += 2.0 * eye
+    sd["linear_mean2.weight"][:, D:2 * D] -= 2.0 * eye
+    return sd
+
+
+def uisrnn_sequence(n_obs: int, obs_dim: int, n_speakers: int, seed: int, noise: float = 0.05, scale: float = 0.5):
+    """Speaker-embedding-like test sequence: `n_speakers` fixed centroids, turns of 2-5 observations,
+    additive Gaussian noise.  -> (float64 [n_obs, obs_dim], list of true speaker labels)."""
+    cent = scale * synth_tensor("uis/centroid/%d" % seed, (n_speakers, obs_dim), 1.0).astype(np.float64)
+    rng = np.random.RandomState(seed)
+    labels, cur = [], 0
+    while len(labels) < n_obs:
+        labels += [cur] * int(rng.randint(2, 6))
+        cur = (cur + int(rng.randint(1, n_speakers))) % n_speakers
+    labels = labels[:n_obs]
+    return cent[labels] + noise * rng.randn(n_obs, obs_dim), labels

@@ -122,6 +122,13 @@ def load_reference():
     asr.models = _load("wildspeech.asr.models", "tal/asr/models.py")
     asr.util = _load("wildspeech.asr.util", "tal/asr/util.py")
     asr.system = _load("wildspeech.asr.system", "tal/asr/system.py")
+    # transcribe.py: audio file IO / VAD / duration probes are import plumbing only
+    # (make_golden feeds the waveform through stand-ins for torchaudio.info / torchaudio.load)
+    asr.speech_detect = _mod("wildspeech.asr.speech_detect", get_speech_frames=None)
+    _mod("librosa")
+    _mod("librosa.core", get_duration=None)
+    _mod("mutagen", File=None)
+    asr.transcribe = _load("wildspeech.asr.transcribe", "tal/asr/transcribe.py")
 
     dia = _mod("wildspeech.diarization")
     dia.__path__ = [os.path.join(REF, "tal/diarization")]
@@ -133,6 +140,7 @@ def load_reference():
     uis_pkg.uisrnn = _load("wildspeech.diarization.uisrnn.uisrnn", "tal/diarization/uisrnn/uisrnn.py")
 
     ns = types.SimpleNamespace(models=asr.models, modules=ws.modules, util=asr.util,
-                               system=asr.system, uisrnn=uis_pkg.uisrnn)
+                               system=asr.system, uisrnn=uis_pkg.uisrnn,
+                               transcribe=asr.transcribe)
     _loaded["ns"] = ns
     return ns

@@ -256,8 +256,124 @@ def sec_flow(ns):
          attn=np.stack([a.numpy()[0] for _, a in align]).astype(np.float32))
 
 
+SPLICE_CASES = [
+    (["the quick brown fox jumps over the lazy dog and runs", "over the lazy dog and runs away to the hills",
+      "away to the hills where nobody ever goes"], 5),
+    (["12 7 99 4 310 25 8 8 41 7", "25 8 8 41 7 300 2 19", "2 19 5 5 5 640 11"], 3),
+    (["no overlap at all here", "completely different words follow", "and a third unrelated one"], 4),
+    (["short ab", "ab tiny"], 5),
+    (["one two three four five six seven eight nine ten", "seven eight nine ten eleven twelve",
+      "eleven twelve thirteen", "twelve thirteen fourteen fifteen sixteen"], 20),
+    (["repeat repeat repeat repeat repeat end", "repeat repeat end of the repeat repeat line", "line done"], 6),
+]
+
+
+def sec_transcribe(ns):
+    """Windowed transcription: the reference's own splice helpers on fixed strings, and
+    its transcribe_file (tal/asr/transcribe.py:79-169) driven through stand-ins for the audio file IO.
+    The reference's transcribe_batch passes beam_width= / lm_weight= to a System.generate that takes
+    beam_size (system.py:67-75); the stand-in `model.generate` below maps one onto the other."""
+    import json
+    import types
+    T = ns.transcribe
+    cases = []
+    for strs, wo in SPLICE_CASES:
+        cases.append({"strs": strs, "word_overlap": wo,
+                      "overlap_ix": [list(T.overlap_ix(strs[i], strs[i + 1], wo)) for i in range(len(strs) - 1)],
+                      "splice_ix": [list(map(int, T.splice_ix(strs[i], strs[i + 1], wo))) for i in range(len(strs) - 1)],
+                      "spliced": T.splice_strings(strs, wo)})
+    with open(os.path.join(HERE, "splice_strings.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    print("splice_strings.json", len(cases), "cases")
+
+    System = ns.system.System
+    model = _asr_model(ns)
+    L, window, stride, bs, length = 400000, 160000, 120000, 2, 16
+    audio = synth.synth_audio_batch(1, L, 909)[0]
+    inner = types.SimpleNamespace(model=model, lm=None,
+                                  tokenizer=types.SimpleNamespace(eos_token_id=1, bos_token_id=0, pad_token_id=2),
+                                  args=types.SimpleNamespace(spk_weight=0.0, lm_weight=0.0))
+    # greedy probe of the windows to choose an end-of-transcript id that some (not all) windows emit
+    bounds = [(stride * i, stride * i + window) for i in range(int(np.ceil((L - window) / stride)) + 1)]
+    probe = []
+    inner_spk = types.SimpleNamespace(model=model, lm=None, tokenizer=inner.tokenizer,   # force_output needs the
+                                      args=types.SimpleNamespace(spk_weight=1.0, lm_weight=0.0))  # speaker head (:232)
+    for s, e in bounds:
+        w = torch.from_numpy(audio[s:e])[None]
+        sq, _ = System.generate(inner_spk, w, torch.zeros(1, 1, dtype=torch.long), torch.tensor([w.shape[1]]),
+                                length=length, beam_size=1, terminate_token=None, force_half=False, force_output=True)
+        probe.append(sq[0].tolist())
+    print("greedy probe:", probe)
+    counts = {}
+    for p in probe:
+        for t in set(p[3:]):
+            counts[t] = counts.get(t, 0) + 1
+    eot = sorted((t for t, c in counts.items() if 0 < c < len(probe)), key=lambda t: (-counts[t], t))
+    eot = eot[0] if eot else probe[0][5]
+
+    def generate(audio_x, generated, audio_lens, length, beam_width, terminate_token, lm_weight):
+        seqs, _ = System.generate(inner, audio_x, generated, audio_lens, length, beam_size=beam_width,
+                                  terminate_token=terminate_token, force_half=False)
+        return seqs
+    me = types.SimpleNamespace(generate=generate,
+                               tokenizer=types.SimpleNamespace(bos_token_id=0, eos_token_id=1, eot_token_id=eot,
+                                                               decode=lambda b: " ".join(str(int(t)) for t in b)))
+    ta = sys.modules["torchaudio"]
+    ta.info = lambda path: (types.SimpleNamespace(rate=16000), None)
+    ta.load = lambda path: (torch.from_numpy(audio)[None], 16000)
+    out = {"audio_seed": 909, "audio_len": L, "window": window, "stride": stride, "batch_size": bs,
+           "length": length, "eot": int(eot), "n_windows": len(bounds)}
+    for beam in (1, 2):
+        texts = T.transcribe_file("synthetic", me, window, stride, batch_size=bs, beam_width=beam, length=length,
+                                  device="cpu", splice=False, use_eot=True)
+        out["beam%d_texts" % beam] = texts
+        print("beam", beam, texts)
+        if len(texts) >= 2:
+            out["beam%d_spliced" % beam] = T.transcribe_file("synthetic", me, window, stride, batch_size=bs,
+                                                             beam_width=beam, length=length, device="cpu",
+                                                             splice=True, use_eot=True)
+    with open(os.path.join(HERE, "flow_transcribe.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+UIS_CASES = [
+    # name, weights, depth, sigma2, transition_bias, crp_alpha, beam, look_ahead, test_iteration, n_obs, n_spk, seed, noise
+    ("echo_la1", "echo", 1, 0.05, 0.3, 1.0, 6, 1, 2, 30, 3, 5, 0.15),
+    ("random_la1", "corernn.", 1, 0.03, 0.1, 1.0, 4, 1, 2, 24, 3, 5, 0.05),
+    ("echo_la2", "echo", 1, 0.05, 0.2, 1.0, 3, 2, 1, 9, 3, 7, 0.05),
+    ("random_depth2", "corernn2.", 2, 0.03, 0.2, 1.0, 4, 1, 2, 16, 2, 11, 0.05),
+]
+
+
+def sec_uisrnn(ns):
+    """UIS-RNN inference: the reference's own UISRNN.predict_single
+    (tal/diarization/uisrnn/uisrnn.py:470-554) on synthetic speaker-embedding sequences."""
+    import json
+    import types
+    out = []
+    for (name, wts, depth, sigma2, tb, alpha, beam, la, iters, n_obs, n_spk, seed, noise) in UIS_CASES:
+        args = types.SimpleNamespace(observation_dim=256, enable_cuda=False, rnn_hidden_size=512, rnn_depth=depth,
+                                     rnn_dropout=0, sigma2=sigma2, transition_bias=tb, crp_alpha=alpha, verbosity=0)
+        m = ns.uisrnn.UISRNN(args)
+        if wts == "echo":
+            m.rnn_model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.uisrnn_echo_state_dict().items()})
+            m.rnn_model.eval()
+        else:
+            fill(m.rnn_model, wts)
+        x, labels = synth.uisrnn_sequence(n_obs, 256, n_spk, seed, noise)
+        inf = types.SimpleNamespace(beam_size=beam, look_ahead=la, test_iteration=iters)
+        pred = [int(t) for t in m.predict_single(x, inf)]
+        print(name, pred)
+        out.append({"name": name, "weights": wts, "depth": depth, "sigma2": sigma2, "transition_bias": tb,
+                    "crp_alpha": alpha, "beam_size": beam, "look_ahead": la, "test_iteration": iters, "n_obs": n_obs,
+                    "n_speakers": n_spk, "seed": seed, "noise": noise, "truth": labels, "pred": pred})
+    with open(os.path.join(HERE, "uisrnn_predict.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 SECTIONS = {"keys": sec_keys, "unit": sec_unit, "sd": sec_sd, "asr": sec_asr,
-            "decode": sec_decode, "gru": sec_gru, "flow": sec_flow}
+            "decode": sec_decode, "gru": sec_gru, "flow": sec_flow,
+            "transcribe": sec_transcribe, "uisrnn": sec_uisrnn}
 
 if __name__ == "__main__":
     ns = load_reference()

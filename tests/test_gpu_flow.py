@@ -96,3 +96,31 @@ def test_beam_topk_kernel_matches_torch():
     v, i = _beam_topk(lp.to(dev()), sc.to(dev()), done.to(dev()), B, beam, beam)
     np.testing.assert_array_equal(i.cpu().numpy(), want_i.numpy())
     np.testing.assert_array_equal(v.cpu().numpy(), want_v.numpy())
+
+
+def test_windowed_transcription_matches_reference_transcribe_file(asr_model):
+    """tal/asr/transcribe.py:79-169 recorded from the reference's own transcribe_file (windows of 10 s,
+    7.5 s apart, batches of 2, a window whose beam never finishes is dropped)."""
+    import json
+    import os
+    from tal_asrd_amd import synth
+    from tal_asrd_amd.system import System
+    from tal_asrd_amd.transcribe import transcribe_file
+    with open(os.path.join(os.path.dirname(__file__), "golden", "flow_transcribe.json")) as f:
+        g = json.load(f)
+    audio = torch.from_numpy(synth.synth_audio_batch(1, g["audio_len"], g["audio_seed"])[0]).to(dev())
+    sys_ = System(asr_model, spk_weight=0.0)
+
+    def text(seq):
+        return " ".join(str(int(t)) for t in seq)
+    for beam in (1, 2):
+        got = transcribe_file(audio, sys_, g["window"], g["stride"], batch_size=g["batch_size"], beam_width=beam,
+                              length=g["length"], use_eot=True, eot_token_id=g["eot"], decode=text)
+        assert got == g["beam%d_texts" % beam]
+        spliced = transcribe_file(audio, sys_, g["window"], g["stride"], batch_size=g["batch_size"],
+                                  beam_width=beam, length=g["length"], use_eot=True, eot_token_id=g["eot"],
+                                  decode=text, splice=True)
+        assert spliced == g["beam%d_spliced" % beam]
+    raw = transcribe_file(audio, sys_, g["window"], g["stride"], batch_size=3, beam_width=1, length=g["length"],
+                          use_eot=True, eot_token_id=g["eot"])
+    assert [text(s) for s in raw] == g["beam1_texts"]       # batch composition does not change results

@@ -195,7 +195,7 @@ __device__ __forceinline__ unsigned logical_tile() {
 // ---------------------------------------------------------------------------------------------
 // hot kernel: direct-to-LDS operand loads, double buffer, one barrier per K step
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int NSUB, bool SPLITK>
+template <int MODE, int NSUB, bool SPLITK, int STAGE>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
     constexpr int BM = 128, BN = 32 * NSUB;
     constexpr int ROWS = BM + BN;                 // 288 operand rows of 32 floats (128 B) per K step
@@ -240,12 +240,38 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
         else
             src[t] = W + (int64_t)(n0 + min(row - BM, b_rows)) * g.ldw + srccol;
     }
+    // STAGE 2 (default): the LDS-DMA loads use the buffer form -- descriptor in SGPRs, one 32-bit lane
+    // offset, the K offset in an SGPR -- instead of 64-bit lane addresses.  On gfx950 every vector-memory
+    // instruction costs the SIMD matrix-pipe issue cycles and the global form (plus the 64-bit VALU add
+    // per load that advances its address) costs the most: K-loop step 4.77 -> 4.43 us of an ideal 4.27
+    // (scripts/ubench/mfma_mix.hip isolates the ingredients; scripts/bench_gemm_fit.py the real kernel).
+    // STAGE 0 keeps the global form for leading dimensions whose lane offsets do not fit 32 bits.
+    // (64-bit multiplies run on the VALU even for uniform values; the descriptors must sit in SGPRs)
+    auto uniform_ptr = [](const float* p) {
+        const uint64_t v = reinterpret_cast<uint64_t>(p);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    };
+    __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(A + m0 * g.lda), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(W + (int64_t)n0 * g.ldw), 0, 0x7fffffff, 0x00020000);
+    int voff[PER_WAVE];
+#pragma unroll
+    for (int t = 0; t < PER_WAVE; ++t) {
+        const int row = 8 * (w + 4 * t) + sub;
+        voff[t] = t < 4 ? (int)((min(row, a_rows) * g.lda + srccol) * 4) : (int)((min(row - BM, b_rows) * g.ldw + srccol) * 4);
+    }
     auto issue = [&](int kt, int buf) {
 #pragma unroll
         for (int t = 0; t < PER_WAVE; ++t) {
             float* dst = lds + buf * (ROWS * 32) + (w + 4 * t) * 256;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            if (STAGE == 2) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass drops the whole kernel stub when it meets this builtin)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(t < 4 ? rsrc_a : rsrc_w, (__attribute__((address_space(3))) void*)dst, 16,
+                                                         voff[t], kt * (BK * 4), 0, 0);
+#endif
+            } else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + kt * BK),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
 
@@ -590,16 +616,31 @@ size_t gemm_splitk_ws_bytes() { return (size_t)SPLITK_MAX_SLICES * 128 * 160 * s
 
 template <int NSUB>
 static void launch_glds(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
+    // the buffer form of the operand loads (default) needs the tile's lane offsets to fit 32 bits
+    static const int want = getenv("TAL_GEMM_STAGE") ? atoi(getenv("TAL_GEMM_STAGE")) : 2;
+    const int st = (want == 2 && g.lda < (1 << 21) && g.ldw < (1 << 21)) ? 2 : 0;
     if (g.split > 1) {   // K-slice launch of the split-K tail: raw accumulators, no epilogue variant
-        hipLaunchKernelGGL((gemm_glds_kernel<0, NSUB, true>), grid, dim3(256), 0, s, g);
+        { if (st == 2) hipLaunchKernelGGL((gemm_glds_kernel<0, NSUB, true, 2>), grid, dim3(256), 0, s, g);
+                else hipLaunchKernelGGL((gemm_glds_kernel<0, NSUB, true, 0>), grid, dim3(256), 0, s, g); }
         return;
     }
     switch (mode) {
-        case 0: hipLaunchKernelGGL((gemm_glds_kernel<0, NSUB, false>), grid, dim3(256), 0, s, g); break;
-        case 1: hipLaunchKernelGGL((gemm_glds_kernel<1, NSUB, false>), grid, dim3(256), 0, s, g); break;
-        case 2: hipLaunchKernelGGL((gemm_glds_kernel<2, NSUB, false>), grid, dim3(256), 0, s, g); break;
-        case 3: hipLaunchKernelGGL((gemm_glds_kernel<3, NSUB, false>), grid, dim3(256), 0, s, g); break;
-        default: hipLaunchKernelGGL((gemm_glds_kernel<4, NSUB, false>), grid, dim3(256), 0, s, g); break;
+        case 0: { if (st == 2) hipLaunchKernelGGL((gemm_glds_kernel<0, NSUB, false, 2>), grid, dim3(256), 0, s, g);
+                else hipLaunchKernelGGL((gemm_glds_kernel<0, NSUB, false, 0>), grid, dim3(256), 0, s, g); }
+                break;
+        case 1: { if (st == 2) hipLaunchKernelGGL((gemm_glds_kernel<1, NSUB, false, 2>), grid, dim3(256), 0, s, g);
+                else hipLaunchKernelGGL((gemm_glds_kernel<1, NSUB, false, 0>), grid, dim3(256), 0, s, g); }
+                break;
+        case 2: { if (st == 2) hipLaunchKernelGGL((gemm_glds_kernel<2, NSUB, false, 2>), grid, dim3(256), 0, s, g);
+                else hipLaunchKernelGGL((gemm_glds_kernel<2, NSUB, false, 0>), grid, dim3(256), 0, s, g); }
+                break;
+        case 3: { if (st == 2) hipLaunchKernelGGL((gemm_glds_kernel<3, NSUB, false, 2>), grid, dim3(256), 0, s, g);
+                else hipLaunchKernelGGL((gemm_glds_kernel<3, NSUB, false, 0>), grid, dim3(256), 0, s, g); }
+                break;
+        default:
+            { if (st == 2) hipLaunchKernelGGL((gemm_glds_kernel<4, NSUB, false, 2>), grid, dim3(256), 0, s, g);
+                else hipLaunchKernelGGL((gemm_glds_kernel<4, NSUB, false, 0>), grid, dim3(256), 0, s, g); }
+                break;
     }
 }
 

@@ -77,6 +77,14 @@ int tal_subtract_scalar(float* x, int64_t n, const float* mean, void* stream);
  * ------------------------------------------------------------------ */
 int tal_linear_fwd(const float* x, const float* w, const float* b, const float* res, float alpha,
                    int mode, int64_t M, int N, int K, float* y, void* stream);
+/* Same layer with caller-provided scratch: lets a large layer (M > 512) cut the tiles of its last,
+ * partial scheduling round along K (results then differ from tal_linear_fwd in the last bits of those
+ * rows: two partial sums instead of one chain).  tal_linear_workspace_bytes returns 0 when scratch
+ * would not be used; workspace may then be NULL. */
+size_t tal_linear_workspace_bytes(int64_t M, int N, int K);
+int tal_linear_ws_fwd(const float* x, const float* w, const float* b, const float* res, float alpha,
+                      int mode, int64_t M, int N, int K, float* y, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Grouped temporal convolutions of the TDS encoder.

@@ -21,12 +21,12 @@ for mode in (1, 2):
         res = torch.randn(M, N, device=dev)
         y = torch.empty(M, N, device=dev)
         for _ in range(3):
-            ops.linear(x, w, b, mode=mode, res=res, alpha=0.3, out=y)
+            ops.linear(x, w, b, mode=mode, res=res, alpha=float(os.environ.get('FIT_ALPHA','0.3')), out=y)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 10
         e0.record()
         for _ in range(n):
-            ops.linear(x, w, b, mode=mode, res=res, alpha=0.3, out=y)
+            ops.linear(x, w, b, mode=mode, res=res, alpha=float(os.environ.get('FIT_ALPHA','0.3')), out=y)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n

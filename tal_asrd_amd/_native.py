@@ -47,6 +47,8 @@ SIGNATURES = {
     "tal_logmel_fwd": (_i, [_p, _p, _i, _i64, _f, _i, _p, _p, _p, _p, _sz, _p]),
     "tal_subtract_scalar": (_i, [_p, _i64, _p, _p]),
     "tal_linear_fwd": (_i, [_p, _p, _p, _p, _f, _i, _i64, _i, _i, _p, _p]),
+    "tal_linear_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "tal_linear_ws_fwd": (_i, [_p, _p, _p, _p, _f, _i, _i64, _i, _i, _p, _p, _sz, _p]),
     "tal_pack_gconv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "tal_gconv_s2_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _p, _p]),
     "tal_gconv_res_fwd": (_i, [_p, _p, _p, _f, _i, _i64, _i, _i, _p, _p]),

@@ -185,6 +185,17 @@ extern "C" int tal_linear_fwd(const float* x, const float* w, const float* b, co
     return launch_linear(x, w, b, res, alpha, mode, M, N, K, y, (hipStream_t)stream);
 }
 
+extern "C" size_t tal_linear_workspace_bytes(int64_t M, int N, int K) {
+    return (M > 512 && K % 32 == 0 && K >= 256 && N > 0) ? gemm_splitk_ws_bytes() : 0;
+}
+
+extern "C" int tal_linear_ws_fwd(const float* x, const float* w, const float* b, const float* res, float alpha, int mode,
+                                 int64_t M, int N, int K, float* y, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+    TAL_CHECK_ARG(workspace || workspace_bytes == 0, "tal_linear_ws_fwd: null workspace with %zu bytes", workspace_bytes);
+    return launch_linear_ws(x, w, b, res, alpha, mode, M, N, K, y, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 extern "C" int tal_gconv_s2_fwd(const float* x, const float* w_packed, const float* bias, int B, int64_t T_in,
                                 int C_in, int C_out, int groups, float* y, void* stream) {
     return launch_gconv_s2(x, w_packed, bias, B, T_in, C_in, C_out, groups, y, (hipStream_t)stream);

@@ -186,11 +186,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 
 // XCD-aware bijective remap: XCD x (= blockIdx % 8) walks a contiguous range of logical tiles,
 // N-tiles of one M-tile first, so the A panel is re-read from that XCD's L2.
-__device__ __forceinline__ unsigned logical_tile() {
-    const unsigned nb = gridDim.x, bid = blockIdx.x;
+__device__ __forceinline__ unsigned logical_tile_of(unsigned nb, unsigned bid) {
     const unsigned xcd = bid & 7u, q = nb >> 3, r = nb & 7u;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
+__device__ __forceinline__ unsigned logical_tile() { return logical_tile_of(gridDim.x, blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------
 // hot kernel: direct-to-LDS operand loads, double buffer, one barrier per K step
@@ -203,10 +203,14 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
     constexpr int PER_WAVE = CHUNKS / 4;          // 9: t < 4 -> A rows, t >= 4 -> W rows
     __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * 32];  // 73,728 B -> 2 workgroups / CU
 
-    // main launch: XCD-remapped tile index; split-K tail launch (g.split > 1): block -> (tile, K slice)
-    const int slice = SPLITK ? (int)(blockIdx.x / (unsigned)g.tail_tiles) : 0;
-    const unsigned logical = SPLITK ? (unsigned)g.tile_base + blockIdx.x % (unsigned)g.tail_tiles
-                                    : (unsigned)g.tile_base + logical_tile();
+    // XCD-remapped tile index.  SPLITK launches carry the whole-round tiles (blocks < tile_base) AND, behind
+    // them in dispatch order, the K slices of the last partial round (block -> (tile, K slice)), so the
+    // slices fill slots as the whole tiles drain instead of waiting for a kernel boundary.
+    const bool is_slice = SPLITK && blockIdx.x >= (unsigned)g.tile_base;
+    const unsigned sbid = blockIdx.x - (unsigned)g.tile_base;
+    const int slice = is_slice ? (int)(sbid / (unsigned)g.tail_tiles) : 0;
+    const unsigned logical = is_slice ? (unsigned)g.tile_base + sbid % (unsigned)g.tail_tiles
+                                      : (SPLITK ? logical_tile_of((unsigned)g.tile_base, blockIdx.x) : logical_tile());
     const int64_t m0 = (int64_t)(logical / (unsigned)g.tiles_n) * BM;
     const int n0 = (int)(logical % (unsigned)g.tiles_n) * BN;
     const int64_t M = g.M;
@@ -286,8 +290,8 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
     const int fsw = frow & 7;
     const int fhalf = lane >> 5;
     const int nk_all = K / BK;
-    const int kt0 = SPLITK ? (int)((int64_t)slice * nk_all / g.split) : 0;
-    const int nk = SPLITK ? (int)((int64_t)(slice + 1) * nk_all / g.split) : nk_all;
+    const int kt0 = is_slice ? (int)((int64_t)slice * nk_all / g.split) : 0;
+    const int nk = is_slice ? (int)((int64_t)(slice + 1) * nk_all / g.split) : nk_all;
     issue(kt0, kt0 & 1);
     for (int kt = kt0; kt < nk; ++kt) {
         // tile kt has landed (vmcnt(0) is part of the barrier while LDS-DMA is in flight) and every
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
         }
     }
     __syncthreads();  // all waves done with the operand buffers before they become the store stage
-    if (SPLITK) {
+    if (is_slice) {
         // raw accumulators of this K slice -> scratch tile [(tile, slice)][128][BN]; the fix-up kernel
         // adds the slices in a fixed order and applies bias / activation / residual
         GemmArgs gp = g;
@@ -611,36 +615,37 @@ static int device_cus() {
     return cus;
 }
 
-constexpr int SPLITK_MAX_SLICES = 512;   // tail tiles x slices
+constexpr int SPLITK_MAX_SLICES = 1024;  // tail tiles x slices (84 MB of scratch)
 size_t gemm_splitk_ws_bytes() { return (size_t)SPLITK_MAX_SLICES * 128 * 160 * sizeof(float); }
 
-template <int NSUB>
-static void launch_glds(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
+template <int MODE, int NSUB, bool SPLITK>
+static void launch_glds_stage(const GemmArgs& g, dim3 grid, hipStream_t s) {
     // the buffer form of the operand loads (default) needs the tile's lane offsets to fit 32 bits
     static const int want = getenv("TAL_GEMM_STAGE") ? atoi(getenv("TAL_GEMM_STAGE")) : 2;
-    const int st = (want == 2 && g.lda < (1 << 21) && g.ldw < (1 << 21)) ? 2 : 0;
-    if (g.split > 1) {   // K-slice launch of the split-K tail: raw accumulators, no epilogue variant
-        { if (st == 2) hipLaunchKernelGGL((gemm_glds_kernel<0, NSUB, true, 2>), grid, dim3(256), 0, s, g);
-                else hipLaunchKernelGGL((gemm_glds_kernel<0, NSUB, true, 0>), grid, dim3(256), 0, s, g); }
+    if (want == 2 && g.lda < (1 << 21) && g.ldw < (1 << 21))
+        hipLaunchKernelGGL((gemm_glds_kernel<MODE, NSUB, SPLITK, 2>), grid, dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_glds_kernel<MODE, NSUB, SPLITK, 0>), grid, dim3(256), 0, s, g);
+}
+
+// splitk: the grid is [whole-round tiles | K slices of the remaining tiles] (modes 0..3 only)
+template <int NSUB>
+static void launch_glds(const GemmArgs& g, int mode, bool splitk, dim3 grid, hipStream_t s) {
+    if (splitk) {
+        switch (mode) {
+            case 0: launch_glds_stage<0, NSUB, true>(g, grid, s); break;
+            case 1: launch_glds_stage<1, NSUB, true>(g, grid, s); break;
+            case 2: launch_glds_stage<2, NSUB, true>(g, grid, s); break;
+            default: launch_glds_stage<3, NSUB, true>(g, grid, s); break;
+        }
         return;
     }
     switch (mode) {
-        case 0: { if (st == 2) hipLaunchKernelGGL((gemm_glds_kernel<0, NSUB, false, 2>), grid, dim3(256), 0, s, g);
-                else hipLaunchKernelGGL((gemm_glds_kernel<0, NSUB, false, 0>), grid, dim3(256), 0, s, g); }
-                break;
-        case 1: { if (st == 2) hipLaunchKernelGGL((gemm_glds_kernel<1, NSUB, false, 2>), grid, dim3(256), 0, s, g);
-                else hipLaunchKernelGGL((gemm_glds_kernel<1, NSUB, false, 0>), grid, dim3(256), 0, s, g); }
-                break;
-        case 2: { if (st == 2) hipLaunchKernelGGL((gemm_glds_kernel<2, NSUB, false, 2>), grid, dim3(256), 0, s, g);
-                else hipLaunchKernelGGL((gemm_glds_kernel<2, NSUB, false, 0>), grid, dim3(256), 0, s, g); }
-                break;
-        case 3: { if (st == 2) hipLaunchKernelGGL((gemm_glds_kernel<3, NSUB, false, 2>), grid, dim3(256), 0, s, g);
-                else hipLaunchKernelGGL((gemm_glds_kernel<3, NSUB, false, 0>), grid, dim3(256), 0, s, g); }
-                break;
-        default:
-            { if (st == 2) hipLaunchKernelGGL((gemm_glds_kernel<4, NSUB, false, 2>), grid, dim3(256), 0, s, g);
-                else hipLaunchKernelGGL((gemm_glds_kernel<4, NSUB, false, 0>), grid, dim3(256), 0, s, g); }
-                break;
+        case 0: launch_glds_stage<0, NSUB, false>(g, grid, s); break;
+        case 1: launch_glds_stage<1, NSUB, false>(g, grid, s); break;
+        case 2: launch_glds_stage<2, NSUB, false>(g, grid, s); break;
+        case 3: launch_glds_stage<3, NSUB, false>(g, grid, s); break;
+        default: launch_glds_stage<4, NSUB, false>(g, grid, s); break;
     }
 }
 
@@ -678,28 +683,37 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
         // (a 128 x 96 tile -- 10.3 instead of 6.2 rounds on the 1-hour stage-3 shape -- was measured at
         //  +2 %, inside run-to-run noise: the 160-wide tile stays)
         // Stream-K-lite: 2 workgroups per CU are resident, so a launch proceeds in rounds of 2*CUs
-        // tiles; when the last round is less than half full and the K loop is long, that remainder is
-        // cut along K so it occupies the whole chip for a fraction of a round instead of a few CUs for a
-        // whole one (1-hour stage-3 shape: 3168 tiles = 6.19 rounds).
+        // tiles; the tiles of the last, partial round are cut along K into `split` slices each, so that
+        // they occupy the whole chip for a fraction of a round instead of part of it for a whole one
+        // (1-hour stage-3 shape: 3168 tiles = 6.19 rounds).  The slices are blocks of the same launch,
+        // dispatched behind the whole tiles; a fix-up kernel adds them in a fixed order.  `split` is
+        // the one that minimises the tail, ceil(rem*split/slots)/split rounds, within the scratch size.
         const int64_t slots = 2 * (int64_t)device_cus();
         const int64_t rem = nb % slots, full = nb - rem;
         const int nk = g.K / BK;
-        int split = rem > 0 ? (int)(slots / rem) : 0;
-        if (split > 8) split = 8;
-        if (split > nk / 4) split = nk / 4;
-        const bool can_split = nbatch == 1 && mode <= 3 && g.splitk_ws && full > 0 && split >= 2 &&
-                               (size_t)rem * split * 128 * 160 * sizeof(float) <= g.splitk_ws_bytes &&
-                               !getenv("TAL_GEMM_NO_SPLITK_TAIL");
-        if (!can_split) {
-            launch_glds<5>(g, mode, grid, s);
+        int split = 0;
+        if (rem > 0 && full > 0 && nbatch == 1 && mode <= 3 && g.splitk_ws && !getenv("TAL_GEMM_NO_SPLITK_TAIL")) {
+            // cost of a candidate in rounds: the slices' own rounds + their scratch traffic (each slice
+            // writes and the fix-up re-reads a 128x160 fp32 tile, ~4 TB/s) relative to one round's duration
+            // (measured: 4.45 us per K step + ~14 us per tile, scripts/bench_gemm_fit.py)
+            const double round_us = 4.45 * nk + 14.0;
+            double best = 0.97;
+            for (int sp = 2; sp <= 8 && sp <= nk / 4; ++sp) {
+                if ((size_t)rem * sp * 128 * 160 * sizeof(float) > g.splitk_ws_bytes) break;
+                const double traffic_us = (double)rem * sp * (2.0 * 128 * 160 * 4) / 4.0e6;
+                const double tail = (double)cdiv(rem * sp, slots) / sp + traffic_us / round_us;
+                if (tail < best) { best = tail; split = sp; }
+            }
+        }
+        if (split < 2) {
+            launch_glds<5>(g, mode, false, grid, s);
         } else {
             GemmArgs h = g;
-            launch_glds<5>(h, mode, dim3((unsigned)full), s);          // whole rounds, normal epilogue
             h.tile_base = (int)full;
             h.split = split;
             h.tail_tiles = (int)rem;
-            launch_glds<5>(h, mode, dim3((unsigned)(rem * split)), s);   // K slices of the remainder -> scratch
-            launch_fixup<5>(h, mode, dim3((unsigned)rem), s);            // ordered sum + epilogue
+            launch_glds<5>(h, mode, true, dim3((unsigned)(full + rem * split)), s);   // whole tiles, then K slices -> scratch
+            launch_fixup<5>(h, mode, dim3((unsigned)rem), s);                         // ordered sum + epilogue
         }
     }
     else

@@ -77,8 +77,14 @@ def linear(x, weight, bias=None, mode=0, res=None, alpha=0.0, out=None):
         res = _f32c(res, "linear(res)")
     if bias is not None:
         bias = _f32c(bias, "linear(bias)")
-    N.check(lib.tal_linear_fwd(N.ptr(x), N.ptr(w2), N.ptr(bias), N.ptr(res), float(alpha), int(mode), M, Nout, K,
-                               N.ptr(y), N.stream_handle()), "tal_linear_fwd")
+    nws = lib.tal_linear_workspace_bytes(M, Nout, K)
+    if nws:
+        ws = _ws(nws, x.device)    # (torch's caching allocator hands the same block back call after call)
+        N.check(lib.tal_linear_ws_fwd(N.ptr(x), N.ptr(w2), N.ptr(bias), N.ptr(res), float(alpha), int(mode), M, Nout, K,
+                                      N.ptr(y), N.ptr(ws), nws, N.stream_handle()), "tal_linear_ws_fwd")
+    else:
+        N.check(lib.tal_linear_fwd(N.ptr(x), N.ptr(w2), N.ptr(bias), N.ptr(res), float(alpha), int(mode), M, Nout, K,
+                                   N.ptr(y), N.stream_handle()), "tal_linear_fwd")
     return y
 
 

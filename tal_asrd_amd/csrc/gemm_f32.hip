@@ -197,6 +197,9 @@ __device__ __forceinline__ unsigned logical_tile() { return logical_tile_of(grid
 // ---------------------------------------------------------------------------------------------
 template <int MODE, int NSUB, bool SPLITK, int STAGE>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
+    // Set-up and epilogue are short VALU / memory sequences; the co-resident workgroup is usually deep in
+    // its MFMA loop, and at equal priority every one of these instructions queues behind a 64-cycle MFMA.
+    __builtin_amdgcn_s_setprio(3);
     constexpr int BM = 128, BN = 32 * NSUB;
     constexpr int ROWS = BM + BN;                 // 288 operand rows of 32 floats (128 B) per K step
     constexpr int CHUNKS = ROWS / 8;              // 36 wave-loads of 1 KB (8 rows) each
@@ -293,6 +296,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
     const int kt0 = is_slice ? (int)((int64_t)slice * nk_all / g.split) : 0;
     const int nk = is_slice ? (int)((int64_t)(slice + 1) * nk_all / g.split) : nk_all;
     issue(kt0, kt0 & 1);
+    __builtin_amdgcn_s_setprio(0);
     for (int kt = kt0; kt < nk; ++kt) {
         // tile kt has landed (vmcnt(0) is part of the barrier while LDS-DMA is in flight) and every
         // wave is done reading the other buffer (it finished step kt-1 before arriving here)
@@ -323,6 +327,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
         }
     }
     __syncthreads();  // all waves done with the operand buffers before they become the store stage
+    __builtin_amdgcn_s_setprio(3);
     if (is_slice) {
         // raw accumulators of this K slice -> scratch tile [(tile, slice)][128][BN]; the fix-up kernel
         // adds the slices in a fixed order and applies bias / activation / residual

@@ -574,21 +574,50 @@ static void launch_splitk4(const GemmArgs& g, int mode, dim3 grid, hipStream_t s
     }
 }
 
-// fix-up of the split-K tail: one workgroup per tail tile, slices added in ascending order
+// fix-up of the split-K tail: FIX_PARTS workgroups per tail tile (32 rows each), slices added in ascending
+// order.  All slice loads of a position are issued before the first add; 16-byte loads and stores.
+constexpr int FIX_PARTS = 4;
 template <int MODE, int NSUB>
 __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(const GemmArgs g) {
-    constexpr int BM = 128, BN = 32 * NSUB;
-    const unsigned logical = (unsigned)g.tile_base + blockIdx.x;
-    const int64_t m0 = (int64_t)(logical / (unsigned)g.tiles_n) * BM;
+    constexpr int BM = 128, BN = 32 * NSUB, RPB = BM / FIX_PARTS, MAXS = 8;
+    const unsigned tile = blockIdx.x / FIX_PARTS, part = blockIdx.x % FIX_PARTS;
+    const unsigned logical = (unsigned)g.tile_base + tile;
+    const int64_t m0 = (int64_t)(logical / (unsigned)g.tiles_n) * BM + part * RPB;
     const int n0 = (int)(logical % (unsigned)g.tiles_n) * BN;
-    const float* base = g.splitk_ws + (size_t)blockIdx.x * g.split * (BM * BN);
-    for (int i = threadIdx.x; i < BM * BN / 4; i += 256) {
+    const float* base = g.splitk_ws + (size_t)tile * g.split * (BM * BN) + part * RPB * BN;
+    const bool vec_ok = (g.ldy % 4 == 0) && (MODE != 2 || g.ldres % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.Y) & 15) == 0) &&
+                        (MODE != 2 || (reinterpret_cast<uintptr_t>(g.res) & 15) == 0) &&
+                        (!g.bias || (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < RPB * BN / 4; i += 256) {
         const int r = i / (BN / 4), c = (i - r * (BN / 4)) * 4;
         const int64_t row = m0 + r;
         const int col = n0 + c;
         if (row >= g.M || col >= g.N) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(base + r * BN + c);
-        for (int q = 1; q < g.split; ++q) v += *reinterpret_cast<const f32x4*>(base + (size_t)q * (BM * BN) + r * BN + c);
+        f32x4 p[MAXS];
+#pragma unroll
+        for (int q = 0; q < MAXS; ++q)
+            p[q] = q < g.split ? *reinterpret_cast<const f32x4*>(base + (size_t)q * (BM * BN) + r * BN + c) : zero4;
+        const bool full = vec_ok && col + 3 < g.N;
+        f32x4 rv = zero4, bv = zero4;
+        if (full) {
+            if (MODE == 2) rv = *reinterpret_cast<const f32x4*>(g.res + row * g.ldres + col);
+            if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
+        }
+        f32x4 v = p[0];
+#pragma unroll
+        for (int q = 1; q < MAXS; ++q)
+            if (q < g.split) v += p[q];
+        if (full) {
+            v += bv;
+            if (MODE == 1) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (MODE == 2) v = rv + g.alpha * v;
+            if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) v = g.alpha * v;
+            *reinterpret_cast<f32x4*>(g.Y + row * g.ldy + col) = v;
+            continue;
+        }
         for (int e = 0; e < 4 && col + e < g.N; ++e) {
             float x = v[e] + (g.bias ? g.bias[col + e] : 0.f);
             if (MODE == 1) x = fmaxf(x, 0.f);
@@ -718,7 +747,7 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
             h.split = split;
             h.tail_tiles = (int)rem;
             launch_glds<5>(h, mode, true, dim3((unsigned)(full + rem * split)), s);   // whole tiles, then K slices -> scratch
-            launch_fixup<5>(h, mode, dim3((unsigned)rem), s);                         // ordered sum + epilogue
+            launch_fixup<5>(h, mode, dim3((unsigned)rem * FIX_PARTS), s);                         // ordered sum + epilogue
         }
     }
     else

@@ -195,11 +195,14 @@ int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, i
     const int cig = C_in / groups, cog = C_out / groups;
     if (cig == 1 && cog == 10 && groups % 16 == 0)
         return launch_spec<1, 10, 2, 16, 128, false>(x, wp, bias, 0.f, y, B, T_in, T_out, C_in, C_out, groups, s);
-    // (4 groups x 128 outputs beats 2 x 256 here: 72 / 54 vs 67 / 46 TFLOP/s on the 1-hour shapes)
+    // Measured on the 1-hour shapes (TFLOP/s): 10->14: 4 groups x 128 outputs 73, 2 x 128 72, 2 x 256 67;
+    // 14->18: 2 x 128 75 (31 KB slab, 5 workgroups / CU), 4 x 128 53 (62 KB, 2 / CU), 2 x 256 46.
+    // (De-interleaving the slab into even / odd time steps, which removes the 2-way bank conflict of the
+    //  stride-2 tap reads, changed nothing: the LDS reads are not the limiter.)
     if (cig == 10 && cog == 14 && groups % 4 == 0)
         return launch_spec<10, 14, 2, 4, 128, false>(x, wp, bias, 0.f, y, B, T_in, T_out, C_in, C_out, groups, s);
-    if (cig == 14 && cog == 18 && groups % 4 == 0)
-        return launch_spec<14, 18, 2, 4, 128, false>(x, wp, bias, 0.f, y, B, T_in, T_out, C_in, C_out, groups, s);
+    if (cig == 14 && cog == 18 && groups % 2 == 0)
+        return launch_spec<14, 18, 2, 2, 128, false>(x, wp, bias, 0.f, y, B, T_in, T_out, C_in, C_out, groups, s);
     return launch_generic<false>(x, wp, bias, 0.f, y, B, T_in, T_out, C_in, C_out, groups, 2, s);
 }
 

@@ -61,6 +61,48 @@ def test_linear_matches_fp64(M, N, K, mode):
     np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), atol=2e-5 * max(1.0, K ** 0.5 / 8), rtol=1e-5)
 
 
+@pytest.mark.parametrize("M,N,K,mode,split", [
+    (70000, 320, 256, 1, True),      # 1094 tiles = 2 whole rounds + 70 tail tiles (cut along K)
+    (100000, 160, 512, 2, False),    # 782 tiles: 270 tail tiles; the cost model declines (scratch traffic > gain)
+    (100000, 160, 1440, 2, True),    # same tiles, long K: 270 tail tiles in 3 slices each
+    (66000, 161, 288, 0, True),      # ragged N, K/32 = 9 K steps
+    (65536 + 128, 160, 256, 3, True),  # a single tail tile
+])
+def test_linear_split_k_tail_matches_fp64_and_is_deterministic(M, N, K, mode, split):
+    """The scratch-enabled dense layer (tal_linear_ws_fwd): tiles of the last partial round are summed from K
+    slices by the fix-up kernel -- same tolerance as the plain path, bitwise repeatable, and identical to the
+    plain path on every row that is not in a tail tile."""
+    import ctypes as C
+    from tal_asrd_amd import ops, _native as N_
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev())
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev())
+    b = torch.randn(N, generator=g).to(dev())
+    res = torch.randn(M, N, generator=g).to(dev())
+    lib = N_.lib()
+    assert lib.tal_linear_workspace_bytes(M, N, K) > 0
+    y1 = ops.linear(x, w, b, mode=mode, res=res if mode == 2 else None, alpha=0.3)
+    y2 = ops.linear(x, w, b, mode=mode, res=res if mode == 2 else None, alpha=0.3)
+    assert torch.equal(y1, y2)
+    plain = torch.empty_like(y1)
+    N_.check(lib.tal_linear_fwd(N_.ptr(x), N_.ptr(w), N_.ptr(b), N_.ptr(res if mode == 2 else None), 0.3, mode, M, N, K,
+                                N_.ptr(plain), N_.stream_handle()), "tal_linear_fwd")
+    torch.cuda.synchronize()
+    ref = x.double() @ w.double().t() + b.double()
+    if mode == 1:
+        ref = ref.clamp_min(0)
+    if mode == 2:
+        ref = res.double() + 0.3 * ref
+    if mode == 3:
+        ref = 0.3 * ref
+    tol = 2e-5 * max(1.0, K ** 0.5 / 8)
+    assert float((y1.double() - ref).abs().max()) < tol
+    assert float((plain.double() - ref).abs().max()) < tol
+    same_rows = (y1 == plain).all(dim=1)
+    assert int(same_rows.sum()) >= 65536 - 128          # the whole-round tiles are untouched by the split
+    assert bool(same_rows.all()) != split               # ...and the tail went through the K slices iff expected
+
+
 def test_linear_identity_asymmetric():
     """A = I against an asymmetric W catches a transposed C write."""
     from tal_asrd_amd import ops

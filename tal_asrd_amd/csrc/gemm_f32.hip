@@ -94,6 +94,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
         float* stage = lds + w * (16 * CW);
         const int n_base = n0 + wn * CW;
         const bool cols_full = n_base + CW <= N;  // wave-uniform
+        // descriptors of this wave's 16 x CW windows (one per half) of Y / res, extent = the rows inside M (the
+        // row offset of a half must not travel in the scalar offset: it is not part of the range check),
+        // and of its bias slice
+        const bool buf_ok = g.ldy < (1 << 21) && (MODE != 2 || g.ldres < (1 << 21));
+        auto uptr = [](const float* p) {
+            const uint64_t v = reinterpret_cast<uint64_t>(p);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+            return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+        };
+        __amdgpu_buffer_rsrc_t rs_y[2], rs_res[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int64_t row0 = m0 + wm * 32 + half * 16;
+            const int rows_valid = (int)(M - row0 < 0 ? 0 : (M - row0 > 16 ? 16 : M - row0));
+            const int ext_y = rows_valid > 0 ? (int)(((rows_valid - 1) * g.ldy + CW) * 4) : 0;
+            const int ext_r = rows_valid > 0 && MODE == 2 ? (int)(((rows_valid - 1) * g.ldres + CW) * 4) : 0;
+            rs_y[half] = __builtin_amdgcn_make_buffer_rsrc(uptr(Y + row0 * g.ldy + n_base), 0, __builtin_amdgcn_readfirstlane(ext_y), 0x00020000);
+            rs_res[half] = __builtin_amdgcn_make_buffer_rsrc(uptr(MODE == 2 ? res + row0 * g.ldres + n_base : Y), 0,
+                                                             __builtin_amdgcn_readfirstlane(ext_r), 0x00020000);
+        }
+        __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(uptr(bias ? bias + n_base : Y), 0, CW * 4, 0x00020000);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -104,23 +125,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                     const int r = rowb + (e8 & 3) + 8 * (e8 >> 2);  // 0..15 inside this half
                     stage[r * CW + j * 32 + colb] = acc[j][e];
                 }
-            if (cols_full) {
-                // Interior fast path: loads first (clamped rows, no branch in front of a load, so
-                // they overlap instead of costing one round trip each); only stores are predicated.
+            if (cols_full && buf_ok) {
+                // Interior fast path.  Output, residual and bias go through buffer descriptors (SGPRs) whose
+                // extent is exactly this wave's valid rows: rows past M need no clamp and no predicate (loads
+                // return 0, stores are dropped), addresses are 32-bit lane offsets + a scalar row offset, and
+                // the buffer form is the cheap one to issue.  All loads are issued before any is consumed.
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                int r = lane / (CW / 4), c4 = lane - r * (CW / 4);
+                int offy[2 * NSUB], offr[2 * NSUB], offb[2 * NSUB], ldsv[2 * NSUB];
                 f32x4 rv[2 * NSUB], bv[2 * NSUB];
-                int64_t rowv[2 * NSUB];
-                int colv[2 * NSUB], ldsv[2 * NSUB];
 #pragma unroll
                 for (int t = 0; t < 2 * NSUB; ++t) {
-                    const int i = lane + 64 * t;
-                    const int r = i / (CW / 4);
-                    const int c = (i - r * (CW / 4)) * 4;
-                    rowv[t] = m0 + wm * 32 + half * 16 + r;
-                    colv[t] = n_base + c;
-                    ldsv[t] = r * CW + c;
-                    const int64_t rc = rowv[t] < M ? rowv[t] : M - 1;
-                    if (MODE == 2) rv[t] = *reinterpret_cast<const f32x4*>(res + rc * g.ldres + colv[t]);
-                    bv[t] = bias ? *reinterpret_cast<const f32x4*>(bias + colv[t]) : zero4;
+                    offy[t] = (r * (int)g.ldy + c4 * 4) * 4;
+                    offr[t] = (r * (int)g.ldres + c4 * 4) * 4;
+                    offb[t] = c4 * 16;
+                    ldsv[t] = r * CW + c4 * 4;
+                    c4 += 64 - CW / 4;          // lane + 64 (t + 1) = (r + 1) * 40 + c4 + 24
+                    r += 1;
+                    if (c4 >= CW / 4) {
+                        c4 -= CW / 4;
+                        r += 1;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 2 * NSUB; ++t) {
+                    if (MODE == 2) rv[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res[half], offr[t], 0, 0));
+                    bv[t] = bias ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, offb[t], 0, 0)) : zero4;
                 }
 #pragma unroll
                 for (int t = 0; t < 2 * NSUB; ++t) {
@@ -129,8 +159,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
                     if (MODE == 2) v = rv[t] + alpha * v;
-                    if (MODE == 3 && (g.scale_cols == 0 || colv[t] < g.scale_cols)) v = alpha * v;
-                    if (rowv[t] < M) *reinterpret_cast<f32x4*>(Y + rowv[t] * g.ldy + colv[t]) = v;
+                    if (MODE == 3 && (g.scale_cols == 0 || n_base + (offb[t] >> 2) < g.scale_cols)) v = alpha * v;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y[half], offy[t], 0, 0);
                 }
                 continue;
             }

@@ -103,6 +103,34 @@ def test_linear_split_k_tail_matches_fp64_and_is_deterministic(M, N, K, mode, sp
     assert bool(same_rows.all()) != split               # ...and the tail went through the K slices iff expected
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(513 + 23, 160, 64, 0), (66000 + 55, 320, 256, 2), (1000 + 17, 800, 800, 1),
+                                        (640 + 9, 1440, 1440, 2), (44983, 160, 256, 3)])
+def test_linear_never_writes_past_the_last_row(M, N, K, mode):
+    """Ragged M: the epilogue's buffer descriptors end at row M-1; the rows behind y (and behind the residual)
+    must stay untouched, for whole tiles, tail tiles and the split-K fix-up alike."""
+    from tal_asrd_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(dev())
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev())
+    b = torch.randn(N, generator=g).to(dev())
+    guard = 7
+    yfull = torch.full((M + guard, N), 12345.0, device=dev())
+    resfull = torch.full((M + guard, N), float("nan"), device=dev())
+    resfull[:M] = torch.randn(M, N, generator=g).to(dev())
+    y = ops.linear(x, w, b, mode=mode, res=resfull[:M] if mode == 2 else None, alpha=0.3, out=yfull[:M])
+    torch.cuda.synchronize()
+    assert bool((yfull[M:] == 12345.0).all())
+    assert bool(torch.isfinite(y).all())
+    ref = x.double() @ w.double().t() + b.double()
+    if mode == 1:
+        ref = ref.clamp_min(0)
+    if mode == 2:
+        ref = resfull[:M].double() + 0.3 * ref
+    if mode == 3:
+        ref = 0.3 * ref
+    assert float((y.double() - ref).abs().max()) < 2e-5 * max(1.0, K ** 0.5 / 8)
+
+
 def test_linear_identity_asymmetric():
     """A = I against an asymmetric W catches a transposed C write."""
     from tal_asrd_amd import ops

@@ -11,18 +11,25 @@
 // reduced-precision trick.  Roofline: 157.3 TFLOP/s (fp32 matrix peak of MI355X; a pure-MFMA
 // loop reaches 155 on this chip, scripts/ubench/mfma_peak.hip).
 //
-// Three kernels, all 4 waves x (32 rows x 32*NSUB columns) of 32x32 accumulators:
+// Kernels, all 4 waves x (32 rows x 32*NSUB columns) of 32x32 accumulators:
 //   gemm_glds_kernel    128(M) x 160(N) x 32(K), the hot one (M > 512, K % 32 == 0).  Operand
-//       tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write),
-//       double-buffered, ONE barrier per K step; the LDS image is lane-linear, so bank conflicts
-//       are removed by an XOR swizzle applied to the per-lane SOURCE address and again on the
-//       fragment read.  160 divides every TDS width (800/1120/1440): no N-tail waste.
-//   gemm_nt_f32_kernel<.,4,5>  same tile, register-staged, single LDS buffer: K tails
-//       (K % 32 != 0; only small test models).
-//   gemm_nt_f32_kernel<.,1,1>  32(M) x 128(N): the decoder's short problems (M <= 512 rows).
-// Epilogue (shared): the wave's tile is staged through LDS 16 rows at a time and written as
-// whole rows with 16-byte stores; bias / ReLU / ReZero-residual / scale are fused; all bias and
-// residual loads of a half tile are issued before any of them is consumed.
+//       tiles go HBM/L2 -> LDS directly (LDS-DMA `buffer_load_dwordx4 ... lds`: SGPR descriptor,
+//       32-bit lane offset, no VGPR staging, no ds_write), double-buffered, ONE barrier per K step;
+//       the LDS image is lane-linear, so bank conflicts are removed by an XOR swizzle applied to the
+//       per-lane SOURCE offset and again on the fragment read.  160 divides every TDS width
+//       (800/1120/1440): no N-tail waste.  The tiles of the last partial scheduling round can be cut
+//       along K (SPLITK launches + gemm_splitk_fixup_kernel) when the caller provides scratch.
+//   gemm_splitk4_kernel 32 x 32 tile, 4 waves split K inside the workgroup: the decoder's short,
+//       latency-bound problems (M <= 512 rows).
+//   gemm_nt_f32_kernel<.,4,5>  128 x 160, register-staged, single LDS buffer: K tails
+//       (K % 32 != 0; only small test models);  <.,1,1>  32 x 128: small M with mode 4 / odd shapes.
+// Epilogue (shared): the wave's tile is staged through LDS 16 rows at a time and written as whole
+// rows with 16-byte buffer stores whose descriptor ends at the last valid row; bias / ReLU /
+// ReZero-residual / scale are fused; all bias and residual loads of a half tile are issued before
+// any of them is consumed.
+// Cost model (measured): the matrix pipe and the vector ALU of a SIMD do not
+// overlap, so every VALU / vector-memory instruction here is matrix time lost -- hence SGPR
+// descriptors, 32-bit offsets and scalar address arithmetic wherever possible.
 #include "common.h"
 
 namespace tal {

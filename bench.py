@@ -60,6 +60,26 @@ def build_model(dev):
     return model.to(dev), sd
 
 
+def dense_layer_algorithmic_bytes(frames):
+    """Algorithmic HBM bytes of the dense-layer launches of one SD-path step over `frames` mel frames, summed
+    and per launch: every launch reads its activations (+ the residual for the second pointwise layer of a
+    TDSBlock) and its weights once and writes its output once.  (For comparison with roofline.traffic.)"""
+    def f(t):
+        return (t - 21) // 2 + 1
+    t1 = f(frames); t2 = f(t1); t3 = f(t2)
+    total = 0.0
+    launches = 0
+    for t, c, depth in ((t1, 800, 2), (t2, 1120, 3), (t3, 1440, 6)):
+        act = 4.0 * t * c
+        w = 4.0 * c * c
+        total += depth * ((act + w + act) + (act + w + act + act))      # relu layer; residual layer
+        launches += 2 * depth
+    total += 4.0 * (t3 * 1440 + 128 * 1440 + t3 * 128)                   # 1440 -> 128 features
+    total += 4.0 * (t3 * 128 + 6008 * 128) + 8.0 * t3 * 38                # 128 -> 6008 logits, arg-max partials only
+    launches += 2
+    return total, launches
+
+
 def cpu_baseline(sd, seconds):
     """The oracle (CPU restatement of the reference's PyTorch-CPU path) on a bounded sample."""
     from oracle import tal_oracle as O
@@ -229,7 +249,8 @@ def main():
                                 "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
                                 "avg_launch_ms": gm["ms_total"] / max(gm["launches"], 1),
                                 "launches": gm["launches"],
-                                "algorithmic_flops_per_launch": gm["work"] / max(gm["launches"], 1)}
+                                "algorithmic_flops_per_launch": gm["work"] / max(gm["launches"], 1),
+                                "algorithmic_bytes_per_launch": (lambda tb: tb[0] / tb[1])(dense_layer_algorithmic_bytes(frames))}
             tot = sum(k["ms_total"] for k in kern.values())
             line["kernel_time_share"] = {k: (v["ms_total"] / tot if tot else 0.0) for k, v in kern.items()}
             line["kernel_ms_per_step"] = {k: v["ms_total"] / args.steps for k, v in kern.items()}

@@ -330,6 +330,18 @@ extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_
         return TAL_ENOMEM;
     }
     if (M == 0) return TAL_OK;
+    if (b_logit && head_argmax_applicable(M, S, E)) {
+        // long inputs: feature strip stationary in registers, running arg-max across N tiles (csrc/head.hip)
+        const int P = head_argmax_partials();
+        float* pv = reinterpret_cast<float*>(workspace);
+        int32_t* pi = reinterpret_cast<int32_t*>(pv + (size_t)M * P);
+        rc = launch_head_argmax(feat, w_logit, b_logit, M, S, pv, pi, s);
+        if (rc) return rc;
+        ProfScope prof(PROF_OTHER, (double)M * P * 8.0, s);
+        hipLaunchKernelGGL(argmax_partials_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, pv, pi, M, P, P, ids);
+        TAL_CHECK_LAUNCH("tal_sd_head_fwd(argmax)");
+        return TAL_OK;
+    }
     // logits are never materialised: the dense layer's epilogue reduces each row of its tile to a
     // (max, arg-max) pair, a tiny second kernel merges the pairs of a row's column tiles
     const int ld = (int)cdiv(S, 32);

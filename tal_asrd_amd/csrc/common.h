@@ -90,5 +90,10 @@ int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, i
 int launch_gconv_res(const float* x, const float* wp, const float* bias, float alpha, int B, int64_t T, int C,
                      int groups, float* y, hipStream_t s);
 int launch_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, hipStream_t s);
+// A-stationary speaker-logit arg-max (csrc/head.hip): partials [M, head_argmax_partials()] for argmax_partials_kernel
+bool head_argmax_applicable(int64_t M, int S, int E);
+int head_argmax_partials();
+int launch_head_argmax(const float* feat, const float* w, const float* b, int64_t M, int S, float* part_val,
+                       int32_t* part_idx, hipStream_t s);
 
 }  // namespace tal

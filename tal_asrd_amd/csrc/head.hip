@@ -1,0 +1,209 @@
+// Speaker-logit arg-max of the diarization head without the logits:
+//   ids[r] = argmax_s ( feat[r, :] . W[s, :] + b[s] ),  feat [M, 128], W [S, 128]   (S = 6008)
+// SDModel.decode's spk_logit_proj followed by the arg-max of tal/baseline/reconcile.py:84.
+//
+// The generic dense-layer kernel spends more time around this GEMM's 4 K steps per 128x160 tile than in
+// them (set-up, arg-max epilogue and partial stores per tile: 13,376 tiles per hour of audio).  Here the
+// [128 x 128] feature strip of a workgroup is A-STATIONARY IN REGISTERS (each wave keeps its 32 x 128 strip as
+// 16 MFMA-ready fragments, 64 VGPRs), only W streams through LDS (LDS-DMA, double-buffered 128 x 32 chunks,
+// one barrier per chunk), and the arg-max is a running (value, column) pair per accumulator element that
+// stays in registers across N tiles -- no cross-lane work and no memory traffic until a row block is done.
+// Work is cut into 2 x CUs equal runs of consecutive (row block, N tile) units, so a row block's 47 N tiles
+// are covered by at most 3 workgroups (N tile = 128 columns: 6008 = 46 x 128 + 120), each leaving one (value, column) partial per row; the existing
+// argmax_partials_kernel merges them in ascending column order (strict '>': lowest index wins ties, as
+// torch.argmax does).
+#include "common.h"
+
+namespace tal {
+
+namespace {
+
+constexpr int HK = 128;            // feature width (K)
+constexpr int HBM = 128, HBN = 128, HNSUB = 4;
+constexpr int HP = 3;              // partial slots per row
+
+__device__ __forceinline__ void* uniform_ptr(const void* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(256, 2) void head_argmax_kernel(const float* __restrict__ feat, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, int64_t M, int S, int NT,
+                                                            int64_t U, float* __restrict__ part_val,
+                                                            int32_t* __restrict__ part_idx) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * HBN * 32];   // 40,960 B
+    const int64_t G = gridDim.x;
+    const int64_t u0 = (int64_t)blockIdx.x * U / G, u1 = ((int64_t)blockIdx.x + 1) * U / G;
+    if (u0 >= u1) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
+    const int frow = lane & 31, fsw = frow & 7, fhalf = lane >> 5;
+    const int sub = lane >> 3, srccol = ((lane & 7) ^ sub) * 4;
+
+    // W: one descriptor over the whole matrix; rows past S read as 0 (their columns are masked below)
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(W), 0, S * HK * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(bias), 0, S * 4, 0x00020000);
+    int wrow[HNSUB];      // byte offset of this lane's source row / 16-byte column inside an N tile
+#pragma unroll
+    for (int t = 0; t < HNSUB; ++t) wrow[t] = ((8 * (w + 4 * t) + sub) * HK + srccol) * 4;
+    // chunk (n, kt): W rows [160 n, 160 n + 160), k in [32 kt, 32 kt + 32) -> LDS buffer `buf` (same image as
+    // the dense-layer kernel's W part: chunk i = w + 4t holds 8 rows x 128 B, XOR-swizzled on the source side)
+    auto issue = [&](int n, int kt, int buf) {
+        const int nbase = n * (HBN * HK * 4);      // row offset goes into the lane offset: it is range-checked
+#pragma unroll
+        for (int t = 0; t < HNSUB; ++t) {
+            float* dst = lds + buf * (HBN * 32) + (w + 4 * t) * 256;
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)dst, 16, wrow[t] + nbase,
+                                                     kt * 128, 0, 0);
+#endif
+        }
+    };
+
+    f32x4 a[HK / 8];                 // this wave's 32 x 128 strip: a[kk] = A[row, 8 kk + 4 (lane >> 5) .. + 3]
+    float best[16];
+    int bidx[16];
+    f32x16 acc[HNSUB];
+#pragma unroll
+    for (int j = 0; j < HNSUB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    auto block_of = [&](int64_t u) {          // workgroup whose run contains unit u
+        int64_t b = u * G / U;
+        while ((b + 1) * U / G <= u) ++b;
+        while (b * U / G > u) --b;
+        return b;
+    };
+
+    issue((int)(u0 % NT), 0, 0);
+    for (int64_t u = u0; u < u1; ++u) {
+        const int64_t m = u / NT;
+        const int n = (int)(u - m * NT);
+        const int64_t row0 = m * HBM + w * 32;
+        if (u == u0 || n == 0) {
+            int64_t r = row0 + frow;
+            r = r < M ? r : M - 1;
+            const float* ap = feat + r * HK + 4 * fhalf;
+#pragma unroll
+            for (int kk = 0; kk < HK / 8; ++kk) a[kk] = *reinterpret_cast<const f32x4*>(ap + 8 * kk);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                best[e] = -INFINITY;
+                bidx[e] = 0x7fffffff;
+            }
+        }
+        float bv[HNSUB];
+#pragma unroll
+        for (int j = 0; j < HNSUB; ++j) bv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, (n * HBN + j * 32 + frow) * 4, 0, 0));
+#pragma unroll
+        for (int kt = 0; kt < HK / 32; ++kt) {
+            const int buf = kt & 1;
+            __syncthreads();      // chunk (n, kt) has landed; everyone is done with the other buffer
+            if (kt + 1 < HK / 32)
+                issue(n, kt + 1, buf ^ 1);
+            else if (u + 1 < u1)
+                issue((int)((u + 1) % NT), 0, buf ^ 1);
+            const float* Bs = lds + buf * (HBN * 32) + frow * 32;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int sl = ((2 * k4 + fhalf) ^ fsw) * 4;
+                f32x4 fb[HNSUB];
+#pragma unroll
+                for (int j = 0; j < HNSUB; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * 32 + sl);
+                const f32x4 fa = a[kt * 4 + k4];
+#pragma unroll
+                for (int j = 0; j < HNSUB; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[j].x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[j].y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[j].z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[j].w, acc[j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting every slice's fragment reads)
+            }
+        }
+        // running arg-max: a lane owns column n*160 + 32 j + (lane & 31) of 16 rows; columns arrive in ascending order
+#pragma unroll
+        for (int j = 0; j < HNSUB; ++j) {
+            const int col = n * HBN + j * 32 + frow;
+            const bool ok = col < S;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = acc[j][e] + bv[j];
+                if (ok && v > best[e]) {
+                    best[e] = v;
+                    bidx[e] = col;
+                }
+                acc[j][e] = 0.f;
+            }
+        }
+        if (n == NT - 1 || u == u1 - 1) {
+            // this workgroup's share of row block m is complete: reduce over the 32 columns-lanes of each half wave
+            const int64_t bf = block_of(m * NT), bl = block_of(m * NT + NT - 1);
+            const int slot = (int)((int64_t)blockIdx.x - bf);
+            const int nslots = (int)(bl - bf + 1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float bvv = best[e];
+                int bi = bidx[e];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) {
+                    const float ov = __shfl_xor(bvv, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (ov > bvv || (ov == bvv && oi < bi)) {
+                        bvv = ov;
+                        bi = oi;
+                    }
+                }
+                const int64_t row = row0 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+                if (frow == 0 && row < M) {
+                    part_val[row * HP + slot] = bvv;
+                    part_idx[row * HP + slot] = bi;
+                    if (slot == 0)
+                        for (int sfill = nslots; sfill < HP; ++sfill) {
+                            part_val[row * HP + sfill] = -INFINITY;
+                            part_idx[row * HP + sfill] = 0x7fffffff;
+                        }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// true when the shape is one this kernel is meant for (the caller falls back to the generic fused path otherwise)
+bool head_argmax_applicable(int64_t M, int S, int E) {
+    if (E != HK || S < HBN) return false;
+    const int64_t units = cdiv(M, HBM) * cdiv(S, HBN);
+    int cus = 256;
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+        cus = p.multiProcessorCount;
+    // every workgroup needs a run of at least half a row block's N tiles, so that a row block spans <= HP workgroups
+    return units >= (int64_t)2 * cus * ((cdiv(S, HBN) + 1) / 2) && !getenv("TAL_HEAD_NO_ASTATIONARY");
+}
+
+int head_argmax_partials() { return HP; }
+
+int launch_head_argmax(const float* feat, const float* w, const float* b, int64_t M, int S, float* part_val,
+                       int32_t* part_idx, hipStream_t s) {
+    TAL_CHECK_ARG(feat && w && b && part_val && part_idx, "head_argmax: null pointer");
+    TAL_CHECK_ARG(((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(w)) & 15) == 0, "head_argmax: operands must be 16-byte aligned");
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+                  ? p.multiProcessorCount : 256;
+    }
+    const int NT = (int)cdiv(S, HBN);
+    const int64_t U = cdiv(M, HBM) * NT;
+    ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)S * HK, s);
+    hipLaunchKernelGGL(head_argmax_kernel, dim3((unsigned)(2 * cus)), dim3(256), 0, s, feat, w, b, M, S, NT, U, part_val, part_idx);
+    TAL_CHECK_LAUNCH("head_argmax");
+    return TAL_OK;
+}
+
+}  // namespace tal

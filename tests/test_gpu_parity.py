@@ -278,6 +278,36 @@ def test_speaker_ids_fused_path(sd_model):
     assert (ids.cpu().numpy() != g["ids"]).sum() == 0
 
 
+@pytest.mark.parametrize("M,S", [(33000, 6008), (32768 + 1, 6008), (70001, 1000)])
+def test_long_input_argmax_head_matches_logits_argmax(M, S):
+    """The A-stationary arg-max kernel (long inputs, 128-d features): same ids as arg-max over materialised
+    logits, ragged last row block and last column tile, and the LOWEST index on exact ties (two identical
+    speaker rows made the winners of a band of rows), as torch.argmax does."""
+    from tal_asrd_amd import ops
+    g = torch.Generator().manual_seed(M + S)
+    x = torch.randn(M, 64, generator=g)
+    we = torch.randn(128, 64, generator=g) / 8
+    be = torch.randn(128, generator=g)
+    wl = torch.randn(S, 128, generator=g) / 11
+    bl = torch.randn(S, generator=g)
+    lo, hi = 37, S - 5                       # a tie between a column of the first tile and one of the last
+    wl[hi] = wl[lo]
+    bl[lo] = bl[hi] = 50.0                   # large bias: the two tie for the maximum of every row
+    d = dev()
+    feat, logits, ids_ref = ops.sd_head(x.to(d), we.to(d), be.to(d), wl.to(d), bl.to(d), want_logits=True, want_ids=True)
+    feat2, _, ids = ops.sd_head(x.to(d), we.to(d), be.to(d), wl.to(d), bl.to(d), want_logits=False, want_ids=True)
+    torch.cuda.synchronize()
+    assert torch.equal(feat, feat2)
+    assert torch.equal(ids, ids_ref)
+    assert torch.equal(ids.long().cpu(), logits.argmax(-1).cpu())
+    assert bool((ids == lo).all())
+    # without the planted winners: ordinary data
+    bl[lo] = bl[hi] = 0.0
+    _, logits, ids_ref = ops.sd_head(x.to(d), we.to(d), be.to(d), wl.to(d), bl.to(d), want_logits=True, want_ids=True)
+    _, _, ids = ops.sd_head(x.to(d), we.to(d), be.to(d), wl.to(d), bl.to(d), want_logits=False, want_ids=True)
+    assert torch.equal(ids.long().cpu(), logits.argmax(-1).cpu())
+
+
 def test_asr_encode_golden(asr_model):
     from tal_asrd_amd import synth
     g = golden("asr_enc_b2")

@@ -516,9 +516,14 @@ static void launch_tile(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
 // length of the dependent chain inside a launch (here: one memory round trip + K/8 MFMAs), and
 // how many CUs share the weight stream ((M/32) x (N/32) workgroups instead of (M/32) x (N/128)).
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256) void gemm_splitk4_kernel(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float part[4 * 32 * 32];
+template <int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_splitk4_kernel(const GemmArgs g) {
+    // per wave: a [32 rows x 64 k] slab of each operand (272-byte row pitch: conflict-free for the 16-byte
+    // row-major writes and for the fragment reads alike); the partial tiles reuse the front of it
+    constexpr int PITCH = 68;                      // floats
+    constexpr int SLAB = 32 * PITCH;
+    __shared__ __attribute__((aligned(16))) float smem[NW * 2 * SLAB];
+    float* part = smem;
     const int tiles_n = g.tiles_n;
     const int64_t m0 = (int64_t)(blockIdx.x / (unsigned)tiles_n) * 32;
     const int n0 = (int)(blockIdx.x % (unsigned)tiles_n) * 32;
@@ -533,52 +538,69 @@ __global__ __launch_bounds__(256) void gemm_splitk4_kernel(const GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
     const int r32 = lane & 31, kh = lane >> 5;
-    const int64_t arow = (m0 + r32 < M) ? m0 + r32 : M - 1;
-    const int wrow = (n0 + r32 < N) ? n0 + r32 : N - 1;
-    const float* ap = A + arow * g.lda + 4 * kh;
-    const float* wp = W + (int64_t)wrow * g.ldw + 4 * kh;
+    // Loads: one instruction covers 4 rows x 256 contiguous bytes (lane -> row 4j + (lane >> 4), 16-byte column
+    // lane & 15), i.e. 8 cache lines.  (Loading the MFMA fragments directly -- lane -> row lane & 31, 16 bytes --
+    // touches 32 lines for 32 useful bytes each, and the CU's line-request rate, not latency, then sets the
+    // kernel's duration: 7 us + 6.8 us per 1024 of K, scripts/bench_small_gemm.py.)
+    const int lrow = lane >> 4, lcol = (lane & 15) * 4;
+    const float* aptr[8];
+    const float* wptr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t ar = m0 + 4 * j + lrow;
+        const int wr = n0 + 4 * j + lrow;
+        aptr[j] = A + (ar < M ? ar : M - 1) * g.lda + lcol;
+        wptr[j] = W + (int64_t)(wr < N ? wr : N - 1) * g.ldw + lcol;
+    }
+    float* As = smem + w * (2 * SLAB);
+    float* Ws = As + SLAB;
 
     const int steps = (K + 7) / 8;                 // one step = 8 consecutive k (two 16-byte halves)
-    const int per = (steps + 3) / 4;
+    const int per = (steps + NW - 1) / NW;
     const int s0 = w * per;
     const int s1 = (s0 + per < steps) ? s0 + per : steps;
+    const int kend = s1 * 8 < K ? s1 * 8 : K;      // this wave's K range is [8 s0, kend)
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int UN = 8;                          // loads in flight per operand
+    constexpr int UN = 8;                          // steps per batch = 64 k = one slab row
     for (int sb = s0; sb < s1; sb += UN) {
-        f32x4 fa[UN], fb[UN];
-        // all loads of the batch first (clamped, always valid addresses; no select in between, so
-        // they are in flight together), then the zero-select for K tails and the MFMAs
+        const int k0 = sb * 8 + lcol;
+        const bool in = k0 < kend;                 // K % 4 == 0: a 16-byte column is in or out as a whole
+        const int kc = in ? k0 - lcol : 0;         // (clamped, always valid address; zero-filled below)
+        f32x4 la[8], lw[8];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int k = (sb + u) * 8;
-            const bool in = (sb + u) < s1 && k + 4 * kh < K;
-            const int kc = in ? k : 0;
-            fa[u] = *reinterpret_cast<const f32x4*>(ap + kc);
-            fb[u] = *reinterpret_cast<const f32x4*>(wp + kc);
+        for (int j = 0; j < 8; ++j) {
+            la[j] = *reinterpret_cast<const f32x4*>(aptr[j] + kc);
+            lw[j] = *reinterpret_cast<const f32x4*>(wptr[j] + kc);
         }
 #pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            *reinterpret_cast<f32x4*>(As + (4 * j + lrow) * PITCH + lcol) = in ? la[j] : zero4;
+            *reinterpret_cast<f32x4*>(Ws + (4 * j + lrow) * PITCH + lcol) = in ? lw[j] : zero4;
+        }
+        // (each wave reads back only what it wrote: LDS operations of one wave are processed in order)
+#pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int k = (sb + u) * 8;
-            const bool in = (sb + u) < s1 && k + 4 * kh < K;
-            const f32x4 a = in ? fa[u] : zero4;
-            const f32x4 b = in ? fb[u] : zero4;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(As + r32 * PITCH + 8 * u + 4 * kh);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(Ws + r32 * PITCH + 8 * u + 4 * kh);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
         }
     }
+    __syncthreads();                               // every wave is done with its slabs before they become `part`
     // partial tiles -> LDS as [wave][row][col]; C/D layout: col = lane & 31, row = (e&3)+8*(e>>2)+4*(lane>>5)
 #pragma unroll
     for (int e = 0; e < 16; ++e) part[w * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * kh) * 32 + r32] = acc[e];
     __syncthreads();
+    if (tid >= 256) return;                        // the first four waves add the partial tiles and write
     const int row = tid >> 3, c = (tid & 7) * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(&part[row * 32 + c]);
 #pragma unroll
-    for (int q = 1; q < 4; ++q) v += *reinterpret_cast<const f32x4*>(&part[q * 1024 + row * 32 + c]);  // waves 0,1,2,3 in order
+    for (int q = 1; q < NW; ++q) v += *reinterpret_cast<const f32x4*>(&part[q * 1024 + row * 32 + c]);  // waves 0..NW-1 in order
     const int64_t gr = m0 + row;
     const int gc = n0 + c;
     if (gr >= M || gc >= N) return;
@@ -603,11 +625,12 @@ __global__ __launch_bounds__(256) void gemm_splitk4_kernel(const GemmArgs g) {
 }
 
 static void launch_splitk4(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) {
+    // (8 waves splitting K were measured for the decoder's K = 2048 layer: 15.6 vs 16.4 us, not worth a variant)
     switch (mode) {
-        case 0: hipLaunchKernelGGL(gemm_splitk4_kernel<0>, grid, dim3(256), 0, s, g); break;
-        case 1: hipLaunchKernelGGL(gemm_splitk4_kernel<1>, grid, dim3(256), 0, s, g); break;
-        case 2: hipLaunchKernelGGL(gemm_splitk4_kernel<2>, grid, dim3(256), 0, s, g); break;
-        default: hipLaunchKernelGGL(gemm_splitk4_kernel<3>, grid, dim3(256), 0, s, g); break;
+        case 0: hipLaunchKernelGGL((gemm_splitk4_kernel<0, 4>), grid, dim3(256), 0, s, g); break;
+        case 1: hipLaunchKernelGGL((gemm_splitk4_kernel<1, 4>), grid, dim3(256), 0, s, g); break;
+        case 2: hipLaunchKernelGGL((gemm_splitk4_kernel<2, 4>), grid, dim3(256), 0, s, g); break;
+        default: hipLaunchKernelGGL((gemm_splitk4_kernel<3, 4>), grid, dim3(256), 0, s, g); break;
     }
 }
 

@@ -222,6 +222,13 @@ int tal_lm_head_fwd(const float* h, int64_t M, int64_t ldh, int D, const float* 
 int tal_transpose_fwd(const float* x, int R, int Cc, float* y, void* stream);
 /* Row-wise log_softmax of [M, N] (system.py:125,366), out may alias x. */
 int tal_log_softmax_rows(const float* x, int64_t M, int N, float* out, void* stream);
+/* Greedy step epilogue of System.generate_unaligned (tal/asr/system.py:355-411) in one launch and one result
+ * buffer: out[0] = argmax(log_softmax(logits [V])) as int32 bits (lowest index on ties), out[1..S] = the new
+ * token's cross-attention row averaged over the n_layers rows attn_rows + l * layer_stride (floats), summed in
+ * layer order.  One D2H copy of 1 + S floats then carries everything the host loop steers by.  token_out
+ * (may be NULL) also receives the token as int64, e.g. the next slot of a device-resident prefix. */
+int tal_greedy_pick_fwd(const float* logits, int V, const float* attn_rows, int n_layers,
+                        int64_t layer_stride, int S, float* out, int64_t* token_out, void* stream);
 /* Beam-search candidate selection of System.generate (system.py:141-160): per batch item the
  * top-k of (logprobs[row, v] + row_score[row]) over its cur_beam rows x V tokens, rows with
  * row_done != 0 masked to -inf.  logprobs [B*cur_beam, V]; row_score / row_done [B*cur_beam]

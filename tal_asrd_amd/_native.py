@@ -68,6 +68,7 @@ SIGNATURES = {
     "tal_decoder_stack_fwd": (_i, [_p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "tal_lm_head_fwd": (_i, [_p, _i64, _i64, _i, _p, _i, _p, _i, _p, _p, _sz, _p]),
     "tal_transpose_fwd": (_i, [_p, _i, _i, _p, _p]),
+    "tal_greedy_pick_fwd": (_i, [_p, _i, _p, _i, _i64, _i, _p, _p, _p]),
     "tal_log_softmax_rows": (_i, [_p, _i64, _i, _p, _p]),
     "tal_beam_topk": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "tal_attn_pool_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p]),

@@ -190,6 +190,72 @@ __global__ __launch_bounds__(256) void log_softmax_row_block_kernel(const float*
     for (int i = threadIdx.x; i < N; i += 256) orow[i] = (xr[i] - m) - lse;
 }
 
+// Greedy step epilogue in one launch and one result buffer: token = argmax(log_softmax(logits)) with exactly the
+// arithmetic (and summation order) of log_softmax_row_block_kernel + argmax_row_block_kernel, and the new token's
+// cross-attention row averaged over the layers in numpy's order, ((l0 + l1) + l2) + ... then / n_layers.
+// out[0] = token (int32 bits), out[1 .. S] = attention.
+__global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restrict__ x, int N, const float* __restrict__ attn,
+                                                         int n_layers, int64_t layer_stride, int S, float* __restrict__ out,
+                                                         int64_t* __restrict__ token_out) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < S; i += 256) {
+        float a = attn[i];
+        for (int l = 1; l < n_layers; ++l) a += attn[l * layer_stride + i];
+        out[1 + i] = a / (float)n_layers;
+    }
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < N; i += 256) m = fmaxf(m, x[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256) sum += expf(x[i] - m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) red[w] = sum;
+    __syncthreads();
+    const float lse = logf((red[0] + red[1]) + (red[2] + red[3]));
+    __syncthreads();
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float v = (x[i] - m) - lse;
+        if (v > best || (v == best && i < bi)) {
+            best = v;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        red[w] = best;
+        redi[w] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 4; ++q)
+            if (red[q] > best || (red[q] == best && redi[q] < bi)) {
+                best = red[q];
+                bi = redi[q];
+            }
+        bi = bi == 0x7fffffff ? 0 : bi;
+        out[0] = __int_as_float(bi);
+        if (token_out) *token_out = bi;          // appended to the device-side prefix: the next step needs no upload
+    }
+}
+
 __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, int64_t M, int N,
                                                               float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -481,6 +547,15 @@ extern "C" int tal_transpose_fwd(const float* x, int R, int Cc, float* y, void* 
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)cdiv(Cc, 32), (unsigned)cdiv(R, 32)), dim3(32, 8), 0,
                        (hipStream_t)stream, x, R, Cc, y);
     TAL_CHECK_LAUNCH("tal_transpose_fwd");
+    return TAL_OK;
+}
+
+extern "C" int tal_greedy_pick_fwd(const float* logits, int V, const float* attn_rows, int n_layers, int64_t layer_stride,
+                                   int S, float* out, int64_t* token_out, void* stream) {
+    TAL_CHECK_ARG(logits && attn_rows && out && V > 0 && S > 0 && n_layers > 0, "tal_greedy_pick_fwd: bad argument");
+    hipLaunchKernelGGL(greedy_pick_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, V, attn_rows, n_layers,
+                       layer_stride, S, out, token_out);
+    TAL_CHECK_LAUNCH("tal_greedy_pick_fwd");
     return TAL_OK;
 }
 

@@ -154,6 +154,8 @@ class System:
         window_time = 0
         window_key, window = None, None
         layers = model.decoder.layers
+        gen_dev = torch.empty(max(1024, 2 * len(gen)), dtype=torch.int64, device=dev)
+        dev_len = -1
         for it in range(max_iters):
             history = gen[history_start:]
             assert len(history) <= max_positions, "Cannot exceed max context length"
@@ -164,16 +166,33 @@ class System:
                 sl = slice(chunk_start, chunk_start + chunk_size)
                 window = {"encoder_out": enc[:, sl].contiguous(), "encoder_padding_mask": mask[:, sl].contiguous()}
                 window_key = chunk_start
-            y = torch.tensor([history], dtype=torch.int64, device=dev)
+            # the prefix lives on the device: the kernel that picks a token appends it, and the host list is
+            # uploaded again only after the control flow below rewrote it (roll-back, forced EOS)
+            n_gen = len(gen)
+            if gen_dev.numel() < n_gen + 1:
+                gen_dev = torch.empty(2 * (n_gen + 1), dtype=torch.int64, device=dev)
+                dev_len = -1
+            if dev_len != n_gen:
+                gen_dev[:n_gen] = torch.tensor(gen, dtype=torch.int64)
+                dev_len = n_gen
+            y = gen_dev[history_start:n_gen].view(1, -1)
             logits = asr_decode(model, y, window, causal=False, last_only=True, check_tokens=(it == 0))  # [1, V]
             if it == 0 and bool(torch.isnan(logits).any()):
                 raise Exception("Logits contain nans!")
-            logprobs = log_softmax(logits)
-            token = int(ops.argmax_rows(logprobs).cpu().item())
+            # token = argmax(log_softmax(logits)) and the attention of the new token averaged over layers (heads
+            # are already averaged by the softmax kernel): one launch, one D2H copy (system.py:366-399 does the
+            # same arithmetic with a log_softmax, an argmax, a .cpu() per quantity and a numpy mean)
+            all_w = model.decoder.src_attn_weights_all                                  # [n_layers, B, U, S]
+            S_w = all_w.shape[-1]
+            picked = torch.empty(1 + S_w, dtype=torch.float32, device=dev)
+            N.check(N.lib().tal_greedy_pick_fwd(N.ptr(logits), logits.shape[-1], N.ptr(all_w[0, 0, -1]), all_w.shape[0],
+                                                all_w.stride(0), S_w, N.ptr(picked), N.ptr(gen_dev[n_gen:]),
+                                                N.stream_handle()), "tal_greedy_pick_fwd")
+            picked = picked.cpu().numpy()
+            token = int(picked[:1].view(np.int32)[0])
             gen.append(token)
-            # attention of the new token, averaged over layers (heads are already averaged by the kernel)
-            rows = model.decoder.src_attn_weights_all[:, 0, -1].cpu().numpy()          # [n_layers, S]
-            attn = rows.astype(np.float32).sum(axis=0, dtype=np.float32) / np.float32(len(layers))
+            dev_len = n_gen + 1
+            attn = picked[1:].astype(np.float32)
             record = [chunk_start, torch.from_numpy(attn.copy()).unsqueeze(0)]
             alignments.append(record)
             assert len(alignments) == len(gen) - 1
@@ -199,6 +218,7 @@ class System:
                         gen = gen[:-(rollback - 1)]
                         alignments = alignments[:-(rollback - 1)]
                     gen[-1] = eos
+                    dev_len = -1                   # the device copy of the prefix is stale
                     history_start = len(gen) - 1
                     highest_progress = 0
                     window_time = 0

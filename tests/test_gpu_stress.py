@@ -1,0 +1,115 @@
+"""Seeded random-shape sweeps of the kernels against float64 host references (GPU): tile-boundary rows, ragged
+columns, K tails, guard rows behind every output, short / odd time axes."""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _linear_case(rng, M, N, K, mode):
+    from tal_asrd_amd import ops
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / max(K, 1) ** 0.5
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    guard = 3
+    yfull = torch.full((M + guard, N), 777.0, device=dev())
+    y = ops.linear(x.to(dev()), w.to(dev()), b.to(dev()), mode=mode, res=res.to(dev()) if mode == 2 else None, alpha=0.3,
+                   out=yfull[:M])
+    torch.cuda.synchronize()
+    ref = x.double() @ w.double().t() + b.double()
+    if mode == 1:
+        ref = ref.clamp_min(0)
+    if mode == 2:
+        ref = res.double() + 0.3 * ref
+    if mode == 3:
+        ref = 0.3 * ref
+    assert bool((yfull[M:] == 777.0).all()), (M, N, K, mode)
+    err = float((y.cpu().double() - ref).abs().max()) if M else 0.0
+    assert err < 2e-5 * max(1.0, K ** 0.5 / 8), (M, N, K, mode, err)
+
+
+def test_linear_random_shapes():
+    rng = np.random.default_rng(2024)
+    for _ in range(40):                                   # small problems: every kernel of the small-M family
+        M = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 200, 511, 512]))
+        N = int(rng.choice([1, 4, 31, 32, 33, 100, 128, 160, 161, 512, 2048]))
+        K = int(rng.choice([4, 8, 28, 32, 36, 60, 64, 68, 128, 132, 512, 516, 2048]))
+        _linear_case(rng, M, N, K, int(rng.integers(0, 4)))
+    for _ in range(24):                                   # large problems: the 128 x 160 tile, ragged everything
+        M = int(rng.choice([513, 640, 641, 767, 1000, 4097, 66000 + int(rng.integers(0, 300))]))
+        N = int(rng.choice([32, 159, 160, 161, 320, 800]))
+        K = int(rng.choice([32, 64, 96, 100, 256, 288, 800]))
+        _linear_case(rng, M, N, K, int(rng.integers(0, 4)))
+
+
+def test_gconv_random_shapes():
+    from tal_asrd_amd import ops
+    rng = np.random.default_rng(7)
+    for _ in range(12):
+        cg = int(rng.choice([10, 14, 18, 4]))
+        G = 80 if cg != 4 else int(rng.choice([2, 8]))
+        T = int(rng.choice([1, 5, 21, 63, 64, 255, 256, 257, 300, 513]))
+        B = int(rng.integers(1, 3))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn(B, G * cg, T, generator=g)
+        w = torch.randn(G * cg, cg, 21, generator=g) / (21 * cg) ** 0.5
+        b = torch.randn(G * cg, generator=g)
+        ref = x.double() + 0.25 * torch.relu(torch.nn.functional.conv1d(x.double(), w.double(), b.double(), padding=10, groups=G))
+        wp = ops.pack_gconv_weight(w.to(dev()), G)
+        y = ops.gconv_res(x.permute(0, 2, 1).contiguous().to(dev()), wp, b.to(dev()), 0.25, G)
+        np.testing.assert_allclose(y.cpu().double().numpy(), ref.permute(0, 2, 1).numpy(), atol=2e-5, rtol=1e-5,
+                                   err_msg=str((cg, G, T, B)))
+    for _ in range(10):
+        cig, cog = [(1, 10), (10, 14), (14, 18), (2, 3)][int(rng.integers(0, 4))]
+        G = 80 if cig != 2 else 8
+        T = int(rng.choice([21, 22, 23, 64, 277, 300, 511, 1000]))
+        B = int(rng.integers(1, 3))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn(B, G * cig, T, generator=g)
+        w = torch.randn(G * cog, cig, 21, generator=g) / (21 * cig) ** 0.5
+        b = torch.randn(G * cog, generator=g)
+        ref = torch.nn.functional.conv1d(x.double(), w.double(), b.double(), stride=2, groups=G).permute(0, 2, 1)
+        wp = ops.pack_gconv_weight(w.to(dev()), G)
+        y = ops.gconv_s2(x.permute(0, 2, 1).contiguous().to(dev()), wp, b.to(dev()), G * cog, G)
+        np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, err_msg=str((cig, cog, T, B)))
+
+
+def test_logmel_random_lengths():
+    from oracle import tal_oracle as O
+    from tal_asrd_amd import LogMelSpec
+    rng = np.random.default_rng(11)
+    m = LogMelSpec().to(dev())
+    for _ in range(10):
+        B = int(rng.integers(1, 4))
+        L = int(rng.choice([201, 400, 401, 1599, 1600, 1601, 5120, 5121, 16000 + int(rng.integers(0, 200)), 48000]))
+        audio = (rng.standard_normal((B, L)) * 0.1).astype(np.float32)
+        got = m(torch.from_numpy(audio).to(dev())).cpu().numpy()
+        assert got.shape == (B, 1 + L // 160, 80)
+        np.testing.assert_allclose(got, O.logmel_f64(audio), atol=2e-4, rtol=0, err_msg=str((B, L)))
+
+
+def test_sd_head_random_shapes():
+    from tal_asrd_amd import ops
+    rng = np.random.default_rng(5)
+    for _ in range(8):
+        M = int(rng.choice([1, 100, 513, 4000, 33000 + int(rng.integers(0, 500))]))
+        S = int(rng.choice([160, 161, 1000, 6008]))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn(M, 96, generator=g).to(dev())
+        we = (torch.randn(128, 96, generator=g) / 10).to(dev())
+        be = torch.randn(128, generator=g).to(dev())
+        wl = (torch.randn(S, 128, generator=g) / 11).to(dev())
+        bl = torch.randn(S, generator=g).to(dev())
+        _, logits, ids_ref = ops.sd_head(x, we, be, wl, bl, want_logits=True, want_ids=True)
+        _, _, ids = ops.sd_head(x, we, be, wl, bl, want_logits=False, want_ids=True)
+        assert torch.equal(ids, ids_ref), (M, S)
+        assert torch.equal(ids.long().cpu(), logits.argmax(-1).cpu()), (M, S)

@@ -38,7 +38,8 @@ constexpr int MAXW = 48;                       // max mel filter support in bins
 
 struct LogmelPlan {
     double basis[NTILE * NFFT * 2 * 16];   // [tile][n][re|im][16 bins], Hann folded in
-    double fbasis[NTILE * NFOLD * 2 * 16]; // symmetric-window form: re rows act on x[n]+x[400-n], im rows on x[n]-x[400-n]
+    double fbasis[NTILE * NFOLD * 16 * 2]; // symmetric-window form, [tile][n][16 bins][re|im] (one 16-byte load per lane and step):
+                                           // re acts on x[n]+x[400-n], im on x[n]-x[400-n]
     int folded;                            // 1 if the window is symmetric (w[n] == w[400-n], w[0] == 0): use fbasis
     int mel_lo[NMEL];
     int mel_cnt[NMEL];
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelPlan* __restric
             //   Re X[k] =  sum_{n=0}^{200} c_n w[n] cos(.) (x[n] + x[400-n])
             //   Im X[k] = -sum_{n=1}^{199}     w[n] sin(.) (x[n] - x[400-n])
             // (c_200 = 1/2; the n = 0 row is w[0] = 0): half the fp64 MFMAs of the direct form.
-            const double* fq = plan->fbasis + ((int64_t)j * NFOLD + kq) * 32 + fi;
+            typedef double f64x2 __attribute__((ext_vector_type(2)));
+            const f64x2* fq = reinterpret_cast<const f64x2*>(plan->fbasis) + ((int64_t)j * NFOLD + kq) * 16 + fi;
             const float* s0 = samp + fi * (HOP + 1);
             const float* s1 = s0 + 16 * (HOP + 1);
 #pragma unroll 3
@@ -89,8 +91,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelPlan* __restric
                 const int om = m + (m >= 2 * HOP ? 2 : 1);        // 197 <= m <= 400
                 const double x0n = (double)s0[on], x0m = (double)s0[om];
                 const double x1n = (double)s1[on], x1m = (double)s1[om];
-                const double br = fq[k * 32];
-                const double bi = fq[k * 32 + 16];
+                const f64x2 bb = fq[k * 16];
+                const double br = bb.x, bi = bb.y;
                 re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0n + x0m, br, re0, 0, 0, 0);
                 im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0n - x0m, bi, im0, 0, 0, 0);
                 re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1n + x1m, br, re1, 0, 0, 0);
@@ -256,8 +258,8 @@ extern "C" int tal_logmel_plan_init(const float* window, const float* fb, void* 
                     re = ws * cos(ang);
                     im = n == NFFT / 2 ? 0.0 : -ws * sin(ang);
                 }
-                hp->fbasis[((j * NFOLD + n) * 2 + 0) * 16 + c] = re;
-                hp->fbasis[((j * NFOLD + n) * 2 + 1) * 16 + c] = im;
+                hp->fbasis[((j * NFOLD + n) * 16 + c) * 2 + 0] = re;
+                hp->fbasis[((j * NFOLD + n) * 16 + c) * 2 + 1] = im;
             }
     for (int m = 0; m < NMEL; ++m) {
         int lo = -1, hi = -1;

@@ -1,0 +1,169 @@
+// Experiment (not product code): fp32 dense layer emulated on the fp16 matrix cores with a hi/lo split,
+//   x = hi + lo * 2^-11,  hi = fp16(x),  lo = fp16((x - hi) * 2^11)
+//   a . w  ~=  sum hi_a hi_w  +  2^-11 * sum (hi_a lo_w + lo_a hi_w)          (lo_a lo_w ~ 2^-22 relative, dropped)
+// three v_mfma_f32_32x32x16_f16 per fp32 product block, fp32 accumulation in two accumulator sets.  Operands are
+// pre-split into the SAME byte geometry as fp32 rows: per row and per 32-wide K block, 32 hi halves then 32 lo
+// halves (128 bytes), so the dense-layer kernel's LDS-DMA pipeline, swizzle and tile shape carry over unchanged.
+// Reports accuracy against a float64 host product (small problem) and throughput (whole-round problem).
+//   hipcc --offload-arch=gfx950 -O3 scripts/ubench/gemm_f16x3.hip -o scripts/ubench/gemm_f16x3
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__global__ void split_kernel(const float* __restrict__ x, _Float16* __restrict__ out, int64_t rows, int K) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * K) return;
+    const int64_t r = i / K;
+    const int k = (int)(i - r * K);
+    const float v = x[i];
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+    _Float16* blk = out + (r * (K / 32) + k / 32) * 64;
+    blk[k % 32] = hi;
+    blk[32 + k % 32] = lo;
+}
+
+constexpr int BM = 128, NSUB = 5, BN = 32 * NSUB, ROWS = BM + BN, BK = 32;
+
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const float* __restrict__ As, const float* __restrict__ Ws,
+                                                           float* __restrict__ C, int64_t M, int N, int K, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * 32];
+    const unsigned tile = blockIdx.x;
+    const int64_t m0 = (int64_t)(tile / (unsigned)tiles_n) * BM;
+    const int n0 = (int)(tile % (unsigned)tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane >> 3, srccol = ((lane & 7) ^ sub) * 4;     // in floats (16-byte slots), as the fp32 kernel
+    const int a_rows = (int)((M - m0) < BM ? (M - m0) : BM) - 1;
+    const int b_rows = ((N - n0) < BN ? (N - n0) : BN) - 1;
+    auto uptr = [](const float* p) {
+        const uint64_t v = reinterpret_cast<uint64_t>(p);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    };
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(uptr(As + m0 * K), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(uptr(Ws + (int64_t)n0 * K), 0, 0x7fffffff, 0x00020000);
+    int voff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int row = 8 * (w + 4 * t) + sub;
+        voff[t] = t < 4 ? (min(row, a_rows) * K + srccol) * 4 : (min(row - BM, b_rows) * K + srccol) * 4;
+    }
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float* dst = lds + buf * (ROWS * 32) + (w + 4 * t) * 256;
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(t < 4 ? rs_a : rs_w, (__attribute__((address_space(3))) void*)dst, 16, voff[t],
+                                                     kt * (BK * 4), 0, 0);
+#endif
+        }
+    };
+    f32x16 hh[NSUB], xx[NSUB];
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hh[j][e] = xx[j][e] = 0.f;
+    const int frow = lane & 31, fsw = frow & 7, fhalf = lane >> 5;
+    const int nk = K / BK;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const float* Asl = lds + (kt & 1) * (ROWS * 32) + (w * 32 + frow) * 32;
+        const float* Bsl = lds + (kt & 1) * (ROWS * 32) + (BM + frow) * 32;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {            // 16 k per MFMA: slots 2g + half (hi) and 4 + 2g + half (lo)
+            const int sh = ((2 * g + fhalf) ^ fsw) * 4, sl = ((4 + 2 * g + fhalf) ^ fsw) * 4;
+            const h8 ahi = *reinterpret_cast<const h8*>(Asl + sh), alo = *reinterpret_cast<const h8*>(Asl + sl);
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) {
+                const h8 bhi = *reinterpret_cast<const h8*>(Bsl + j * 32 * 32 + sh), blo = *reinterpret_cast<const h8*>(Bsl + j * 32 * 32 + sl);
+                hh[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, hh[j], 0, 0, 0);
+                xx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, xx[j], 0, 0, 0);
+                xx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, xx[j], 0, 0, 0);
+            }
+        }
+    }
+    const int colb = lane & 31, rowb = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+        const int col = n0 + j * 32 + colb;
+        if (col >= N) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t row = m0 + w * 32 + rowb + (e & 3) + 8 * (e >> 2);
+            if (row < M) C[row * N + col] = hh[j][e] + xx[j][e] * (1.0f / 2048.0f);
+        }
+    }
+}
+
+static void run(int64_t M, int N, int K, bool check) {
+    std::vector<float> ha((size_t)M * K), hw((size_t)N * K);
+    uint64_t s = 12345;
+    auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (float)((s >> 33) & 0xffffff) / 8388608.0f - 1.0f; };
+    for (auto& v : ha) v = rnd() * 3.0f;            // activations of a few units
+    for (auto& v : hw) v = rnd() * 0.05f;           // weights ~ 1/sqrt(K)
+    float *a, *wt, *c;
+    _Float16 *as, *ws;
+    (void)hipMalloc(&a, ha.size() * 4);
+    (void)hipMalloc(&wt, hw.size() * 4);
+    (void)hipMalloc(&as, ha.size() * 4);
+    (void)hipMalloc(&ws, hw.size() * 4);
+    (void)hipMalloc(&c, (size_t)M * N * 4);
+    (void)hipMemcpy(a, ha.data(), ha.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(wt, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)((ha.size() + 255) / 256)), dim3(256), 0, 0, a, as, M, K);
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)((hw.size() + 255) / 256)), dim3(256), 0, 0, wt, ws, (int64_t)N, K);
+    const int tiles_n = (N + BN - 1) / BN;
+    const unsigned grid = (unsigned)(((M + BM - 1) / BM) * tiles_n);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rep = 0; rep < (check ? 1 : 5); ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(gemm_f16x3_kernel, dim3(grid), dim3(256), 0, 0, (const float*)as, (const float*)ws, c, M, N, K, tiles_n);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    printf("M=%lld N=%d K=%d: %.3f ms  %.1f fp32-equivalent TFLOP/s (%s)\n", (long long)M, N, K, best, 2.0 * M * N * K / best / 1e9,
+           hipGetErrorString(hipGetLastError()));
+    if (check) {
+        std::vector<float> hc((size_t)M * N);
+        (void)hipMemcpy(hc.data(), c, hc.size() * 4, hipMemcpyDeviceToHost);
+        double e_split = 0, e_f32 = 0, scale = 0;
+        for (int64_t i = 0; i < M; i += 7)
+            for (int j = 0; j < N; j += 3) {
+                double ref = 0;
+                float f32 = 0.f;
+                for (int k = 0; k < K; ++k) {
+                    ref += (double)ha[i * K + k] * (double)hw[(size_t)j * K + k];
+                    f32 = fmaf(ha[i * K + k], hw[(size_t)j * K + k], f32);
+                }
+                e_split = fmax(e_split, fabs((double)hc[i * N + j] - ref));
+                e_f32 = fmax(e_f32, fabs((double)f32 - ref));
+                scale = fmax(scale, fabs(ref));
+            }
+        printf("  max |err| vs float64: f16x3 split %.3e, plain fp32 fmaf chain %.3e   (max |value| %.2f)\n", e_split, e_f32, scale);
+    }
+    (void)hipFree(a); (void)hipFree(wt); (void)hipFree(as); (void)hipFree(ws); (void)hipFree(c);
+}
+
+int main() {
+    run(300, 170, 1440, true);
+    run(1000, 800, 800, true);
+    run(65536, 1440, 1440, false);
+    run(65536, 800, 800, false);
+    return 0;
+}

@@ -86,6 +86,19 @@ int tal_linear_ws_fwd(const float* x, const float* w, const float* b, const floa
                       int mode, int64_t M, int N, int K, float* y, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* fp16x3 form of a large dense layer: fp32 data is carried as hi = fp16(x), lo = fp16((x - hi) * 2^11) in the byte
+ * geometry of fp32 rows (per row and 32-wide K block: 32 hi halves, then 32 lo halves), and
+ *   x . w = sum hi_x hi_w + 2^-11 sum (hi_x lo_w + lo_x hi_w)        (lo_x lo_w, 2^-22 relative, dropped)
+ * runs as three fp16 MFMAs with fp32 accumulation: measured error against float64 is below that of an fp32 fmaf
+ * chain (scripts/ubench/gemm_f16x3.hip), at ~2.4x the fp32 matrix rate.  Requires |x| < 65504 (fp16 range).
+ * tal_split_f16x3_fwd: x [rows, K] fp32 -> out (rows * K * 4 bytes), K % 32 == 0.
+ * tal_linear_f16x3_fwd: tal_linear_ws_fwd on pre-split x / w (M > 512, K % 32 == 0, modes 0-3); out_split != 0
+ * writes y in the split form too (N % 160 == 0), as the next layer's input. */
+int tal_split_f16x3_fwd(const float* x, void* out, int64_t rows, int K, void* stream);
+int tal_linear_f16x3_fwd(const void* x_split, const void* w_split, const float* b, const float* res, float alpha,
+                         int mode, int64_t M, int N, int K, void* y, int out_split, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ *
  * Grouped temporal convolutions of the TDS encoder.
  * Packed weight layout [G][C_in/G][21][C_out/G] (tal_pack_gconv_weight
@@ -114,6 +127,8 @@ typedef struct tal_tds_block_w {
     const float* fc3_b;    /* [C]                                    (fc.3.bias)     */
     float resweight;       /* host scalar                            (resweight)     */
     int32_t _pad;
+    const void* fc0_w_split; /* fc.0.weight / fc.3.weight as hi/lo fp16 splits (tal_split_f16x3_fwd), or NULL: */
+    const void* fc3_w_split; /* with both present the block's dense layers run in the fp16x3 form for M > 512   */
 } tal_tds_block_w;
 
 typedef struct tal_tds_desc {

@@ -18,7 +18,8 @@ c_float_p = C.c_void_p  # device pointers travel as integers
 
 class TdsBlockW(C.Structure):
     _fields_ = [("conv_w", C.c_void_p), ("conv_b", C.c_void_p), ("fc0_w", C.c_void_p), ("fc0_b", C.c_void_p),
-                ("fc3_w", C.c_void_p), ("fc3_b", C.c_void_p), ("resweight", C.c_float), ("_pad", C.c_int32)]
+                ("fc3_w", C.c_void_p), ("fc3_b", C.c_void_p), ("resweight", C.c_float), ("_pad", C.c_int32),
+                ("fc0_w_split", C.c_void_p), ("fc3_w_split", C.c_void_p)]
 
 
 class TdsDesc(C.Structure):
@@ -48,6 +49,8 @@ SIGNATURES = {
     "tal_subtract_scalar": (_i, [_p, _i64, _p, _p]),
     "tal_linear_fwd": (_i, [_p, _p, _p, _p, _f, _i, _i64, _i, _i, _p, _p]),
     "tal_linear_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "tal_split_f16x3_fwd": (_i, [_p, _p, _i64, _i, _p]),
+    "tal_linear_f16x3_fwd": (_i, [_p, _p, _p, _p, _f, _i, _i64, _i, _i, _p, _i, _p, _sz, _p]),
     "tal_linear_ws_fwd": (_i, [_p, _p, _p, _p, _f, _i, _i64, _i, _i, _p, _p, _sz, _p]),
     "tal_pack_gconv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "tal_gconv_s2_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _p, _p]),

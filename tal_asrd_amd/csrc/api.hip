@@ -244,7 +244,7 @@ static size_t tds_buf_floats(const tal_tds_desc* d, int B, int64_t T) {
 
 extern "C" size_t tal_tds_workspace_bytes(const tal_tds_desc* d, int B, int64_t T) {
     if (!d || B <= 0 || T <= 0) return 0;
-    return 3 * tds_buf_floats(d, B, T) * sizeof(float) + gemm_splitk_ws_bytes();
+    return 4 * tds_buf_floats(d, B, T) * sizeof(float) + gemm_splitk_ws_bytes();
 }
 
 extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t T, float* y, void* workspace,
@@ -259,10 +259,11 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
     }
     hipStream_t s = (hipStream_t)stream;
     const size_t nf = tds_buf_floats(d, B, T);
-    float* buf[3] = {reinterpret_cast<float*>(workspace), reinterpret_cast<float*>(workspace) + nf,
-                     reinterpret_cast<float*>(workspace) + 2 * nf};
-    float* skws = reinterpret_cast<float*>(workspace) + 3 * nf;   // split-K scratch of the dense layers
-    // three rotating buffers; `ia` = index of the buffer holding the live activations (-1: caller's x).
+    float* buf[4];
+    for (int q = 0; q < 4; ++q) buf[q] = reinterpret_cast<float*>(workspace) + q * nf;
+    float* skws = reinterpret_cast<float*>(workspace) + 4 * nf;   // split-K scratch of the dense layers
+    static const bool force_f32 = getenv("TAL_TDS_F32") != nullptr;
+    // four rotating buffers; `ia` = index of the buffer holding the live activations (-1: caller's x).
     // No launch ever reads and writes the same buffer (workgroups read halos of their neighbours).
     const float* cur = x;
     int ia = -1;
@@ -272,7 +273,7 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
         const int64_t To = conv_out_len(Tc);
         const bool last_stage = i == d->n_stages - 1;
         // resize conv: cur -> a (a buffer other than cur's)
-        const int io = (ia + 1) % 3;
+        const int io = (ia + 1) % 4;
         float* a = (last_stage && d->depths[i] == 0) ? y : buf[io];
         rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s);
         if (rc) return rc;
@@ -281,25 +282,50 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
         for (int j = 0; j < d->depths[i]; ++j) {
             const tal_tds_block_w& bw = d->blocks[i][j];
             TAL_CHECK_ARG(bw.conv_w && bw.conv_b && bw.fc0_w && bw.fc0_b && bw.fc3_w && bw.fc3_b, "tal_tds_fwd: null weight in block %d.%d", i, j);
-            float* x1 = buf[(ia + 1) % 3];
-            float* h = buf[(ia + 2) % 3];
+            float* x1 = buf[(ia + 1) % 4];
+            float* h = buf[(ia + 2) % 4];
+            float* x1s = buf[(ia + 3) % 4];
+            float* outp = (last_stage && j == d->depths[i] - 1) ? y : buf[ia];
             // x1 = x + rw * relu(gconv(x))            : a -> x1
             rc = launch_gconv_res(a, bw.conv_w, bw.conv_b, bw.resweight, B, To, c, d->groups, x1, s);
             if (rc) return rc;
-            // h = relu(fc0(x1))                        : x1 -> h
-            rc = launch_linear_ws(x1, bw.fc0_w, bw.fc0_b, nullptr, 0.f, 1, M, c, c, h, skws, gemm_splitk_ws_bytes(), s);
-            if (rc) return rc;
-            // x2 = x1 + rw * fc3(h)                    : h (+res x1) -> a's buffer (dead since the gconv)
-            float* outp = (last_stage && j == d->depths[i] - 1) ? y : buf[ia];
-            rc = launch_linear_ws(h, bw.fc3_w, bw.fc3_b, x1, bw.resweight, 2, M, c, c, outp, skws,
-                                  gemm_splitk_ws_bytes(), s);
-            if (rc) return rc;
+            const bool f16x3 = !force_f32 && bw.fc0_w_split && bw.fc3_w_split && M > 512 && c % 160 == 0;
+            if (f16x3) {
+                // the two dense layers in the fp16x3 form: x1 is split once, fc0 writes its output already split
+                rc = launch_split_f16x3(x1, x1s, M, c, s);
+                if (rc) return rc;
+                rc = launch_linear_f16x3(x1s, bw.fc0_w_split, bw.fc0_b, nullptr, 0.f, 1, M, c, c, h, 1, skws, gemm_splitk_ws_bytes(), s);
+                if (rc) return rc;
+                rc = launch_linear_f16x3(h, bw.fc3_w_split, bw.fc3_b, x1, bw.resweight, 2, M, c, c, outp, 0, skws,
+                                         gemm_splitk_ws_bytes(), s);
+                if (rc) return rc;
+            } else {
+                // h = relu(fc0(x1))                        : x1 -> h
+                rc = launch_linear_ws(x1, bw.fc0_w, bw.fc0_b, nullptr, 0.f, 1, M, c, c, h, skws, gemm_splitk_ws_bytes(), s);
+                if (rc) return rc;
+                // x2 = x1 + rw * fc3(h)                    : h (+res x1) -> a's buffer (dead since the gconv)
+                rc = launch_linear_ws(h, bw.fc3_w, bw.fc3_b, x1, bw.resweight, 2, M, c, c, outp, skws,
+                                      gemm_splitk_ws_bytes(), s);
+                if (rc) return rc;
+            }
             a = outp;
         }
         cur = a;
         Tc = To;
     }
     return TAL_OK;
+}
+
+extern "C" int tal_split_f16x3_fwd(const float* x, void* out, int64_t rows, int K, void* stream) {
+    return launch_split_f16x3(x, out, rows, K, (hipStream_t)stream);
+}
+
+extern "C" int tal_linear_f16x3_fwd(const void* x_split, const void* w_split, const float* b, const float* res, float alpha,
+                                    int mode, int64_t M, int N, int K, void* y, int out_split, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    TAL_CHECK_ARG(workspace || workspace_bytes == 0, "tal_linear_f16x3_fwd: null workspace with %zu bytes", workspace_bytes);
+    return launch_linear_f16x3(x_split, w_split, b, res, alpha, mode, M, N, K, y, out_split, (float*)workspace, workspace_bytes,
+                               (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------

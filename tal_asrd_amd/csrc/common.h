@@ -31,6 +31,8 @@ void set_error(const char* fmt, ...);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -73,6 +75,10 @@ struct GemmArgs {
     int tile_base, split, tail_tiles;
     float* splitk_ws;
     size_t splitk_ws_bytes;
+    // fp16x3 form (dense layers of the TDS blocks): A and W are hi/lo fp16 splits of fp32 data in the byte geometry of
+    // fp32 rows (per row and 32-wide K block: 32 hi halves, then 32 lo halves scaled by 2^11); out_split: write Y in
+    // the same split form (it is the next layer's A) instead of fp32.  Needs K % 32 == 0 (and N % 32 == 0 for out_split).
+    int f16x3, out_split;
 };
 // mode 0: acc+b | 1: relu(acc+b) | 2: res + alpha*(acc+b) | 3: alpha*(acc+b) | 4: row arg-max partials of acc+b
 int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s);
@@ -85,6 +91,11 @@ int launch_linear(const float* x, const float* w, const float* b, const float* r
 int launch_linear_ws(const float* x, const float* w, const float* b, const float* res, float alpha, int mode,
                      int64_t M, int N, int K, float* y, float* ws, size_t ws_bytes, hipStream_t s);
 size_t gemm_splitk_ws_bytes();
+// fp32 [rows, K] -> hi/lo fp16 split in fp32-row geometry (K % 32 == 0)
+int launch_split_f16x3(const float* x, void* out, int64_t rows, int K, hipStream_t s);
+// dense layer on pre-split operands (see GemmArgs::f16x3); ws as launch_linear_ws
+int launch_linear_f16x3(const void* xs, const void* wsplit, const float* b, const float* res, float alpha, int mode, int64_t M,
+                        int N, int K, void* y, int out_split, float* ws, size_t ws_bytes, hipStream_t s);
 int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, int64_t T_in, int C_in, int C_out,
                     int groups, float* y, hipStream_t s);
 int launch_gconv_res(const float* x, const float* wp, const float* bias, float alpha, int B, int64_t T, int C,

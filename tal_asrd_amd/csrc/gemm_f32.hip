@@ -167,6 +167,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                     }
                     if (MODE == 2) v = rv[t] + alpha * v;
                     if (MODE == 3 && (g.scale_cols == 0 || n_base + (offb[t] >> 2) < g.scale_cols)) v = alpha * v;
+                    if (g.out_split) {
+                        // the next layer's A operand: hi / lo fp16 halves of these 4 columns, in the row's 128-byte
+                        // K blocks [32 hi | 32 lo]  (column c of the wave's window -> block c / 32, slot c % 32)
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        const f16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                        const f16x4 lo = {(_Float16)((v.x - (float)hi.x) * 2048.f), (_Float16)((v.y - (float)hi.y) * 2048.f),
+                                          (_Float16)((v.z - (float)hi.z) * 2048.f), (_Float16)((v.w - (float)hi.w) * 2048.f)};
+                        const int cw = offb[t] >> 2;                                  // column inside the window
+                        const int so = offy[t] - offb[t] + (cw >> 5) * 128 + (cw & 31) * 2;   // row part + block + slot
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rs_y[half], so, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rs_y[half], so + 64, 0, 0);
+                        continue;
+                    }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y[half], offy[t], 0, 0);
                 }
                 continue;
@@ -232,7 +245,7 @@ __device__ __forceinline__ unsigned logical_tile() { return logical_tile_of(grid
 // ---------------------------------------------------------------------------------------------
 // hot kernel: direct-to-LDS operand loads, double buffer, one barrier per K step
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int NSUB, bool SPLITK, int STAGE>
+template <int MODE, int NSUB, bool SPLITK, int STAGE, bool F16X3 = false>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
     // Set-up and epilogue are short VALU / memory sequences; the co-resident workgroup is usually deep in
     // its MFMA loop, and at equal priority every one of these instructions queues behind a 64-cycle MFMA.
@@ -320,10 +333,15 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
     };
 
     f32x16 acc[NSUB];
+    f32x16 accx[F16X3 ? NSUB : 1];     // fp16x3: the cross terms hi*lo + lo*hi (scaled by 2^11)
 #pragma unroll
     for (int j = 0; j < NSUB; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < (F16X3 ? NSUB : 1); ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accx[j][e] = 0.f;
 
     // fragment read: row (l & 31) of a 32-row block, logical 16-byte column 2*kk + (l >> 5)
     const int frow = lane & 31;
@@ -341,6 +359,25 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const float* As = lds + (kt & 1) * (ROWS * 32) + (wm * 32 + frow) * 32;
         const float* Bs = lds + (kt & 1) * (ROWS * 32) + (BM + frow) * 32;
+        if (F16X3) {
+            // operands are hi/lo fp16 splits: a 128-byte row of this K block is [32 hi | 32 lo]; one MFMA takes 16 k,
+            // lanes < 32 the first 8 and lanes >= 32 the next 8: 16-byte slot 2g + half (hi), 4 + 2g + half (lo).
+            // a.w = sum hi*hi + 2^-11 sum (hi*lo + lo*hi), fp32 accumulation; lo*lo (2^-22 relative) is dropped.
+#pragma unroll
+            for (int gk = 0; gk < 2; ++gk) {
+                const int sh = ((2 * gk + fhalf) ^ fsw) * 4, sl = ((4 + 2 * gk + fhalf) ^ fsw) * 4;
+                const f16x8 ahi = *reinterpret_cast<const f16x8*>(As + sh), alo = *reinterpret_cast<const f16x8*>(As + sl);
+#pragma unroll
+                for (int j = 0; j < NSUB; ++j) {
+                    const f16x8 bhi = *reinterpret_cast<const f16x8*>(Bs + j * 32 * 32 + sh);
+                    const f16x8 blo = *reinterpret_cast<const f16x8*>(Bs + j * 32 * 32 + sl);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[j], 0, 0, 0);
+                    accx[F16X3 ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, accx[F16X3 ? j : 0], 0, 0, 0);
+                    accx[F16X3 ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, accx[F16X3 ? j : 0], 0, 0, 0);
+                }
+            }
+            continue;
+        }
         f32x4 fa[2], fb[2][NSUB];
         fa[0] = *reinterpret_cast<const f32x4*>(As + ((fhalf) ^ fsw) * 4);
 #pragma unroll
@@ -365,6 +402,12 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
     }
     __syncthreads();  // all waves done with the operand buffers before they become the store stage
     __builtin_amdgcn_s_setprio(3);
+    if (F16X3) {
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = fmaf(accx[F16X3 ? j : 0][e], 1.0f / 2048.0f, acc[j][e]);
+    }
     if (is_slice) {
         // raw accumulators of this K slice -> scratch tile [(tile, slice)][128][BN]; the fix-up kernel
         // adds the slices in a fixed order and applies bias / activation / residual
@@ -372,6 +415,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
         gp.M = m0 + BM;
         gp.N = n0 + BN;
         gp.ldy = BN;
+        gp.out_split = 0;            // partial sums stay fp32; the fix-up kernel writes the split form
         float* tile_ws = g.splitk_ws + ((size_t)(logical - g.tile_base) * g.split + slice) * (BM * BN);
         gemm_epilogue<0, NSUB>(gp, acc, lds, tile_ws - (m0 * BN + n0), nullptr, nullptr, m0, n0, lane, w, wm, wn);
     } else {
@@ -675,6 +719,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(const GemmArgs g
             }
             if (MODE == 2) v = rv + g.alpha * v;
             if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) v = g.alpha * v;
+            if (g.out_split) {
+                const f16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                const f16x4 lo = {(_Float16)((v.x - (float)hi.x) * 2048.f), (_Float16)((v.y - (float)hi.y) * 2048.f),
+                                  (_Float16)((v.z - (float)hi.z) * 2048.f), (_Float16)((v.w - (float)hi.w) * 2048.f)};
+                _Float16* yr = reinterpret_cast<_Float16*>(g.Y + row * g.ldy) + (col >> 5) * 64 + (col & 31);
+                *reinterpret_cast<f16x4*>(yr) = hi;
+                *reinterpret_cast<f16x4*>(yr + 32) = lo;
+                continue;
+            }
             *reinterpret_cast<f32x4*>(g.Y + row * g.ldy + col) = v;
             continue;
         }
@@ -716,6 +769,10 @@ template <int MODE, int NSUB, bool SPLITK>
 static void launch_glds_stage(const GemmArgs& g, dim3 grid, hipStream_t s) {
     // the buffer form of the operand loads (default) needs the tile's lane offsets to fit 32 bits
     static const int want = getenv("TAL_GEMM_STAGE") ? atoi(getenv("TAL_GEMM_STAGE")) : 2;
+    if (g.f16x3) {
+        if constexpr (MODE <= 3) hipLaunchKernelGGL((gemm_glds_kernel<MODE, NSUB, SPLITK, 2, true>), grid, dim3(256), 0, s, g);
+        return;
+    }
     if (want == 2 && g.lda < (1 << 21) && g.ldw < (1 << 21))
         hipLaunchKernelGGL((gemm_glds_kernel<MODE, NSUB, SPLITK, 2>), grid, dim3(256), 0, s, g);
     else
@@ -753,6 +810,12 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
     TAL_CHECK_ARG(g.scale_cols % 4 == 0, "gemm: scale_cols must be a multiple of 4");
     TAL_CHECK_ARG(nbatch >= 1 && nbatch <= 65535 && g.nb2 >= 1, "gemm: batch %d", nbatch);
     if (g.M == 0) return TAL_OK;
+    if (g.f16x3 || g.out_split) {
+        TAL_CHECK_ARG(g.f16x3, "gemm: out_split needs the fp16x3 form");
+        TAL_CHECK_ARG(g.M > 512 && g.K % BK == 0 && mode <= 3 && nbatch == 1, "gemm: the fp16x3 form needs M > 512, K %% 32 == 0, modes 0-3");
+        TAL_CHECK_ARG(!g.out_split || (g.N % 160 == 0 && g.ldy % 4 == 0), "gemm: split output needs N %% 160 == 0");
+        TAL_CHECK_ARG(g.lda < (1 << 21) && g.ldw < (1 << 21), "gemm: leading dimension too large for the fp16x3 form");
+    }
     const bool small = g.M <= 512;
     const int bm = small ? 32 : 128, bn = small ? 128 : 160;
     g.tiles_n = (int)cdiv(g.N, bn);
@@ -827,6 +890,50 @@ int launch_linear_ws(const float* x, const float* w, const float* b, const float
     g.alpha = alpha;
     g.splitk_ws = ws;
     g.splitk_ws_bytes = ws_bytes;
+    return launch_gemm(g, mode, 1, s);
+}
+
+// fp32 -> hi / lo fp16 split in fp32-row geometry: per row and 32-wide K block, 32 hi halves then 32 lo halves
+// (lo = (x - hi) * 2^11): one thread per 4 consecutive floats
+__global__ __launch_bounds__(256) void split_f16x3_kernel(const float* __restrict__ x, _Float16* __restrict__ out, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    const f16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    const f16x4 lo = {(_Float16)((v.x - (float)hi.x) * 2048.f), (_Float16)((v.y - (float)hi.y) * 2048.f),
+                      (_Float16)((v.z - (float)hi.z) * 2048.f), (_Float16)((v.w - (float)hi.w) * 2048.f)};
+    // element index e = 4 i inside a row-major [rows, K] array with K % 32 == 0: block e / 32 (64 halves), slot e % 32
+    const int64_t e = 4 * i;
+    _Float16* o = out + (e >> 5) * 64 + (e & 31);
+    *reinterpret_cast<f16x4*>(o) = hi;
+    *reinterpret_cast<f16x4*>(o + 32) = lo;
+}
+
+int launch_split_f16x3(const float* x, void* out, int64_t rows, int K, hipStream_t s) {
+    TAL_CHECK_ARG(x && out && rows >= 0 && K > 0 && K % 32 == 0, "split_f16x3: bad argument (K %% 32 == 0 required)");
+    TAL_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "split_f16x3: 16-byte alignment required");
+    const int64_t n4 = rows * K / 4;
+    if (n4 == 0) return TAL_OK;
+    ProfScope prof(PROF_OTHER, (double)rows * K * 8.0, s);
+    hipLaunchKernelGGL(split_f16x3_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, s, x, reinterpret_cast<_Float16*>(out), n4);
+    TAL_CHECK_LAUNCH("split_f16x3");
+    return TAL_OK;
+}
+
+int launch_linear_f16x3(const void* xs, const void* wsplit, const float* b, const float* res, float alpha, int mode, int64_t M,
+                        int N, int K, void* y, int out_split, float* ws, size_t ws_bytes, hipStream_t s) {
+    TAL_CHECK_ARG(xs && wsplit && y, "linear_f16x3: null pointer");
+    GemmArgs g = {};
+    g.A = reinterpret_cast<const float*>(xs); g.W = reinterpret_cast<const float*>(wsplit); g.bias = b; g.res = res;
+    g.Y = reinterpret_cast<float*>(y);
+    g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldw = K; g.ldy = N; g.ldres = N;
+    g.nb2 = 1;
+    g.alpha = alpha;
+    g.splitk_ws = ws;
+    g.splitk_ws_bytes = ws_bytes;
+    g.f16x3 = 1;
+    g.out_split = out_split;
     return launch_gemm(g, mode, 1, s);
 }
 

@@ -88,6 +88,17 @@ def linear(x, weight, bias=None, mode=0, res=None, alpha=0.0, out=None):
     return y
 
 
+def split_f16x3(x2d):
+    """fp32 [rows, K] (K % 32 == 0) -> the hi / lo fp16 split the fp16x3 dense layers consume (same number of bytes,
+    returned as an opaque uint8 tensor)."""
+    lib = N.lib()
+    x2d = _f32c(x2d, "split_f16x3")
+    rows, K = x2d.shape
+    out = torch.empty(rows * K * 4, dtype=torch.uint8, device=x2d.device)
+    N.check(lib.tal_split_f16x3_fwd(N.ptr(x2d), N.ptr(out), rows, K, N.stream_handle()), "tal_split_f16x3_fwd")
+    return out
+
+
 # ------------------------------------------------------------------ grouped conv
 def pack_gconv_weight(weight, groups):
     """reference Conv1d weight [C_out, C_in/G, 21] -> packed [G][C_in/G][21][C_out/G]."""

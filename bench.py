@@ -13,8 +13,9 @@ rank processes its own clip (independent episodes; no data-path collective excep
 result gather of ids + features to rank 0, which is inside the timed region).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     -- dominant kernel (fp32 MFMA dense layer): algorithmic flops / HIP-event
-                  time of its launches inside the timed region vs the 157.3 TFLOP/s peak
+  roofline     -- dominant kernel (the dense layers): algorithmic fp32 flops / HIP-event time of its launches
+                  inside the timed region vs the matrix peak of the MFMA it issues (fp16: 2500 TFLOP/s; the TDS
+                  pointwise layers run as 3 f16 MFMAs per fp32 product; TAL_TDS_F32=1: pure fp32, 157.3)
   cpu_baseline -- the CPU oracle (a port of the reference's PyTorch-CPU path) timed on
                   this box's host cores on a bounded 5-minute sample.
 """
@@ -32,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+F16_MATRIX_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/FP16 MFMA dense (v_mfma_f32_32x32x16_f16)
+POINTWISE_MAC_PER_FRAME = 6_272_000   # the 22 pointwise layers of the TDS blocks: fp16x3 form
 MAC_PER_FRAME_GEMM = 6_272_000 + 119_168 / 1.0  # pointwise pairs + SD head (per mel frame)
 
 
@@ -222,7 +225,9 @@ def main():
             "metric": "audio frames/sec (16 kHz, 10 ms hop) end-to-end log-mel -> TDS encoder -> diarization head",
             "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if os.environ.get("TAL_TDS_F32") else "f32 (dense layers: 3 x f16 MFMA hi/lo split, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "%d x %.0f s 16 kHz clip per GPU, each a whole-episode B=1 call "
                                    "(BASELINE.json configs[2]; SDModel path of tal/baseline/reconcile.py:76-85: "
                                    "log-mel -> TDS 80-800-1120-1440 -> 128-d feat + argmax over 6008 speakers)"
@@ -244,9 +249,21 @@ def main():
                     traffic = json.load(f)["hbm_bytes_per_launch"]
             except Exception:
                 pass
-            line["roofline"] = {"bound": "mfma", "kernel": "tal::gemm_glds_kernel (fp32 MFMA dense layer, all epilogues)",
-                                "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+            f32_only = bool(os.environ.get("TAL_TDS_F32"))
+            peak = FP32_MATRIX_PEAK_TFLOPS if f32_only else F16_MATRIX_PEAK_TFLOPS
+            # MFMA flops actually issued: the pointwise layers run as 3 fp16 MFMAs per fp32 product (hi*hi, hi*lo, lo*hi)
+            pw = 2.0 * POINTWISE_MAC_PER_FRAME * frames * args.segments * args.steps
+            issued = gm["work"] + (0.0 if f32_only else 2.0 * pw)
+            line["roofline"] = {"bound": "mfma",
+                                "kernel": "tal::gemm_glds_kernel (dense layers; TDS pointwise layers in the fp16x3 form: fp32 "
+                                          "products as 3 f16 MFMAs, fp32 accumulate)" if not f32_only else
+                                          "tal::gemm_glds_kernel (fp32 MFMA dense layer, all epilogues)",
+                                "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                                "frac": achieved / peak, "traffic": traffic,
+                                "achieved_is": "algorithmic fp32 flops (2 M N K per dense layer) / HIP-event time",
+                                "issued_mfma_tflops": issued / (gm["ms_total"] * 1e-3) / 1e12 if gm["ms_total"] > 0 else 0.0,
+                                "issued_frac": (issued / (gm["ms_total"] * 1e-3) / 1e12 / peak) if gm["ms_total"] > 0 else 0.0,
+                                "fp32_matrix_peak": FP32_MATRIX_PEAK_TFLOPS,
                                 "avg_launch_ms": gm["ms_total"] / max(gm["launches"], 1),
                                 "launches": gm["launches"],
                                 "algorithmic_flops_per_launch": gm["work"] / max(gm["launches"], 1),

@@ -36,6 +36,13 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// fp32 -> (hi, lo) fp16 pair of the fp16x3 operand form: hi = fp16(x), lo = fp16((x - hi) * 2^11).  Both halves are
+// clamped to the finite fp16 range, so an activation beyond +-65504 degrades gracefully instead of becoming inf.
+__device__ __forceinline__ void split_f16x3(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+    lo = (_Float16)fminf(fmaxf((x - (float)hi) * 2048.f, -65504.f), 65504.f);
+}
+
 // wave-uniform wave index inside the workgroup, provably uniform to the compiler
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 

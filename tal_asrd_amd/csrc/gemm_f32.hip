@@ -171,9 +171,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                         // the next layer's A operand: hi / lo fp16 halves of these 4 columns, in the row's 128-byte
                         // K blocks [32 hi | 32 lo]  (column c of the wave's window -> block c / 32, slot c % 32)
                         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        const f16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-                        const f16x4 lo = {(_Float16)((v.x - (float)hi.x) * 2048.f), (_Float16)((v.y - (float)hi.y) * 2048.f),
-                                          (_Float16)((v.z - (float)hi.z) * 2048.f), (_Float16)((v.w - (float)hi.w) * 2048.f)};
+                        f16x4 hi, lo;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            _Float16 h, l;
+                            split_f16x3(v[q], h, l);
+                            hi[q] = h;
+                            lo[q] = l;
+                        }
                         const int cw = offb[t] >> 2;                                  // column inside the window
                         const int so = offy[t] - offb[t] + (cw >> 5) * 128 + (cw & 31) * 2;   // row part + block + slot
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rs_y[half], so, 0, 0);
@@ -720,9 +725,14 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(const GemmArgs g
             if (MODE == 2) v = rv + g.alpha * v;
             if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) v = g.alpha * v;
             if (g.out_split) {
-                const f16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-                const f16x4 lo = {(_Float16)((v.x - (float)hi.x) * 2048.f), (_Float16)((v.y - (float)hi.y) * 2048.f),
-                                  (_Float16)((v.z - (float)hi.z) * 2048.f), (_Float16)((v.w - (float)hi.w) * 2048.f)};
+                f16x4 hi, lo;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    _Float16 h, l;
+                    split_f16x3(v[q], h, l);
+                    hi[q] = h;
+                    lo[q] = l;
+                }
                 _Float16* yr = reinterpret_cast<_Float16*>(g.Y + row * g.ldy) + (col >> 5) * 64 + (col & 31);
                 *reinterpret_cast<f16x4*>(yr) = hi;
                 *reinterpret_cast<f16x4*>(yr + 32) = lo;
@@ -899,9 +909,14 @@ __global__ __launch_bounds__(256) void split_f16x3_kernel(const float* __restric
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-    const f16x4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-    const f16x4 lo = {(_Float16)((v.x - (float)hi.x) * 2048.f), (_Float16)((v.y - (float)hi.y) * 2048.f),
-                      (_Float16)((v.z - (float)hi.z) * 2048.f), (_Float16)((v.w - (float)hi.w) * 2048.f)};
+    f16x4 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        _Float16 h, l;
+        split_f16x3(v[q], h, l);
+        hi[q] = h;
+        lo[q] = l;
+    }
     // element index e = 4 i inside a row-major [rows, K] array with K % 32 == 0: block e / 32 (64 halves), slot e % 32
     const int64_t e = 4 * i;
     _Float16* o = out + (e >> 5) * 64 + (e & 31);

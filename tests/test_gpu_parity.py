@@ -131,6 +131,66 @@ def test_linear_never_writes_past_the_last_row(M, N, K, mode):
     assert float((y.double() - ref).abs().max()) < 2e-5 * max(1.0, K ** 0.5 / 8)
 
 
+def _np_split(x):
+    """host statement of the fp16x3 operand format (include/tal_asrd.h): per row and 32-wide K block, 32 hi halves
+    then 32 lo halves, hi = fp16(x), lo = fp16((x - hi) * 2^11)."""
+    rows, K = x.shape
+    hi = np.clip(x, -65504.0, 65504.0).astype(np.float16)
+    lo = np.clip((x - hi.astype(np.float32)) * np.float32(2048.0), -65504.0, 65504.0).astype(np.float16)
+    out = np.empty((rows, K // 32, 64), dtype=np.float16)
+    out[:, :, :32] = hi.reshape(rows, K // 32, 32)
+    out[:, :, 32:] = lo.reshape(rows, K // 32, 32)
+    return out
+
+
+def test_split_f16x3_format_is_bit_exact():
+    from tal_asrd_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(777, 160, generator=g) * torch.logspace(-6, 6, 160)).contiguous()   # incl. values past the fp16 range
+    got = ops.split_f16x3(x.to(dev())).cpu().numpy().view(np.float16).reshape(777, 5, 64)
+    np.testing.assert_array_equal(got.view(np.uint16), _np_split(x.numpy()).view(np.uint16))
+
+
+@pytest.mark.parametrize("M,C,K", [(70000, 320, 256), (66000 + 55, 160, 1440), (1000 + 17, 800, 800), (44983, 1440, 1440)])
+def test_linear_f16x3_pair_matches_fp64(M, C, K):
+    """The two dense layers of a TDSBlock in the fp16x3 form (relu layer writing its output pre-split, residual layer
+    reading it): against float64, with the tolerance of the fp32 path, guard rows untouched, bitwise repeatable."""
+    import ctypes as CT
+    from tal_asrd_amd import ops, _native as N_
+    lib = N_.lib()
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, K, generator=g).to(dev())
+    w0 = (torch.randn(C, K, generator=g) / K ** 0.5).to(dev())
+    b0 = torch.randn(C, generator=g).to(dev())
+    w1 = (torch.randn(K, C, generator=g) / C ** 0.5).to(dev())
+    b1 = torch.randn(K, generator=g).to(dev())
+    xs, w0s, w1s = ops.split_f16x3(x), ops.split_f16x3(w0), ops.split_f16x3(w1)
+    nws = lib.tal_linear_workspace_bytes(M, C, K)
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev())
+    guard = 5
+    hs = torch.full(((M + guard) * C * 4,), 0x5A, dtype=torch.uint8, device=dev())
+    yfull = torch.full((M + guard, K), 4321.0, device=dev())
+    def run():
+        N_.check(lib.tal_linear_f16x3_fwd(N_.ptr(xs), N_.ptr(w0s), N_.ptr(b0), None, 0.0, 1, M, C, K, N_.ptr(hs), 1, N_.ptr(ws), nws,
+                                          N_.stream_handle()), "tal_linear_f16x3_fwd")
+        N_.check(lib.tal_linear_f16x3_fwd(N_.ptr(hs), N_.ptr(w1s), N_.ptr(b1), N_.ptr(x), 0.3, 2, M, K, C, N_.ptr(yfull), 0, N_.ptr(ws), nws,
+                                          N_.stream_handle()), "tal_linear_f16x3_fwd")
+        torch.cuda.synchronize()
+        return yfull[:M].clone()
+    y1 = run()
+    y2 = run()
+    assert torch.equal(y1, y2)
+    assert bool((hs[M * C * 4:] == 0x5A).all()) and bool((yfull[M:] == 4321.0).all())
+    h = torch.relu(x.double() @ w0.double().t() + b0.double())
+    ref = x.double() + 0.3 * (h @ w1.double().t() + b1.double())
+    err = float((y1.double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, max(K, C) ** 0.5 / 8), err
+    # the hidden activations, decoded from the split form
+    hsp = hs[:M * C * 4].cpu().numpy().view(np.float16).reshape(M, C // 32, 64).astype(np.float32)
+    hdec = (hsp[:, :, :32] + hsp[:, :, 32:] / 2048.0).reshape(M, C)
+    assert float(np.abs(hdec - h.cpu().numpy()).max()) < 2e-5 * max(1.0, K ** 0.5 / 8)
+
+
 def test_linear_identity_asymmetric():
     """A = I against an asymmetric W catches a transposed C write."""
     from tal_asrd_amd import ops

@@ -40,7 +40,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const float* __restr
     const int n0 = (int)(tile % (unsigned)tiles_n) * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sub = lane >> 3, srccol = ((lane & 7) ^ sub) * 4;     // in floats (16-byte slots), as the fp32 kernel
+    // LDS row r keeps its logical 16-byte slot s at physical slot s ^ ((r >> 1) & 7): 16 consecutive rows then cover all
+    // 64 banks (gfx950 serves a ds_read_b128 sixteen lanes at a time; the (r & 7) form of CDNA3 leaves a 2-way conflict)
+    const int sub = lane >> 3, srccol = ((lane & 7) ^ (((w & 1) * 4 + (lane >> 4)) & 7)) * 4;
     const int a_rows = (int)((M - m0) < BM ? (M - m0) : BM) - 1;
     const int b_rows = ((N - n0) < BN ? (N - n0) : BN) - 1;
     auto uptr = [](const float* p) {
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const float* __restr
     for (int j = 0; j < NSUB; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) hh[j][e] = xx[j][e] = 0.f;
-    const int frow = lane & 31, fsw = frow & 7, fhalf = lane >> 5;
+    const int frow = lane & 31, fsw = (frow >> 1) & 7, fhalf = lane >> 5;
     const int nk = K / BK;
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -79,17 +81,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const float* __restr
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const float* Asl = lds + (kt & 1) * (ROWS * 32) + (w * 32 + frow) * 32;
         const float* Bsl = lds + (kt & 1) * (ROWS * 32) + (BM + frow) * 32;
+        // flattened (g, j) stages q = 5 g + j: stage q issues the B fragments of stage q + 2 (and the A fragments of the
+        // next g at q = 3) before its three MFMAs, so every LDS read has ~200 cycles of MFMA work between issue and use
+        h8 ahi[2], alo[2], bhi[3], blo[3];
+        auto sl_hi = [&](int g) { return ((2 * g + fhalf) ^ fsw) * 4; };
+        auto sl_lo = [&](int g) { return ((4 + 2 * g + fhalf) ^ fsw) * 4; };
+        auto readB = [&](int q, int slot) {
+            const int g = q / 5, j = q % 5;
+            bhi[slot] = *reinterpret_cast<const h8*>(Bsl + j * 32 * 32 + sl_hi(g));
+            blo[slot] = *reinterpret_cast<const h8*>(Bsl + j * 32 * 32 + sl_lo(g));
+        };
+        ahi[0] = *reinterpret_cast<const h8*>(Asl + sl_hi(0));
+        alo[0] = *reinterpret_cast<const h8*>(Asl + sl_lo(0));
+        readB(0, 0);
+        readB(1, 1);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {            // 16 k per MFMA: slots 2g + half (hi) and 4 + 2g + half (lo)
-            const int sh = ((2 * g + fhalf) ^ fsw) * 4, sl = ((4 + 2 * g + fhalf) ^ fsw) * 4;
-            const h8 ahi = *reinterpret_cast<const h8*>(Asl + sh), alo = *reinterpret_cast<const h8*>(Asl + sl);
-#pragma unroll
-            for (int j = 0; j < NSUB; ++j) {
-                const h8 bhi = *reinterpret_cast<const h8*>(Bsl + j * 32 * 32 + sh), blo = *reinterpret_cast<const h8*>(Bsl + j * 32 * 32 + sl);
-                hh[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, hh[j], 0, 0, 0);
-                xx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, xx[j], 0, 0, 0);
-                xx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, xx[j], 0, 0, 0);
+        for (int q = 0; q < 10; ++q) {
+            const int g = q / 5, j = q % 5;
+            if (q + 2 < 10) readB(q + 2, (q + 2) % 3);
+            if (q == 3) {
+                ahi[1] = *reinterpret_cast<const h8*>(Asl + sl_hi(1));
+                alo[1] = *reinterpret_cast<const h8*>(Asl + sl_lo(1));
             }
+            __builtin_amdgcn_sched_barrier(0);
+            hh[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[g], bhi[q % 3], hh[j], 0, 0, 0);
+            xx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[g], blo[q % 3], xx[j], 0, 0, 0);
+            xx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[g], bhi[q % 3], xx[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     const int colb = lane & 31, rowb = 4 * (lane >> 5);

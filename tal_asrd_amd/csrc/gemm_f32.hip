@@ -250,8 +250,9 @@ __device__ __forceinline__ unsigned logical_tile() { return logical_tile_of(grid
 // ---------------------------------------------------------------------------------------------
 // hot kernel: direct-to-LDS operand loads, double buffer, one barrier per K step
 // ---------------------------------------------------------------------------------------------
+// (the fp16x3 form carries two accumulator sets: it is held to 256 registers = 2 workgroups per CU explicitly)
 template <int MODE, int NSUB, bool SPLITK, int STAGE, bool F16X3 = false>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, F16X3 ? 2 : 1) void gemm_glds_kernel(const GemmArgs g) {
     // Set-up and epilogue are short VALU / memory sequences; the co-resident workgroup is usually deep in
     // its MFMA loop, and at equal priority every one of these instructions queues behind a 64-cycle MFMA.
     __builtin_amdgcn_s_setprio(3);
@@ -286,11 +287,14 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
     const int wm = w, wn = 0;
 
     // Wave w loads chunks i = w + 4t.  A chunk is 8 rows x 128 B; lane l lands at LDS byte
-    // i*1024 + l*16 = row (8i + l/8), 16-byte slot (l%8).  Slot s of row r holds the row's logical
-    // 16-byte column s ^ (r & 7) (= s ^ (l >> 3), a per-lane constant): the swizzle is applied to
-    // the global source address, the LDS destination stays linear as the instruction requires.
-    const int sub = lane >> 3;                    // row inside the chunk == row & 7
-    const int srccol = ((lane & 7) ^ sub) * 4;    // logical float column this lane fetches
+    // i*1024 + l*16 = row r = 8i + l/8, 16-byte slot l%8.  Slot s of row r holds the row's logical
+    // 16-byte column s ^ ((r >> 1) & 7): the swizzle is applied to the global source address, the LDS
+    // destination stays linear as the instruction requires.  gfx950 serves a ds_read_b128 sixteen
+    // lanes (256 bytes, 64 banks) at a time: with (r >> 1) & 7 sixteen consecutive rows cover all 64
+    // banks (SQ_LDS_BANK_CONFLICT = 0); the (r & 7) form, enough for 8-lane phases, measured 50 %
+    // conflict cycles.  (r >> 1) & 7 = (4 (i & 1) + (l >> 4)) & 7, and i & 1 = w & 1: a per-lane constant.
+    const int sub = lane >> 3;                    // row inside the chunk
+    const int srccol = ((lane & 7) ^ (((w & 1) * 4 + (lane >> 4)) & 7)) * 4;    // logical float column this lane fetches
     const int a_rows = (int)((M - m0) < BM ? (M - m0) : BM) - 1;
     const int b_rows = ((N - n0) < BN ? (N - n0) : BN) - 1;
     const float* src[PER_WAVE];
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
 
     // fragment read: row (l & 31) of a 32-row block, logical 16-byte column 2*kk + (l >> 5)
     const int frow = lane & 31;
-    const int fsw = frow & 7;
+    const int fsw = (frow >> 1) & 7;
     const int fhalf = lane >> 5;
     const int nk_all = K / BK;
     const int kt0 = is_slice ? (int)((int64_t)slice * nk_all / g.split) : 0;
@@ -368,18 +372,34 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs g) {
             // operands are hi/lo fp16 splits: a 128-byte row of this K block is [32 hi | 32 lo]; one MFMA takes 16 k,
             // lanes < 32 the first 8 and lanes >= 32 the next 8: 16-byte slot 2g + half (hi), 4 + 2g + half (lo).
             // a.w = sum hi*hi + 2^-11 sum (hi*lo + lo*hi), fp32 accumulation; lo*lo (2^-22 relative) is dropped.
+            // Flattened (gk, j) stages q = NSUB gk + j: stage q issues the B fragments of stage q + 2 (and the A
+            // fragments of the next gk) before its three MFMAs -- an MFMA is only 32 cycles here, and with two
+            // waves per SIMD every LDS read needs ~200 cycles of issued matrix work between issue and use.
+            f16x8 ahi[2], alo[2], bhi[3], blo[3];
+            auto slh = [&](int gk) { return ((2 * gk + fhalf) ^ fsw) * 4; };
+            auto sll = [&](int gk) { return ((4 + 2 * gk + fhalf) ^ fsw) * 4; };
+            auto read_b = [&](int q, int slot) {
+                const int gk = q / NSUB, j = q % NSUB;
+                bhi[slot] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * 32 + slh(gk));
+                blo[slot] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * 32 + sll(gk));
+            };
+            ahi[0] = *reinterpret_cast<const f16x8*>(As + slh(0));
+            alo[0] = *reinterpret_cast<const f16x8*>(As + sll(0));
+            read_b(0, 0);
+            read_b(1, 1);
 #pragma unroll
-            for (int gk = 0; gk < 2; ++gk) {
-                const int sh = ((2 * gk + fhalf) ^ fsw) * 4, sl = ((4 + 2 * gk + fhalf) ^ fsw) * 4;
-                const f16x8 ahi = *reinterpret_cast<const f16x8*>(As + sh), alo = *reinterpret_cast<const f16x8*>(As + sl);
-#pragma unroll
-                for (int j = 0; j < NSUB; ++j) {
-                    const f16x8 bhi = *reinterpret_cast<const f16x8*>(Bs + j * 32 * 32 + sh);
-                    const f16x8 blo = *reinterpret_cast<const f16x8*>(Bs + j * 32 * 32 + sl);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[j], 0, 0, 0);
-                    accx[F16X3 ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, accx[F16X3 ? j : 0], 0, 0, 0);
-                    accx[F16X3 ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, accx[F16X3 ? j : 0], 0, 0, 0);
+            for (int q = 0; q < 2 * NSUB; ++q) {
+                const int gk = q / NSUB, j = q % NSUB;
+                if (q + 2 < 2 * NSUB) read_b(q + 2, (q + 2) % 3);
+                if (q == NSUB - 2) {
+                    ahi[1] = *reinterpret_cast<const f16x8*>(As + slh(1));
+                    alo[1] = *reinterpret_cast<const f16x8*>(As + sll(1));
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[gk], bhi[q % 3], acc[j], 0, 0, 0);
+                accx[F16X3 ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[gk], blo[q % 3], accx[F16X3 ? j : 0], 0, 0, 0);
+                accx[F16X3 ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[gk], bhi[q % 3], accx[F16X3 ? j : 0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             continue;
         }

@@ -37,8 +37,8 @@ __global__ __launch_bounds__(256, 2) void head_argmax_kernel(const float* __rest
     const int64_t u0 = (int64_t)blockIdx.x * U / G, u1 = ((int64_t)blockIdx.x + 1) * U / G;
     if (u0 >= u1) return;
     const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
-    const int frow = lane & 31, fsw = frow & 7, fhalf = lane >> 5;
-    const int sub = lane >> 3, srccol = ((lane & 7) ^ sub) * 4;
+    const int frow = lane & 31, fsw = (frow >> 1) & 7, fhalf = lane >> 5;     // swizzle: see gemm_glds_kernel
+    const int sub = lane >> 3, srccol = ((lane & 7) ^ (((w & 1) * 4 + (lane >> 4)) & 7)) * 4;
 
     // W: one descriptor over the whole matrix; rows past S read as 0 (their columns are masked below)
     __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(W), 0, S * HK * 4, 0x00020000);

@@ -115,6 +115,17 @@ int tal_gconv_s2_fwd(const float* x, const float* w_packed, const float* bias, i
 int tal_gconv_res_fwd(const float* x, const float* w_packed, const float* bias, float alpha, int B,
                       int64_t T, int C, int groups, float* y, void* stream);
 
+/* The same TDSBlock conv (tal/asr/models.py:304-308,329) on the fp16 matrix cores in the fp16x3 form of the dense
+ * layers (three fp16 MFMAs per fp32 product block, fp32 accumulation; error against float64 below an fp32 fmaf chain).
+ * Built for C / groups = 10, 14, 18 with groups % 4 == 0 (tal_gconv_f16x3_weight_bytes returns 0 otherwise).
+ * tal_pack_gconv_f16x3_weight: reference Conv1d weight [C, C/G, 21] -> MFMA operand fragments (hi / lo halves).
+ * tal_gconv_res_f16x3_fwd: y = x + alpha * relu(conv(x) + b); y_split != NULL additionally receives y as the hi / lo
+ * split the fp16x3 dense layers consume (tal_split_f16x3_fwd's format; C % 32 == 0), fused into the store. */
+size_t tal_gconv_f16x3_weight_bytes(int C, int groups);
+int tal_pack_gconv_f16x3_weight(const float* w_ref, void* w_frag, int C, int groups, void* stream);
+int tal_gconv_res_f16x3_fwd(const float* x, const void* w_frag, const float* bias, float alpha, int B,
+                            int64_t T, int C, int groups, float* y, void* y_split, void* stream);
+
 /* ------------------------------------------------------------------ *
  * Whole TDS encoder: TDS.forward, tal/asr/models.py:349-397 (+TDSBlock :298-331)
  * ------------------------------------------------------------------ */
@@ -129,6 +140,8 @@ typedef struct tal_tds_block_w {
     int32_t _pad;
     const void* fc0_w_split; /* fc.0.weight / fc.3.weight as hi/lo fp16 splits (tal_split_f16x3_fwd), or NULL: */
     const void* fc3_w_split; /* with both present the block's dense layers run in the fp16x3 form for M > 512   */
+    const void* conv_w_frag; /* conv.0.weight as fp16x3 MFMA fragments (tal_pack_gconv_f16x3_weight), or NULL: with it
+                              * (and the two splits above) the grouped conv runs on the matrix cores for M > 512     */
 } tal_tds_block_w;
 
 typedef struct tal_tds_desc {

@@ -23,6 +23,13 @@ for T, cg in ((179991, 10), (89986, 14), (44983, 18)):
     wp = ops.pack_gconv_weight(w, G)
     ms = timeit(lambda: ops.gconv_res(x, wp, b, 0.25, G))
     print("gconv_res T=%6d C=%4d: %.3f ms  %.1f TFLOP/s  (%.0f GB/s algorithmic)" % (T, C, ms, 2.0 * T * C * cg * 21 / ms / 1e9, 2 * T * C * 4 / ms / 1e6))
+    wf = ops.pack_gconv_f16x3_weight(w, G)
+    for split in (False, True):
+        ms = timeit(lambda: ops.gconv_res_f16x3(x, wf, b, 0.25, G, want_split=split))
+        print("gconv_res_f16x3 (matrix cores%s) T=%6d C=%4d: %.3f ms  %.1f TFLOP/s fp32-equivalent" % (", + split output" if split else "", T, C, ms, 2.0 * T * C * cg * 21 / ms / 1e9))
+    x0 = torch.zeros_like(x)
+    ms = timeit(lambda: ops.gconv_res_f16x3(x0, wf, b, 0.25, G, want_split=True))
+    print("   ... on all-zero input: %.3f ms" % ms)
 for T, cin, cout in ((360001, 1, 10), (179991, 10, 14), (89986, 14, 18)):
     x = torch.randn(1, T, G * cin, device=dev)
     w = torch.randn(G * cout, cin, 21, device=dev)

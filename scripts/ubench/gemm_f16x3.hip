@@ -33,7 +33,7 @@ __global__ void split_kernel(const float* __restrict__ x, _Float16* __restrict__
 constexpr int BM = 128, NSUB = 5, BN = 32 * NSUB, ROWS = BM + BN, BK = 32;
 
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const float* __restrict__ As, const float* __restrict__ Ws,
-                                                           float* __restrict__ C, int64_t M, int N, int K, int tiles_n) {
+                                                           float* __restrict__ C, int64_t M, int N, int K, int tiles_n, long long* clk) {
     __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * 32];
     const unsigned tile = blockIdx.x;
     const int64_t m0 = (int64_t)(tile / (unsigned)tiles_n) * BM;
@@ -75,24 +75,40 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const float* __restr
         for (int e = 0; e < 16; ++e) hh[j][e] = xx[j][e] = 0.f;
     const int frow = lane & 31, fsw = (frow >> 1) & 7, fhalf = lane >> 5;
     const int nk = K / BK;
+    const long long c0 = clock64(), w0 = wall_clock64();
     issue(0, 0);
+    // ABL (ablation bitmask, timing only -- results are wrong): 1 = no operand loads inside the loop, 2 = fragment
+    // reads do not depend on kt (the compiler hoists them), 4 = no barrier
+#ifndef ABL
+#define ABL 0
+#endif
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const float* Asl = lds + (kt & 1) * (ROWS * 32) + (w * 32 + frow) * 32;
-        const float* Bsl = lds + (kt & 1) * (ROWS * 32) + (BM + frow) * 32;
+        if (!(ABL & 4)) __syncthreads();
+        if (!(ABL & 1) && kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const int kb = (ABL & 2) ? 0 : (kt & 1);
+        const float* Asl = lds + kb * (ROWS * 32) + (w * 32 + frow) * 32;
+        const float* Bsl = lds + kb * (ROWS * 32) + (BM + frow) * 32;
         // flattened (g, j) stages q = 5 g + j: stage q issues the B fragments of stage q + 2 (and the A fragments of the
         // next g at q = 3) before its three MFMAs, so every LDS read has ~200 cycles of MFMA work between issue and use
         h8 ahi[2], alo[2], bhi[3], blo[3];
+#if ABL & 8
+        for (int i = 0; i < 8; ++i) {     // fragments from registers: no LDS reads at all
+            ahi[0][i] = ahi[1][i] = (_Float16)(float)lane; alo[0][i] = alo[1][i] = (_Float16)(float)(lane + i);
+            for (int t = 0; t < 3; ++t) { bhi[t][i] = (_Float16)(float)(t + i); blo[t][i] = (_Float16)(float)(t * lane); }
+        }
+#define RD(dst, src) asm volatile("" : "+v"(dst))
+#else
+#define RD(dst, src) dst = src
+#endif
         auto sl_hi = [&](int g) { return ((2 * g + fhalf) ^ fsw) * 4; };
         auto sl_lo = [&](int g) { return ((4 + 2 * g + fhalf) ^ fsw) * 4; };
         auto readB = [&](int q, int slot) {
             const int g = q / 5, j = q % 5;
-            bhi[slot] = *reinterpret_cast<const h8*>(Bsl + j * 32 * 32 + sl_hi(g));
-            blo[slot] = *reinterpret_cast<const h8*>(Bsl + j * 32 * 32 + sl_lo(g));
+            RD(bhi[slot], *reinterpret_cast<const h8*>(Bsl + j * 32 * 32 + sl_hi(g)));
+            RD(blo[slot], *reinterpret_cast<const h8*>(Bsl + j * 32 * 32 + sl_lo(g)));
         };
-        ahi[0] = *reinterpret_cast<const h8*>(Asl + sl_hi(0));
-        alo[0] = *reinterpret_cast<const h8*>(Asl + sl_lo(0));
+        RD(ahi[0], *reinterpret_cast<const h8*>(Asl + sl_hi(0)));
+        RD(alo[0], *reinterpret_cast<const h8*>(Asl + sl_lo(0)));
         readB(0, 0);
         readB(1, 1);
 #pragma unroll
@@ -100,8 +116,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const float* __restr
             const int g = q / 5, j = q % 5;
             if (q + 2 < 10) readB(q + 2, (q + 2) % 3);
             if (q == 3) {
-                ahi[1] = *reinterpret_cast<const h8*>(Asl + sl_hi(1));
-                alo[1] = *reinterpret_cast<const h8*>(Asl + sl_lo(1));
+                RD(ahi[1], *reinterpret_cast<const h8*>(Asl + sl_hi(1)));
+                RD(alo[1], *reinterpret_cast<const h8*>(Asl + sl_lo(1)));
             }
             __builtin_amdgcn_sched_barrier(0);
             hh[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[g], bhi[q % 3], hh[j], 0, 0, 0);
@@ -109,6 +125,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const float* __restr
             xx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[g], bhi[q % 3], xx[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if (clk && tid == 0 && blockIdx.x < 8192) {      // effective shader clock of the K loop: s_memtime ticks per 100 MHz wall tick
+        clk[2 * blockIdx.x] = (long long)(clock64() - c0);
+        clk[2 * blockIdx.x + 1] = (long long)(wall_clock64() - w0);
     }
     const int colb = lane & 31, rowb = 4 * (lane >> 5);
 #pragma unroll
@@ -136,6 +156,9 @@ static void run(int64_t M, int N, int K, bool check) {
     (void)hipMalloc(&as, ha.size() * 4);
     (void)hipMalloc(&ws, hw.size() * 4);
     (void)hipMalloc(&c, (size_t)M * N * 4);
+    long long* clk;
+    (void)hipMalloc(&clk, 16384 * 8);
+    (void)hipMemset(clk, 0, 16384 * 8);
     (void)hipMemcpy(a, ha.data(), ha.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(wt, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(split_kernel, dim3((unsigned)((ha.size() + 255) / 256)), dim3(256), 0, 0, a, as, M, K);
@@ -146,14 +169,23 @@ static void run(int64_t M, int N, int K, bool check) {
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     float best = 1e9;
-    for (int rep = 0; rep < (check ? 1 : 5); ++rep) {
+    for (int rep = 0; rep < (check ? 1 : 40); ++rep) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL(gemm_f16x3_kernel, dim3(grid), dim3(256), 0, 0, (const float*)as, (const float*)ws, c, M, N, K, tiles_n);
+        hipLaunchKernelGGL(gemm_f16x3_kernel, dim3(grid), dim3(256), 0, 0, (const float*)as, (const float*)ws, c, M, N, K, tiles_n, clk);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms;
         (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
+    }
+    {
+        std::vector<long long> hclk(16384);
+        (void)hipMemcpy(hclk.data(), clk, 16384 * 8, hipMemcpyDeviceToHost);
+        double cs = 0, wsum = 0;
+        const int nt = grid < 8192 ? (int)grid : 8192;
+        for (int i = 0; i < nt; ++i) { cs += (double)hclk[2 * i]; wsum += (double)hclk[2 * i + 1]; }
+        if (!check) printf("  K loop, mean over %d tiles: %.0f shader cycles, %.2f us -> %.2f GHz effective; %.0f cycles per K step\n",
+                           nt, cs / nt, wsum / nt / 100.0, cs / wsum / 10.0, cs / nt / (K / 32));
     }
     printf("M=%lld N=%d K=%d: %.3f ms  %.1f fp32-equivalent TFLOP/s (%s)\n", (long long)M, N, K, best, 2.0 * M * N * K / best / 1e9,
            hipGetErrorString(hipGetLastError()));

@@ -19,7 +19,7 @@ c_float_p = C.c_void_p  # device pointers travel as integers
 class TdsBlockW(C.Structure):
     _fields_ = [("conv_w", C.c_void_p), ("conv_b", C.c_void_p), ("fc0_w", C.c_void_p), ("fc0_b", C.c_void_p),
                 ("fc3_w", C.c_void_p), ("fc3_b", C.c_void_p), ("resweight", C.c_float), ("_pad", C.c_int32),
-                ("fc0_w_split", C.c_void_p), ("fc3_w_split", C.c_void_p)]
+                ("fc0_w_split", C.c_void_p), ("fc3_w_split", C.c_void_p), ("conv_w_frag", C.c_void_p)]
 
 
 class TdsDesc(C.Structure):
@@ -55,6 +55,9 @@ SIGNATURES = {
     "tal_pack_gconv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "tal_gconv_s2_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _p, _p]),
     "tal_gconv_res_fwd": (_i, [_p, _p, _p, _f, _i, _i64, _i, _i, _p, _p]),
+    "tal_gconv_f16x3_weight_bytes": (C.c_size_t, [_i, _i]),
+    "tal_pack_gconv_f16x3_weight": (_i, [_p, _p, _i, _i, _p]),
+    "tal_gconv_res_f16x3_fwd": (_i, [_p, _p, _p, _f, _i, _i64, _i, _i, _p, _p, _p]),
     "tal_tds_out_len": (_i64, [C.POINTER(TdsDesc), _i64]),
     "tal_tds_workspace_bytes": (_sz, [C.POINTER(TdsDesc), _i, _i64]),
     "tal_tds_fwd": (_i, [C.POINTER(TdsDesc), _p, _i, _i64, _p, _p, _sz, _p]),

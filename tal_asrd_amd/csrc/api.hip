@@ -206,6 +206,17 @@ extern "C" int tal_gconv_res_fwd(const float* x, const float* w_packed, const fl
     return launch_gconv_res(x, w_packed, bias, alpha, B, T, C, groups, y, (hipStream_t)stream);
 }
 
+extern "C" size_t tal_gconv_f16x3_weight_bytes(int C, int groups) { return gconv_f16x3_weight_bytes(C, groups); }
+
+extern "C" int tal_pack_gconv_f16x3_weight(const float* w_ref, void* w_frag, int C, int groups, void* stream) {
+    return launch_pack_gconv_f16x3(w_ref, w_frag, C, groups, (hipStream_t)stream);
+}
+
+extern "C" int tal_gconv_res_f16x3_fwd(const float* x, const void* w_frag, const float* bias, float alpha, int B,
+                                       int64_t T, int C, int groups, float* y, void* y_split, void* stream) {
+    return launch_gconv_res_f16x3(x, w_frag, bias, alpha, B, T, C, groups, y, y_split, (hipStream_t)stream);
+}
+
 extern "C" int tal_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, void* stream) {
     return launch_argmax_rows(x, M, N, ids, (hipStream_t)stream);
 }
@@ -286,13 +297,21 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
             float* h = buf[(ia + 2) % 4];
             float* x1s = buf[(ia + 3) % 4];
             float* outp = (last_stage && j == d->depths[i] - 1) ? y : buf[ia];
-            // x1 = x + rw * relu(gconv(x))            : a -> x1
-            rc = launch_gconv_res(a, bw.conv_w, bw.conv_b, bw.resweight, B, To, c, d->groups, x1, s);
-            if (rc) return rc;
             const bool f16x3 = !force_f32 && bw.fc0_w_split && bw.fc3_w_split && M > 512 && c % 160 == 0;
+            const bool conv_mfma = f16x3 && bw.conv_w_frag && gconv_f16x3_weight_bytes(c, d->groups) > 0;
+            // x1 = x + rw * relu(gconv(x))            : a -> x1
+            // (The matrix-core kernel can also emit x1 as the hi / lo split; measured on the 1-hour shapes that fused store
+            //  costs +0.35 / +0.21 / +0.14 ms per launch -- 8-byte pieces that fill 32-byte sectors only partially -- against
+            //  0.20 / 0.12 / 0.09 ms for the separate, fully coalesced split pass, so the driver keeps the pass.)
+            static const bool fuse_split = getenv("TAL_GCONV_FUSE_SPLIT") != nullptr;
+            if (conv_mfma)
+                rc = launch_gconv_res_f16x3(a, bw.conv_w_frag, bw.conv_b, bw.resweight, B, To, c, d->groups, x1, fuse_split ? x1s : nullptr, s);
+            else
+                rc = launch_gconv_res(a, bw.conv_w, bw.conv_b, bw.resweight, B, To, c, d->groups, x1, s);
+            if (rc) return rc;
             if (f16x3) {
                 // the two dense layers in the fp16x3 form: x1 is split once, fc0 writes its output already split
-                rc = launch_split_f16x3(x1, x1s, M, c, s);
+                if (!(conv_mfma && fuse_split)) rc = launch_split_f16x3(x1, x1s, M, c, s);
                 if (rc) return rc;
                 rc = launch_linear_f16x3(x1s, bw.fc0_w_split, bw.fc0_b, nullptr, 0.f, 1, M, c, c, h, 1, skws, gemm_splitk_ws_bytes(), s);
                 if (rc) return rc;

@@ -224,6 +224,302 @@ int launch_gconv_res(const float* x, const float* wp, const float* bias, float a
     return launch_generic<true>(x, wp, bias, alpha, y, B, T, T, C, C, groups, 1, s);
 }
 
+// ---------------------------------------------------------------------------------------------
+// TDSBlock grouped conv on the fp16 matrix cores (fp16x3 form, as the dense layers of the block)
+// ---------------------------------------------------------------------------------------------
+// Per group the conv is a small GEMM  out[co, t] = sum_k W[co, k] X[k, t],  k = tap * P + ci,
+// X[k, t] = x[t + tap - 10][ci].  The group's input slab sits in LDS TIME-major with row pitch P halves
+// ([t][P], hi and lo arrays), so column t of X is simply the 21 * P consecutive halves that start at
+// slab[t * P] (a Hankel matrix): one MFMA operand fragment (8 consecutive k of one column) is one LDS
+// read, no im2col.  M = output channels (weights: register-resident MFMA A fragments, zero rows past
+// CG, zero columns for the P - CG pad channels and past the last tap), N = 16 time steps, K rounded up
+// to 32.  v_mfma_f32_16x16x32_f16 x 3 per product block (hi*hi, hi*lo, lo*hi; fp32 accumulate, three
+// independent accumulators).  The C layout hands a lane 4 consecutive channels of one time step: the
+// residual is one 16-byte load (fetched three blocks ahead: an L2 round trip outlasts a block), the
+// output one 16-byte store, plus -- fused -- the hi / lo split of the output that the next dense layer
+// consumes (saves the separate split pass: 8 bytes per element of HBM traffic).
+// Measured (scripts/ubench/gconv_mfma.hip, 1-hour shapes): 0.60 / 0.33 / 0.31 ms per launch against
+// 0.65 / 0.59 / 0.54 for the VALU kernel above; max error against float64 5e-7 (values of a few units).
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef _Float16 f16x8u __attribute__((ext_vector_type(8), aligned(4)));
+typedef _Float16 f16x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// LDS row pitch (halves) per channels-per-group; 0 = no MFMA kernel for this width.  16 / 24: 16-byte aligned
+// fragments (one ds_read_b128; P = 16 is bank-conflict-free); 10: compact (two ds_read2_b32, fewest MFMAs).
+static inline int gconv_mfma_pitch(int cg) { return cg == 10 ? 10 : cg == 14 ? 16 : cg == 18 ? 24 : 0; }
+static inline int gconv_mfma_nks(int cg) { return ((KS - 1) * gconv_mfma_pitch(cg) + cg + 31) / 32; }
+
+template <int P>
+__device__ __forceinline__ f16x8 gconv_frag(const _Float16* p) {
+    if (P % 8 == 0) return *reinterpret_cast<const f16x8*>(p);
+    return *reinterpret_cast<const f16x8u*>(p);
+}
+
+template <int CG, int P, int GB, int TT, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restrict__ x, const _Float16* __restrict__ wfrag,
+                                                           const float* __restrict__ bias, float alpha, float* __restrict__ y,
+                                                           _Float16* __restrict__ ysplit, int64_t T, int C) {
+    constexpr int KTOT = (KS - 1) * P + CG, NKS = (KTOT + 31) / 32, MT = (CG + 15) / 16;
+    constexpr int PADT = KS / 2;
+    constexpr int TIN = TT + 2 * PADT;
+    constexpr int SLAB = (TIN * P + (32 * NKS > KS * P ? 32 * NKS - KS * P : 0) + 7) & ~7;
+    constexpr int CH = GB * CG, CH4 = CH / 4;
+    constexpr int RPP = 256 / CH4;                    // time steps per pass of the slab load
+    static_assert(CH % 4 == 0 && CG % 2 == 0 && TT % 64 == 0 && P % 2 == 0 && P >= CG, "shape");
+    extern __shared__ __attribute__((aligned(16))) _Float16 slab[];   // [2 (hi, lo)][GB][SLAB]
+    _Float16* s_hi = slab;
+    _Float16* s_lo = slab + GB * SLAB;
+
+    const int b = blockIdx.z, g0 = blockIdx.y * GB;
+    const int64_t t0 = (int64_t)blockIdx.x * TT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = wave_id();
+    const float* xb = x + (int64_t)b * T * C;
+    float* yb = y + (int64_t)b * T * C;
+
+    // ---- slab load: thread = (time step inside a pass, 16-byte column piece): 16-byte global loads (GB*CG
+    // contiguous floats per time step), all passes in flight (at most two round trips), split, 4-byte LDS
+    // stores at per-thread constant offsets ----
+    {
+        const int r0 = tid / CH4, c4 = tid - r0 * CH4;
+        const bool active = r0 < RPP;
+        int so[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ch = c4 * 4 + 2 * q, gl = ch / CG;
+            so[q] = gl * SLAB + (ch - gl * CG);
+        }
+        const float* xc = xb + g0 * CG + (active ? c4 * 4 : 0);
+        constexpr int NPASS = (TIN + RPP - 1) / RPP, UNR = NPASS > 12 ? (NPASS + 1) / 2 : NPASS;
+        for (int p0 = 0; p0 < NPASS; p0 += UNR) {
+            f32x4 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int64_t t = t0 - PADT + r0 + (p0 + u) * RPP;
+                const int64_t tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+                v[u] = *reinterpret_cast<const f32x4*>(xc + tc * C);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int ti = r0 + (p0 + u) * RPP;
+                const int64_t t = t0 - PADT + ti;
+                const bool in = t >= 0 && t < T;          // zero padding at the true ends of the batch item
+                if (active && ti < TIN) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        _Float16 h0, l0, h1, l1;
+                        split_f16x3(in ? v[u][2 * q] : 0.f, h0, l0);
+                        split_f16x3(in ? v[u][2 * q + 1] : 0.f, h1, l1);
+                        const f16x2 hh = {h0, h1}, ll = {l0, l1};
+                        *reinterpret_cast<f16x2*>(s_hi + so[q] + ti * P) = hh;
+                        *reinterpret_cast<f16x2*>(s_lo + so[q] + ti * P) = ll;
+                    }
+                }
+            }
+        }
+        // zeros in the pad channels of every row and behind the last row (finite bytes under zero weights)
+        const f16x2 z2 = {(_Float16)0.f, (_Float16)0.f};
+        if (P > CG)
+            for (int i = tid; i < 2 * GB * TIN; i += 256)
+#pragma unroll
+                for (int c = CG; c < P; c += 2) *reinterpret_cast<f16x2*>(slab + (i / TIN) * SLAB + (i % TIN) * P + c) = z2;
+        for (int i = tid; i < GB * (SLAB - TIN * P); i += 256) {   // (2 GB arrays, two halves per store)
+            const int a = i / ((SLAB - TIN * P) / 2), r = i - a * ((SLAB - TIN * P) / 2);
+            *reinterpret_cast<f16x2*>(slab + a * SLAB + TIN * P + 2 * r) = z2;
+        }
+    }
+    __syncthreads();
+
+    // ---- units = (group, 16-channel M tile); a wave owns one unit (or a time slice of one) at a time ----
+    constexpr int NU = GB * MT, NB = TT / 16;
+    constexpr int UPW = NU >= 4 ? NU / 4 : 1;         // units per wave
+    constexpr int WPU = NU >= 4 ? 1 : 4 / NU;         // waves per unit
+    constexpr int NBW = NB / WPU;
+    static_assert(NU == 1 || NU == 2 || NU % 4 == 0, "units");
+    const int col = lane & 15, kg = lane >> 4;
+    for (int uu = 0; uu < UPW; ++uu) {
+        const int u = NU >= 4 ? w + 4 * uu : w / WPU;
+        const int part = NU >= 4 ? 0 : w % WPU;
+        const int gl = u / MT, mt = u - gl * MT, g = g0 + gl;
+        f16x8 wh[NKS], wl[NKS];
+        const f16x8* wf = reinterpret_cast<const f16x8*>(wfrag) + (int64_t)(g * MT + mt) * (NKS * 2 * 64) + lane;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            wh[ks] = wf[(ks * 2 + 0) * 64];
+            wl[ks] = wf[(ks * 2 + 1) * 64];
+        }
+        const int ch0 = mt * 16 + 4 * kg;
+        const int nvalid = CG - ch0;                  // >= 4: four channels, 2: two, <= 0: none
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nvalid) bv[i] = bias[g * CG + ch0 + i];
+        const _Float16* hs = s_hi + gl * SLAB + (part * NBW * 16 + col) * P + 8 * kg;
+        const _Float16* ls = s_lo + gl * SLAB + (part * NBW * 16 + col) * P + 8 * kg;
+        int boff = 0;
+        f16x8 c0h = gconv_frag<P>(hs), c0l = gconv_frag<P>(ls);
+        f16x8 c1h = gconv_frag<P>(hs + 32), c1l = gconv_frag<P>(ls + 32);
+        // residual x of block tb is fetched XD blocks ahead; the block loop is unrolled by XD + 1 so the ring of
+        // in-flight registers is indexed statically.  Branch-free: every lane loads 16 bytes; a lane with two valid
+        // channels loads from two floats earlier and keeps the upper half, a lane with none re-reads the group's first
+        // channels (all addresses stay inside the row); the choice is applied at the point of use, so no wait sits
+        // behind the load.
+        constexpr int XD = 3;
+        static_assert(NBW % (XD + 1) == 0, "blocks per wave");
+        const int tbeg = part * NBW, tend = (part + 1) * NBW;
+        const int cbase = g * CG + ch0;
+        const float* xcol = xb + cbase + (nvalid >= 4 ? 0 : (nvalid == 2 ? -2 : -ch0));
+        auto load_x = [&](int tb) {
+            int64_t t = t0 + tb * 16 + col;
+            t = t < T ? t : T - 1;
+            return *reinterpret_cast<const f32x4u*>(xcol + t * C);
+        };
+        f32x4 xr[XD + 1];
+#pragma unroll
+        for (int j = 0; j < XD; ++j) xr[j] = load_x(tbeg + j);
+        for (int tb0 = tbeg; tb0 < tend; tb0 += XD + 1) {
+#pragma unroll
+            for (int j = 0; j <= XD; ++j) {
+                const int tb = tb0 + j;
+                xr[(j + XD) % (XD + 1)] = load_x(tb + XD < tend ? tb + XD : tb);
+                f32x4 acc = bv, ax1 = {0.f, 0.f, 0.f, 0.f}, ax2 = {0.f, 0.f, 0.f, 0.f};
+                const int nboff = tb + 1 < tend ? boff + 16 * P : boff;
+                f16x8 bh[3], bl[3];
+                bh[0] = c0h; bl[0] = c0l; bh[1] = c1h; bl[1] = c1l;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    // fragments of K chunk ks + 2 (of the next block at the end) are read before the MFMAs of chunk ks
+                    const int pk = ks + 2;
+                    const int po = pk < NKS ? boff + 32 * pk : nboff + 32 * (pk - NKS);
+                    bh[pk % 3] = gconv_frag<P>(hs + po);
+                    bl[pk % 3] = gconv_frag<P>(ls + po);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], bh[ks % 3], acc, 0, 0, 0);
+                    ax1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], bl[ks % 3], ax1, 0, 0, 0);
+                    ax2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks], bh[ks % 3], ax2, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                c0h = bh[NKS % 3]; c0l = bl[NKS % 3]; c1h = bh[(NKS + 1) % 3]; c1l = bl[(NKS + 1) % 3];
+                boff = nboff;
+                const int64_t t = t0 + tb * 16 + col;
+                const f32x4 xs2 = {xr[j][2], xr[j][3], 0.f, 0.f};
+                const f32x4 xv = nvalid >= 4 ? xr[j] : xs2;
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = xv[i] + alpha * fmaxf(acc[i] + (ax1[i] + ax2[i]) * (1.0f / 2048.0f), 0.f);
+                if (t < T && nvalid > 0) {
+                    float* yp = yb + t * C + cbase;
+                    if (nvalid >= 4) *reinterpret_cast<f32x4u*>(yp) = o;
+                    else { const f32x2u q2 = {o[0], o[1]}; *reinterpret_cast<f32x2u*>(yp) = q2; }
+                    if (SPLIT) {
+                        // the same values as hi / lo halves in the dense layers' operand geometry: per row and 32-channel
+                        // block 32 hi halves, then 32 lo halves (channels cbase .. cbase + 3; cbase is even)
+                        _Float16 h[4], l[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) split_f16x3(o[i], h[i], l[i]);
+                        _Float16* sp = ysplit + (((int64_t)b * T + t) * (C >> 5) + (cbase >> 5)) * 64 + (cbase & 31);
+                        const f16x2 h01 = {h[0], h[1]}, l01 = {l[0], l[1]}, h23 = {h[2], h[3]}, l23 = {l[2], l[3]};
+                        if (nvalid >= 4 && (cbase & 31) != 30) {
+                            const f16x4u h4 = {h[0], h[1], h[2], h[3]}, l4 = {l[0], l[1], l[2], l[3]};
+                            *reinterpret_cast<f16x4u*>(sp) = h4;
+                            *reinterpret_cast<f16x4u*>(sp + 32) = l4;
+                        } else {
+                            *reinterpret_cast<f16x2*>(sp) = h01;
+                            *reinterpret_cast<f16x2*>(sp + 32) = l01;
+                            if (nvalid >= 4) {        // the second pair opens the next 32-channel block
+                                *reinterpret_cast<f16x2*>(sp + 34) = h23;
+                                *reinterpret_cast<f16x2*>(sp + 66) = l23;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// reference Conv1d weight [C, CG, 21] -> MFMA A fragments [g][mt][ks][hi, lo][lane][8 halves]:
+// row = mt * 16 + (lane & 15) (output channel), k = 32 ks + 8 (lane >> 4) + i = tap * P + ci
+__global__ void pack_gconv_mfma_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int groups, int cg, int pitch,
+                                       int nks, int mt_n) {
+    const int64_t total = (int64_t)groups * mt_n * nks * 64 * 8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int i = (int)(idx & 7), l = (int)((idx >> 3) & 63);
+    int64_t r = idx >> 9;
+    const int ks = (int)(r % nks);
+    r /= nks;
+    const int mt = (int)(r % mt_n), g = (int)(r / mt_n);
+    const int co = mt * 16 + (l & 15), k = 32 * ks + 8 * (l >> 4) + i;
+    const int tap = k / pitch, ci = k - tap * pitch;
+    float v = 0.f;
+    if (co < cg && tap < KS && ci < cg) v = src[((int64_t)(g * cg + co) * cg + ci) * KS + tap];
+    _Float16 hi, lo;
+    split_f16x3(v, hi, lo);
+    const int64_t base = ((((int64_t)(g * mt_n + mt) * nks + ks) * 2) * 64 + l) * 8 + i;
+    dst[base] = hi;
+    dst[base + 64 * 8] = lo;
+}
+
+template <int CG, int P, int GB, int TT>
+static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias, float alpha, float* y, void* ysplit, int B, int64_t T,
+                            int C, int groups, hipStream_t s) {
+    constexpr int KTOT = (KS - 1) * P + CG, NKS = (KTOT + 31) / 32, TIN = TT + 2 * (KS / 2);
+    constexpr int SLAB = (TIN * P + (32 * NKS > KS * P ? 32 * NKS - KS * P : 0) + 7) & ~7;
+    constexpr size_t lds = (size_t)2 * GB * SLAB * sizeof(_Float16);
+    auto k0 = gconv_mfma_kernel<CG, P, GB, TT, false>;
+    auto k1 = gconv_mfma_kernel<CG, P, GB, TT, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("gconv (fp16x3): cannot reserve %zu bytes of LDS", lds);
+            return TAL_EHIP;
+        }
+        attr_set = true;
+    }
+    dim3 grid((unsigned)cdiv(T, TT), (unsigned)(groups / GB), (unsigned)B);
+    ProfScope prof(PROF_GCONV_RES, 2.0 * (double)B * (double)T * C * CG * KS, s);
+    hipLaunchKernelGGL(ysplit ? k1 : k0, grid, dim3(256), lds, s, x, reinterpret_cast<const _Float16*>(wfrag), bias, alpha, y,
+                       reinterpret_cast<_Float16*>(ysplit), T, C);
+    TAL_CHECK_LAUNCH("gconv (fp16x3)");
+    return TAL_OK;
+}
+
+size_t gconv_f16x3_weight_bytes(int C, int groups) {
+    if (groups <= 0 || C % groups) return 0;
+    const int cg = C / groups;
+    if (!gconv_mfma_pitch(cg) || groups % 4) return 0;
+    return (size_t)groups * ((cg + 15) / 16) * gconv_mfma_nks(cg) * 2 * 64 * 8 * sizeof(_Float16);
+}
+
+int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C, int groups, hipStream_t s) {
+    TAL_CHECK_ARG(w_ref && w_frag, "tal_pack_gconv_f16x3_weight: null pointer");
+    TAL_CHECK_ARG(gconv_f16x3_weight_bytes(C, groups) > 0, "tal_pack_gconv_f16x3_weight: no fp16x3 kernel for C=%d groups=%d", C, groups);
+    const int cg = C / groups, mt_n = (cg + 15) / 16, nks = gconv_mfma_nks(cg);
+    const int64_t total = (int64_t)groups * mt_n * nks * 64 * 8;
+    hipLaunchKernelGGL(pack_gconv_mfma_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w_ref, reinterpret_cast<_Float16*>(w_frag),
+                       groups, cg, gconv_mfma_pitch(cg), nks, mt_n);
+    TAL_CHECK_LAUNCH("tal_pack_gconv_f16x3_weight");
+    return TAL_OK;
+}
+
+int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias, float alpha, int B, int64_t T, int C, int groups,
+                           float* y, void* y_split, hipStream_t s) {
+    TAL_CHECK_ARG(x && w_frag && bias && y, "tal_gconv_res_f16x3_fwd: null pointer");
+    TAL_CHECK_ARG(x != y, "tal_gconv_res_f16x3_fwd: in-place not supported (halo reads)");
+    TAL_CHECK_ARG(gconv_f16x3_weight_bytes(C, groups) > 0, "tal_gconv_res_f16x3_fwd: no fp16x3 kernel for C=%d groups=%d", C, groups);
+    TAL_CHECK_ARG(B > 0 && T > 0, "tal_gconv_res_f16x3_fwd: bad shape");
+    TAL_CHECK_ARG(!y_split || C % 32 == 0, "tal_gconv_res_f16x3_fwd: the split output needs C %% 32 == 0 (C=%d)", C);
+    TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && C % 4 == 0, "tal_gconv_res_f16x3_fwd: x must be 16-byte aligned");
+    const int cg = C / groups;
+    if (cg == 10) return launch_mfma_spec<10, 10, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, C, groups, s);
+    if (cg == 14) return launch_mfma_spec<14, 16, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, C, groups, s);
+    return launch_mfma_spec<18, 24, 2, 256>(x, w_frag, bias, alpha, y, y_split, B, T, C, groups, s);
+}
+
 // reference Conv1d weight [C_out, CIG, K] -> packed [G][CIG][K][COG]
 __global__ void pack_gconv_kernel(const float* __restrict__ src, float* __restrict__ dst, int c_out, int cig, int ks,
                                   int groups) {

@@ -232,6 +232,11 @@ class TDS(nn.Module):
                     w3s = ops.split_f16x3(blk.fc[3].weight.detach().reshape(c, c))
                     keep += [w0s, w3s]
                     bw.fc0_w_split, bw.fc3_w_split = w0s.data_ptr(), w3s.data_ptr()
+                    # ... and the grouped conv as fp16x3 MFMA operand fragments (widths 10 / 14 / 18 per group)
+                    wf = ops.pack_gconv_f16x3_weight(g.weight.detach(), g.groups)
+                    if wf is not None:
+                        keep.append(wf)
+                        bw.conv_w_frag = wf.data_ptr()
         self._desc, self._desc_key, self._keep = d, key, keep
         return d
 

@@ -133,6 +133,34 @@ def gconv_res(x, w_packed, bias, alpha, groups):
     return y
 
 
+def pack_gconv_f16x3_weight(weight, groups):
+    """reference Conv1d weight [C, C/G, 21] -> fp16x3 MFMA operand fragments (opaque uint8 tensor), or None when the
+    width has no matrix-core kernel (tal_gconv_f16x3_weight_bytes == 0)."""
+    lib = N.lib()
+    w = _f32c(weight, "pack_gconv_f16x3_weight")
+    c, cig, ks = w.shape
+    nbytes = lib.tal_gconv_f16x3_weight_bytes(c, groups)
+    if nbytes == 0 or ks != 21 or cig * groups != c:
+        return None
+    frag = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    N.check(lib.tal_pack_gconv_f16x3_weight(N.ptr(w), N.ptr(frag), c, groups, N.stream_handle()),
+            "tal_pack_gconv_f16x3_weight")
+    return frag
+
+
+def gconv_res_f16x3(x, w_frag, bias, alpha, groups, want_split=False):
+    """x + alpha * relu(gconv21(x)) on [B, T, C] on the matrix cores (fp16x3 form); with want_split also returns the
+    result as the hi / lo split the fp16x3 dense layers consume (split_f16x3's format)."""
+    lib = N.lib()
+    x = _f32c(x, "gconv_res_f16x3")
+    B, T, c = x.shape
+    y = torch.empty_like(x)
+    ys = torch.empty(B * T * c * 4, dtype=torch.uint8, device=x.device) if want_split else None
+    N.check(lib.tal_gconv_res_f16x3_fwd(N.ptr(x), N.ptr(w_frag), N.ptr(bias), float(alpha), B, T, c, groups, N.ptr(y),
+                                        N.ptr(ys) if want_split else None, N.stream_handle()), "tal_gconv_res_f16x3_fwd")
+    return (y, ys) if want_split else y
+
+
 # ------------------------------------------------------------------ TDS driver
 def tds_forward(desc, x, c_out):
     """x [B, T, C0] -> [B, T', C_last] through tal_tds_fwd (whole encoder, one C call)."""

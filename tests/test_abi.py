@@ -41,7 +41,7 @@ def test_struct_layout_matches_header():
     """ctypes mirror of tal_tds_desc must have the C layout (8-byte pointers, natural alignment)."""
     import ctypes as C
     from tal_asrd_amd import _native
-    assert C.sizeof(_native.TdsBlockW) == 6 * 8 + 8 + 2 * 8
+    assert C.sizeof(_native.TdsBlockW) == 6 * 8 + 8 + 3 * 8
     expect = 4 + 4 + 5 * 4 + 4 * 4          # ints
     expect = (expect + 7) // 8 * 8           # align for pointers
     expect += 4 * 8 * 2 + 4 * 8 * C.sizeof(_native.TdsBlockW)

@@ -261,6 +261,40 @@ def test_gconv_res_matches_torch(cg, T, B):
     np.testing.assert_allclose(y.cpu().double().numpy(), ref.permute(0, 2, 1).numpy(), atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("cg,T,B", [(10, 700, 2), (14, 256, 1), (14, 1000, 1), (18, 300, 2), (18, 5, 1), (10, 1, 1), (18, 529, 1)])
+def test_gconv_res_f16x3_matches_float64(cg, T, B):
+    """TDSBlock grouped conv on the matrix cores (fp16x3 form): same tolerance as the fp32 VALU kernel, the fused
+    hi / lo split of the output is bit-identical to tal_split_f16x3_fwd of the fp32 output, rows behind the
+    output stay untouched."""
+    from tal_asrd_amd import ops
+    G = 80
+    g = torch.Generator().manual_seed(1000 + cg + T)
+    x = torch.randn(B, G * cg, T, generator=g) * 2.0
+    w = torch.randn(G * cg, cg, 21, generator=g) / (21 * cg) ** 0.5
+    b = torch.randn(G * cg, generator=g)
+    xd = x.double()
+    ref = (xd + 0.25 * torch.relu(torch.nn.functional.conv1d(xd, w.double(), b.double(), padding=10, groups=G)))
+    wf = ops.pack_gconv_f16x3_weight(w.to(dev()), G)
+    assert wf is not None
+    xt = x.permute(0, 2, 1).contiguous().to(dev())
+    y, ys = ops.gconv_res_f16x3(xt, wf, b.to(dev()), 0.25, G, want_split=True)
+    y2 = ops.gconv_res_f16x3(xt, wf, b.to(dev()), 0.25, G)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.cpu().double().numpy(), ref.permute(0, 2, 1).numpy(), atol=2e-5, rtol=1e-5)
+    assert torch.equal(y, y2)
+    if (G * cg) % 32 == 0:
+        want = ops.split_f16x3(y.reshape(B * T, G * cg))
+        assert torch.equal(ys, want)
+
+
+def test_gconv_f16x3_unsupported_width_reports_zero_bytes():
+    from tal_asrd_amd import _native as N
+    lib = N.lib()
+    assert lib.tal_gconv_f16x3_weight_bytes(80 * 12, 80) == 0
+    assert lib.tal_gconv_f16x3_weight_bytes(8 * 4, 8) == 0
+    assert lib.tal_gconv_f16x3_weight_bytes(800, 80) > 0 and lib.tal_gconv_f16x3_weight_bytes(1440, 80) > 0
+
+
 # ------------------------------------------------------------------ golden: small TDS / block through the module API
 def test_tds_small_golden():
     from tal_asrd_amd import TDS, synth

@@ -16,6 +16,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void split_kernel(const float* __restrict__ x, _Float16* __restrict__ out, int64_t rows, int K) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -30,9 +31,13 @@ __global__ void split_kernel(const float* __restrict__ x, _Float16* __restrict__
     blk[32 + k % 32] = lo;
 }
 
-constexpr int BM = 128, NSUB = 5, BN = 32 * NSUB, ROWS = BM + BN, BK = 32;
+#ifndef WAVES
+#define WAVES 4
+#endif
+constexpr int BM = 32 * WAVES, NSUB = 5, BN = 32 * NSUB, ROWS = BM + BN, BK = 32;
+constexpr int CHUNKS = ROWS / 8, PER_WAVE = (CHUNKS + WAVES - 1) / WAVES, A_T = BM / 8 / WAVES;   // chunk i = w + WAVES t; t < A_T: A rows
 
-__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const float* __restrict__ As, const float* __restrict__ Ws,
+__global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_f16x3_kernel(const float* __restrict__ As, const float* __restrict__ Ws,
                                                            float* __restrict__ C, int64_t M, int N, int K, int tiles_n, long long* clk) {
     __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * 32];
     const unsigned tile = blockIdx.x;
@@ -52,18 +57,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const float* __restr
     };
     __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(uptr(As + m0 * K), 0, 0x7fffffff, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(uptr(Ws + (int64_t)n0 * K), 0, 0x7fffffff, 0x00020000);
-    int voff[9];
+    int voff[PER_WAVE];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int row = 8 * (w + 4 * t) + sub;
-        voff[t] = t < 4 ? (min(row, a_rows) * K + srccol) * 4 : (min(row - BM, b_rows) * K + srccol) * 4;
+    for (int t = 0; t < PER_WAVE; ++t) {
+        const int row = 8 * (w + WAVES * t) + sub;
+        voff[t] = t < A_T ? (min(row, a_rows) * K + srccol) * 4 : (min(row - BM, b_rows) * K + srccol) * 4;
     }
+#ifndef ABL
+#define ABL 0
+#endif
+    u32x4 sink[PER_WAVE];
     auto issue = [&](int kt, int buf) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            float* dst = lds + buf * (ROWS * 32) + (w + 4 * t) * 256;
+        for (int t = 0; t < PER_WAVE; ++t) {
+            if (w + WAVES * t >= CHUNKS) continue;        // (wave-uniform: the last pass is partial with 8 waves)
+            float* dst = lds + buf * (ROWS * 32) + (w + WAVES * t) * 256;
 #if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(t < 4 ? rs_a : rs_w, (__attribute__((address_space(3))) void*)dst, 16, voff[t],
+#if ABL & 16      // the same loads into registers (consumed at the end of the K step): vector-memory issue and L2 traffic without the LDS writes
+            if (kt > 0) { sink[t] = __builtin_amdgcn_raw_buffer_load_b128(t < A_T ? rs_a : rs_w, voff[t], kt * (BK * 4), 0); continue; }
+#endif
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(t < A_T ? rs_a : rs_w, (__attribute__((address_space(3))) void*)dst, 16, voff[t],
                                                      kt * (BK * 4), 0, 0);
 #endif
         }
@@ -125,6 +138,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const float* __restr
             xx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[g], bhi[q % 3], xx[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#if ABL & 16
+#pragma unroll
+        for (int t = 0; t < PER_WAVE; ++t) asm volatile("" ::"v"(sink[t]));
+#endif
     }
     if (clk && tid == 0 && blockIdx.x < 8192) {      // effective shader clock of the K loop: s_memtime ticks per 100 MHz wall tick
         clk[2 * blockIdx.x] = (long long)(clock64() - c0);
@@ -171,7 +188,7 @@ static void run(int64_t M, int N, int K, bool check) {
     float best = 1e9;
     for (int rep = 0; rep < (check ? 1 : 40); ++rep) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL(gemm_f16x3_kernel, dim3(grid), dim3(256), 0, 0, (const float*)as, (const float*)ws, c, M, N, K, tiles_n, clk);
+        hipLaunchKernelGGL(gemm_f16x3_kernel, dim3(grid), dim3(64 * WAVES), 0, 0, (const float*)as, (const float*)ws, c, M, N, K, tiles_n, clk);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms;

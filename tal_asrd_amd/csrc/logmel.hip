@@ -34,19 +34,22 @@ constexpr int NS = (FB - 1) * HOP + NFFT + 1;  // 5361 samples per workgroup (+1
 constexpr int NSP = NS + NS / HOP + 2;         // + one pad word per hop
 constexpr int NFOLD = 204;                     // folded DFT length: n = 0..200, padded to a multiple of 4
 constexpr int PLD = NTILE * 16 + 1;            // power tile pitch (209)
+constexpr int HTILE = 7;                       // 7 x 16 = 112 >= 101 bins (k = 0..100) of the even / odd half transforms
+constexpr int NHALF = 104;                     // folded half-transform length: n' = 0..100, padded to a multiple of 4
 constexpr int MAXW = 48;                       // max mel filter support in bins
 
 struct LogmelPlan {
     double basis[NTILE * NFFT * 2 * 16];   // [tile][n][re|im][16 bins], Hann folded in
     double fbasis[NTILE * NFOLD * 16 * 2]; // symmetric-window form, [tile][n][16 bins][re|im] (one 16-byte load per lane and step):
                                            // re acts on x[n]+x[400-n], im on x[n]-x[400-n]
+    double hbasis[HTILE * 2 * NHALF * 16 * 2]; // fbasis split by the parity of n, bins 0..100 only: [tile][n & 1][n >> 1][16 bins][re|im]
     int folded;                            // 1 if the window is symmetric (w[n] == w[400-n], w[0] == 0): use fbasis
     int mel_lo[NMEL];
     int mel_cnt[NMEL];
     float mel_w[NMEL * MAXW];
 };
 
-__global__ __launch_bounds__(256) void logmel_kernel(const LogmelPlan* __restrict__ plan,
+__global__ __launch_bounds__(256, 3) void logmel_kernel(const LogmelPlan* __restrict__ plan,
                                                     const float* __restrict__ audio, int64_t L, int64_t T, float eps,
                                                     float* __restrict__ out, double* __restrict__ partial) {
     __shared__ float samp[NSP];
@@ -80,24 +83,51 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogmelPlan* __restric
             //   Re X[k] =  sum_{n=0}^{200} c_n w[n] cos(.) (x[n] + x[400-n])
             //   Im X[k] = -sum_{n=1}^{199}     w[n] sin(.) (x[n] - x[400-n])
             // (c_200 = 1/2; the n = 0 row is w[0] = 0): half the fp64 MFMAs of the direct form.
+            // One radix-2 step on top: with E[k] / O[k] the partial sums over even / odd n,
+            //   X[k] = E[k] + O[k],   X[200-k] = conj(E[k] - O[k])     (cos / sin(2 pi (200-k) n / 400) = +-(-1)^n cos / sin(2 pi k n / 400))
+            // so bins 0..100 of the two half sums give all 201 bins: half the MFMAs again (7 bin tiles instead of 13).
+            if (j >= HTILE) continue;
             typedef double f64x2 __attribute__((ext_vector_type(2)));
-            const f64x2* fq = reinterpret_cast<const f64x2*>(plan->fbasis) + ((int64_t)j * NFOLD + kq) * 16 + fi;
+            const f64x4 zero = {0., 0., 0., 0.};
+            f64x4 ore0 = zero, oim0 = zero, ore1 = zero, oim1 = zero;
             const float* s0 = samp + fi * (HOP + 1);
             const float* s1 = s0 + 16 * (HOP + 1);
-#pragma unroll 3
-            for (int k = 0; k < NFOLD; k += 4) {
-                const int n = k + kq, m = NFFT - n;
-                const int on = n + (n >= HOP ? 1 : 0);            // + pad words crossed (n <= 203)
-                const int om = m + (m >= 2 * HOP ? 2 : 1);        // 197 <= m <= 400
-                const double x0n = (double)s0[on], x0m = (double)s0[om];
-                const double x1n = (double)s1[on], x1m = (double)s1[om];
-                const f64x2 bb = fq[k * 16];
-                const double br = bb.x, bi = bb.y;
-                re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0n + x0m, br, re0, 0, 0, 0);
-                im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0n - x0m, bi, im0, 0, 0, 0);
-                re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1n + x1m, br, re1, 0, 0, 0);
-                im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1n - x1m, bi, im1, 0, 0, 0);
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const f64x2* fq = reinterpret_cast<const f64x2*>(plan->hbasis) + ((int64_t)(j * 2 + par) * NHALF + kq) * 16 + fi;
+                f64x4 r0 = zero, i0 = zero, r1 = zero, i1 = zero;
+#pragma unroll 2      // (3 needs more than the 168 registers that keep three workgroups on a CU)
+                for (int k = 0; k < (par ? NHALF - 4 : NHALF); k += 4) {
+                    const int n = 2 * (k + kq) + par, m = NFFT - n;   // n <= 207, 193 <= m <= 400
+                    const int on = n + (n >= HOP ? 1 : 0);            // + pad words crossed
+                    const int om = m + (m >= 2 * HOP ? 2 : 1);
+                    const double x0n = (double)s0[on], x0m = (double)s0[om];
+                    const double x1n = (double)s1[on], x1m = (double)s1[om];
+                    const f64x2 bb = fq[k * 16];
+                    const double br = bb.x, bi = bb.y;
+                    r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0n + x0m, br, r0, 0, 0, 0);
+                    i0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0n - x0m, bi, i0, 0, 0, 0);
+                    r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1n + x1m, br, r1, 0, 0, 0);
+                    i1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1n - x1m, bi, i1, 0, 0, 0);
+                }
+                if (par == 0) { re0 = r0; im0 = i0; re1 = r1; im1 = i1; }
+                else { ore0 = r0; oim0 = i0; ore1 = r1; oim1 = i1; }
             }
+            // f64 16x16 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+            const int bin = j * 16 + fi;
+            if (bin <= NFFT / 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int frame = kq + 4 * e;
+                    const double a0 = re0[e] + ore0[e], b0 = im0[e] + oim0[e], c0 = re0[e] - ore0[e], d0 = im0[e] - oim0[e];
+                    const double a1 = re1[e] + ore1[e], b1 = im1[e] + oim1[e], c1 = re1[e] - ore1[e], d1 = im1[e] - oim1[e];
+                    P[frame * PLD + bin] = (float)(a0 * a0 + b0 * b0);
+                    P[frame * PLD + NFFT / 2 - bin] = (float)(c0 * c0 + d0 * d0);
+                    P[(frame + 16) * PLD + bin] = (float)(a1 * a1 + b1 * b1);
+                    P[(frame + 16) * PLD + NFFT / 2 - bin] = (float)(c1 * c1 + d1 * d1);
+                }
+            }
+            continue;
         } else {
             const double* bp = plan->basis + ((int64_t)j * NFFT + kq) * 32 + fi;
             const float* sp0 = samp + fi * (HOP + 1) + kq;
@@ -261,6 +291,22 @@ extern "C" int tal_logmel_plan_init(const float* window, const float* fb, void* 
                 hp->fbasis[((j * NFOLD + n) * 16 + c) * 2 + 0] = re;
                 hp->fbasis[((j * NFOLD + n) * 16 + c) * 2 + 1] = im;
             }
+    for (int j = 0; j < HTILE; ++j)
+        for (int par = 0; par < 2; ++par)
+            for (int h = 0; h < NHALF; ++h)
+                for (int c = 0; c < 16; ++c) {
+                    const int bin = j * 16 + c, n = 2 * h + par;
+                    double re = 0.0, im = 0.0;
+                    if (bin <= NFFT / 4 && n >= 1 && n <= NFFT / 2) {
+                        const int ph = (int)(((int64_t)bin * n) % NFFT);
+                        const double ang = two_pi * (double)ph / (double)NFFT;
+                        const double ws = n == NFFT / 2 ? 0.5 * (double)hwin[n] : 0.5 * ((double)hwin[n] + (double)hwin[NFFT - n]);
+                        re = ws * cos(ang);
+                        im = n == NFFT / 2 ? 0.0 : -ws * sin(ang);
+                    }
+                    hp->hbasis[((((j * 2 + par) * NHALF + h) * 16) + c) * 2 + 0] = re;
+                    hp->hbasis[((((j * 2 + par) * NHALF + h) * 16) + c) * 2 + 1] = im;
+                }
     for (int m = 0; m < NMEL; ++m) {
         int lo = -1, hi = -1;
         for (int k = 0; k < NBIN; ++k)

@@ -115,16 +115,21 @@ int tal_gconv_s2_fwd(const float* x, const float* w_packed, const float* bias, i
 int tal_gconv_res_fwd(const float* x, const float* w_packed, const float* bias, float alpha, int B,
                       int64_t T, int C, int groups, float* y, void* stream);
 
-/* The same TDSBlock conv (tal/asr/models.py:304-308,329) on the fp16 matrix cores in the fp16x3 form of the dense
- * layers (three fp16 MFMAs per fp32 product block, fp32 accumulation; error against float64 below an fp32 fmaf chain).
- * Built for C / groups = 10, 14, 18 with groups % 4 == 0 (tal_gconv_f16x3_weight_bytes returns 0 otherwise).
- * tal_pack_gconv_f16x3_weight: reference Conv1d weight [C, C/G, 21] -> MFMA operand fragments (hi / lo halves).
+/* The grouped convs on the fp16 matrix cores in the fp16x3 form of the dense layers (three fp16 MFMAs per fp32 product
+ * block, fp32 accumulation; error against float64 below an fp32 fmaf chain).  Built for the TDSBlock conv (stride 1,
+ * C_in = C_out, models.py:304-308,329) with C / groups = 10, 14, 18 and for the stride-2 resize convs (models.py:363-364)
+ * 10 -> 14 and 14 -> 18 channels per group, groups % 4 == 0; tal_gconv_f16x3_weight_bytes returns 0 for anything else.
+ * tal_pack_gconv_f16x3_weight: reference Conv1d weight [C_out, C_in/G, 21] -> MFMA operand fragments (hi / lo halves).
  * tal_gconv_res_f16x3_fwd: y = x + alpha * relu(conv(x) + b); y_split != NULL additionally receives y as the hi / lo
- * split the fp16x3 dense layers consume (tal_split_f16x3_fwd's format; C % 32 == 0), fused into the store. */
-size_t tal_gconv_f16x3_weight_bytes(int C, int groups);
-int tal_pack_gconv_f16x3_weight(const float* w_ref, void* w_frag, int C, int groups, void* stream);
+ * split the fp16x3 dense layers consume (tal_split_f16x3_fwd's format; C % 32 == 0), fused into the store.
+ * tal_gconv_s2_f16x3_fwd: y = conv(x) + b, stride 2, no padding: [B, T_in, C_in] -> [B, (T_in-21)/2+1, C_out]. */
+size_t tal_gconv_f16x3_weight_bytes(int C_in, int C_out, int groups, int stride);
+int tal_pack_gconv_f16x3_weight(const float* w_ref, void* w_frag, int C_in, int C_out, int groups, int stride,
+                                void* stream);
 int tal_gconv_res_f16x3_fwd(const float* x, const void* w_frag, const float* bias, float alpha, int B,
                             int64_t T, int C, int groups, float* y, void* y_split, void* stream);
+int tal_gconv_s2_f16x3_fwd(const float* x, const void* w_frag, const float* bias, int B, int64_t T_in,
+                           int C_in, int C_out, int groups, float* y, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Whole TDS encoder: TDS.forward, tal/asr/models.py:349-397 (+TDSBlock :298-331)
@@ -152,6 +157,7 @@ typedef struct tal_tds_desc {
     const float* down_w[TAL_MAX_STAGES];  /* packed stride-2 conv weight (blocks.i.0.weight) */
     const float* down_b[TAL_MAX_STAGES];  /* (blocks.i.0.bias) */
     tal_tds_block_w blocks[TAL_MAX_STAGES][TAL_MAX_DEPTH];
+    const void* down_w_frag[TAL_MAX_STAGES]; /* stride-2 conv weights as fp16x3 MFMA fragments, or NULL (VALU kernel) */
 } tal_tds_desc;
 
 /* output length after all stride-2 stages: T' = f(f(f(T))), f(t) = (t-21)/2+1 */

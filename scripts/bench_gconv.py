@@ -38,3 +38,7 @@ for T, cin, cout in ((360001, 1, 10), (179991, 10, 14), (89986, 14, 18)):
     ms = timeit(lambda: ops.gconv_s2(x, wp, b, G * cout, G))
     To = (T - 21) // 2 + 1
     print("gconv_s2  T=%6d %d->%d: %.3f ms  %.1f TFLOP/s" % (T, G * cin, G * cout, ms, 2.0 * To * G * cout * cin * 21 / ms / 1e9))
+    wf = ops.pack_gconv_f16x3_weight(w, G, stride=2)
+    if wf is not None:
+        ms = timeit(lambda: ops.gconv_s2_f16x3(x, wf, b, G * cout, G))
+        print("gconv_s2_f16x3 (matrix cores) T=%6d %d->%d: %.3f ms  %.1f TFLOP/s fp32-equivalent" % (T, G * cin, G * cout, ms, 2.0 * To * G * cout * cin * 21 / ms / 1e9))

@@ -26,7 +26,8 @@ class TdsDesc(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("groups", C.c_int32),
                 ("channels", C.c_int32 * (TAL_MAX_STAGES + 1)), ("depths", C.c_int32 * TAL_MAX_STAGES),
                 ("down_w", C.c_void_p * TAL_MAX_STAGES), ("down_b", C.c_void_p * TAL_MAX_STAGES),
-                ("blocks", (TdsBlockW * TAL_MAX_DEPTH) * TAL_MAX_STAGES)]
+                ("blocks", (TdsBlockW * TAL_MAX_DEPTH) * TAL_MAX_STAGES),
+                ("down_w_frag", C.c_void_p * TAL_MAX_STAGES)]
 
 
 class DecoderLayerW(C.Structure):
@@ -55,8 +56,9 @@ SIGNATURES = {
     "tal_pack_gconv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "tal_gconv_s2_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _p, _p]),
     "tal_gconv_res_fwd": (_i, [_p, _p, _p, _f, _i, _i64, _i, _i, _p, _p]),
-    "tal_gconv_f16x3_weight_bytes": (C.c_size_t, [_i, _i]),
-    "tal_pack_gconv_f16x3_weight": (_i, [_p, _p, _i, _i, _p]),
+    "tal_gconv_f16x3_weight_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "tal_pack_gconv_f16x3_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "tal_gconv_s2_f16x3_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _p, _p]),
     "tal_gconv_res_f16x3_fwd": (_i, [_p, _p, _p, _f, _i, _i64, _i, _i, _p, _p, _p]),
     "tal_tds_out_len": (_i64, [C.POINTER(TdsDesc), _i64]),
     "tal_tds_workspace_bytes": (_sz, [C.POINTER(TdsDesc), _i, _i64]),

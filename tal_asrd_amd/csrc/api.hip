@@ -206,15 +206,22 @@ extern "C" int tal_gconv_res_fwd(const float* x, const float* w_packed, const fl
     return launch_gconv_res(x, w_packed, bias, alpha, B, T, C, groups, y, (hipStream_t)stream);
 }
 
-extern "C" size_t tal_gconv_f16x3_weight_bytes(int C, int groups) { return gconv_f16x3_weight_bytes(C, groups); }
+extern "C" size_t tal_gconv_f16x3_weight_bytes(int C_in, int C_out, int groups, int stride) {
+    return gconv_f16x3_weight_bytes(C_in, C_out, groups, stride);
+}
 
-extern "C" int tal_pack_gconv_f16x3_weight(const float* w_ref, void* w_frag, int C, int groups, void* stream) {
-    return launch_pack_gconv_f16x3(w_ref, w_frag, C, groups, (hipStream_t)stream);
+extern "C" int tal_pack_gconv_f16x3_weight(const float* w_ref, void* w_frag, int C_in, int C_out, int groups, int stride, void* stream) {
+    return launch_pack_gconv_f16x3(w_ref, w_frag, C_in, C_out, groups, stride, (hipStream_t)stream);
 }
 
 extern "C" int tal_gconv_res_f16x3_fwd(const float* x, const void* w_frag, const float* bias, float alpha, int B,
                                        int64_t T, int C, int groups, float* y, void* y_split, void* stream) {
     return launch_gconv_res_f16x3(x, w_frag, bias, alpha, B, T, C, groups, y, y_split, (hipStream_t)stream);
+}
+
+extern "C" int tal_gconv_s2_f16x3_fwd(const float* x, const void* w_frag, const float* bias, int B, int64_t T_in, int C_in,
+                                      int C_out, int groups, float* y, void* stream) {
+    return launch_gconv_s2_f16x3(x, w_frag, bias, B, T_in, C_in, C_out, groups, y, (hipStream_t)stream);
 }
 
 extern "C" int tal_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, void* stream) {
@@ -286,7 +293,11 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
         // resize conv: cur -> a (a buffer other than cur's)
         const int io = (ia + 1) % 4;
         float* a = (last_stage && d->depths[i] == 0) ? y : buf[io];
-        rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s);
+        // stride-2 resize conv: on the matrix cores for long inputs when the fragments are there (10 -> 14, 14 -> 18 per group)
+        if (!force_f32 && d->down_w_frag[i] && (int64_t)B * To > 512 && gconv_f16x3_weight_bytes(cin, c, d->groups, 2) > 0)
+            rc = launch_gconv_s2_f16x3(cur, d->down_w_frag[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s);
+        else
+            rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s);
         if (rc) return rc;
         ia = io;
         const int64_t M = (int64_t)B * To;
@@ -298,7 +309,7 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
             float* x1s = buf[(ia + 3) % 4];
             float* outp = (last_stage && j == d->depths[i] - 1) ? y : buf[ia];
             const bool f16x3 = !force_f32 && bw.fc0_w_split && bw.fc3_w_split && M > 512 && c % 160 == 0;
-            const bool conv_mfma = f16x3 && bw.conv_w_frag && gconv_f16x3_weight_bytes(c, d->groups) > 0;
+            const bool conv_mfma = f16x3 && bw.conv_w_frag && gconv_f16x3_weight_bytes(c, c, d->groups, 1) > 0;
             // x1 = x + rw * relu(gconv(x))            : a -> x1
             // (The matrix-core kernel can also emit x1 as the hi / lo split; measured on the 1-hour shapes that fused store
             //  costs +0.35 / +0.21 / +0.14 ms per launch -- 8-byte pieces that fill 32-byte sectors only partially -- against

@@ -225,31 +225,80 @@ int launch_gconv_res(const float* x, const float* wp, const float* bias, float a
 }
 
 // ---------------------------------------------------------------------------------------------
-// TDSBlock grouped conv on the fp16 matrix cores (fp16x3 form, as the dense layers of the block)
+// Grouped convs on the fp16 matrix cores (fp16x3 form, as the dense layers of the block)
 // ---------------------------------------------------------------------------------------------
-// Per group the conv is a small GEMM  out[co, t] = sum_k W[co, k] X[k, t],  k = tap * P + ci,
-// X[k, t] = x[t + tap - 10][ci].  The group's input slab sits in LDS TIME-major with row pitch P halves
-// ([t][P], hi and lo arrays), so column t of X is simply the 21 * P consecutive halves that start at
-// slab[t * P] (a Hankel matrix): one MFMA operand fragment (8 consecutive k of one column) is one LDS
-// read, no im2col.  M = output channels (weights: register-resident MFMA A fragments, zero rows past
-// CG, zero columns for the P - CG pad channels and past the last tap), N = 16 time steps, K rounded up
-// to 32.  v_mfma_f32_16x16x32_f16 x 3 per product block (hi*hi, hi*lo, lo*hi; fp32 accumulate, three
-// independent accumulators).  The C layout hands a lane 4 consecutive channels of one time step: the
-// residual is one 16-byte load (fetched three blocks ahead: an L2 round trip outlasts a block), the
-// output one 16-byte store, plus -- fused -- the hi / lo split of the output that the next dense layer
-// consumes (saves the separate split pass: 8 bytes per element of HBM traffic).
-// Measured (scripts/ubench/gconv_mfma.hip, 1-hour shapes): 0.60 / 0.33 / 0.31 ms per launch against
-// 0.65 / 0.59 / 0.54 for the VALU kernel above; max error against float64 5e-7 (values of a few units).
+// Per group the conv is a small GEMM  out[co, t] = sum_k W[co, k] X[k, t],  k = j * P + c  (j-th tap of a K segment,
+// channel c).  A segment's input slab sits in LDS TIME-major with row pitch P halves ([row][P], hi and lo arrays), so
+// column t of X is simply the ntap * P consecutive halves that start at slab[t * P] (a Hankel matrix): one MFMA operand
+// fragment (8 consecutive k of one column) is one LDS read, no im2col.  M = output channels (weights: register-resident
+// MFMA A fragments, zero rows past C_out/G, zero columns for pad channels and past the last tap), N = 16 output steps,
+// K rounded up to 32 per segment.  v_mfma_f32_16x16x32_f16 x 3 per product block (hi*hi, hi*lo, lo*hi; fp32 accumulate,
+// three independent accumulators).  Segments keep every fragment 16-byte aligned and bank-conflict-free:
+//   stride 1, C_in/G <= 16 : one segment, 21 taps (P = 16; P = 10 compact for 10 channels: that stage is HBM-bound)
+//   stride 1, C_in/G = 18  : channels 0-15 (P = 16) + channels 16-17 (P = 8); a single P = 24 slab measured 37 % of
+//                            the kernel time in LDS bank-conflict cycles (SQ_LDS_BANK_CONFLICT)
+//   stride 2               : even taps read the slab of even input rows, odd taps the slab of odd rows (P = 16 each), so
+//                            consecutive output steps stay one row apart
+// The C layout hands a lane 4 consecutive channels of one output step: the TDSBlock residual is one 16-byte load (fetched
+// three blocks ahead: an L2 round trip outlasts a block), the output one 16-byte store; optionally the hi / lo split of
+// the output for the next dense layer is stored too (measured slower than the separate split pass: see tal_tds_fwd).
+// Measured (1-hour shapes): TDSBlock convs 0.60 / 0.33 / 0.31 ms per launch against 0.65 / 0.59 / 0.54 for the VALU
+// kernel above; max error against float64 5e-7 (values of a few units).  scripts/ubench/gconv_mfma.hip is the test bed.
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef _Float16 f16x8u __attribute__((ext_vector_type(8), aligned(4)));
 typedef _Float16 f16x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// LDS row pitch (halves) per channels-per-group; 0 = no MFMA kernel for this width.  16 / 24: 16-byte aligned
-// fragments (one ds_read_b128; P = 16 is bank-conflict-free); 10: compact (two ds_read2_b32, fewest MFMAs).
-static inline int gconv_mfma_pitch(int cg) { return cg == 10 ? 10 : cg == 14 ? 16 : cg == 18 ? 24 : 0; }
-static inline int gconv_mfma_nks(int cg) { return ((KS - 1) * gconv_mfma_pitch(cg) + cg + 31) / 32; }
+// K-segment layout (host + device, compile time)
+template <int CIG, int STRIDE>
+struct GcLayout {
+    static constexpr int NSEG = (STRIDE == 2 || CIG > 16) ? 2 : 1;
+    static constexpr int pitch(int s) { return STRIDE == 2 ? 16 : (CIG > 16 ? (s == 0 ? 16 : 8) : (CIG == 10 ? 10 : 16)); }
+    static constexpr int ntap(int s) { return STRIDE == 2 ? (s == 0 ? (KS + 1) / 2 : KS / 2) : KS; }
+    static constexpr int nch(int s) { return CIG > 16 ? (s == 0 ? 16 : CIG - 16) : CIG; }
+    static constexpr int choff(int s) { return (CIG > 16 && s == 1) ? 16 : 0; }
+    static constexpr int tap0(int s) { return STRIDE == 2 ? s : 0; }
+    static constexpr int nk(int s) { return s < NSEG ? ((ntap(s) - 1) * pitch(s) + nch(s) + 31) / 32 : 0; }
+    static constexpr int NKS = nk(0) + nk(1);
+    static constexpr int rows(int s, int tt) { return STRIDE == 2 ? tt + ntap(s) - 1 : tt + KS - 1; }
+    static constexpr int slab(int s, int tt) {       // halves, incl. the K round-up the last output step reads past its window
+        if (s >= NSEG) return 0;
+        const int over = 32 * nk(s) - ntap(s) * pitch(s);
+        return (rows(s, tt) * pitch(s) + (over > 0 ? over : 0) + 7) & ~7;
+    }
+};
+
+// runtime mirror for the weight packer
+struct GcPackDesc {
+    int nseg, pitch[2], ntap[2], nch[2], choff[2], tap0[2], nk[2], tapstep, cig, cog, mt_n, groups;
+};
+template <int CIG, int STRIDE>
+static GcPackDesc make_pack_desc(int cog, int groups) {
+    using LY = GcLayout<CIG, STRIDE>;
+    GcPackDesc d = {};
+    d.nseg = LY::NSEG;
+    for (int s2 = 0; s2 < 2; ++s2) {
+        d.pitch[s2] = LY::pitch(s2); d.ntap[s2] = LY::ntap(s2); d.nch[s2] = LY::nch(s2);
+        d.choff[s2] = LY::choff(s2); d.tap0[s2] = LY::tap0(s2); d.nk[s2] = LY::nk(s2);
+    }
+    d.tapstep = STRIDE; d.cig = CIG; d.cog = cog; d.mt_n = (cog + 15) / 16; d.groups = groups;
+    return d;
+}
+// the (C_in/G, C_out/G, stride) combinations with a kernel; false: none
+static bool gconv_mfma_desc(int cig, int cog, int stride, int groups, GcPackDesc& d) {
+    if (groups <= 0 || groups % 4) return false;
+    if (stride == 1 && cig == cog) {
+        if (cig == 10) { d = make_pack_desc<10, 1>(cog, groups); return true; }
+        if (cig == 14) { d = make_pack_desc<14, 1>(cog, groups); return true; }
+        if (cig == 18) { d = make_pack_desc<18, 1>(cog, groups); return true; }
+    }
+    if (stride == 2) {
+        if (cig == 10 && cog == 14) { d = make_pack_desc<10, 2>(cog, groups); return true; }
+        if (cig == 14 && cog == 18) { d = make_pack_desc<14, 2>(cog, groups); return true; }
+    }
+    return false;
+}
 
 template <int P>
 __device__ __forceinline__ f16x8 gconv_frag(const _Float16* p) {
@@ -257,55 +306,62 @@ __device__ __forceinline__ f16x8 gconv_frag(const _Float16* p) {
     return *reinterpret_cast<const f16x8u*>(p);
 }
 
-template <int CG, int P, int GB, int TT, bool SPLIT>
+template <int CIG, int COG, int STRIDE, bool RESID, int GB, int TT, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restrict__ x, const _Float16* __restrict__ wfrag,
                                                            const float* __restrict__ bias, float alpha, float* __restrict__ y,
-                                                           _Float16* __restrict__ ysplit, int64_t T, int C) {
-    constexpr int KTOT = (KS - 1) * P + CG, NKS = (KTOT + 31) / 32, MT = (CG + 15) / 16;
-    constexpr int PADT = KS / 2;
-    constexpr int TIN = TT + 2 * PADT;
-    constexpr int SLAB = (TIN * P + (32 * NKS > KS * P ? 32 * NKS - KS * P : 0) + 7) & ~7;
-    constexpr int CH = GB * CG, CH4 = CH / 4;
-    constexpr int RPP = 256 / CH4;                    // time steps per pass of the slab load
-    static_assert(CH % 4 == 0 && CG % 2 == 0 && TT % 64 == 0 && P % 2 == 0 && P >= CG, "shape");
-    extern __shared__ __attribute__((aligned(16))) _Float16 slab[];   // [2 (hi, lo)][GB][SLAB]
+                                                           _Float16* __restrict__ ysplit, int64_t T_in, int64_t T_out, int C_in,
+                                                           int C_out) {
+    using LY = GcLayout<CIG, STRIDE>;
+    constexpr int NKS = LY::NKS, NK0 = LY::nk(0), MT = (COG + 15) / 16;
+    constexpr int P0 = LY::pitch(0), P1 = LY::pitch(1);
+    constexpr int PADT = RESID ? KS / 2 : 0;
+    constexpr int TIN = (TT - 1) * STRIDE + KS;                     // input rows a tile of TT outputs reads
+    constexpr int SL0 = LY::slab(0, TT), SL1 = LY::slab(1, TT), GS = SL0 + SL1;   // halves per group and (hi | lo) array
+    constexpr int CH = GB * CIG, CH4 = CH / 4;
+    constexpr int RPP = 256 / CH4;                                  // input rows per pass of the slab load
+    static_assert(CH % 4 == 0 && CIG % 2 == 0 && TT % 64 == 0 && (!RESID || (CIG == COG && STRIDE == 1)), "shape");
+    extern __shared__ __attribute__((aligned(16))) _Float16 slab[];   // [2 (hi, lo)][GB][GS]
     _Float16* s_hi = slab;
-    _Float16* s_lo = slab + GB * SLAB;
+    _Float16* s_lo = slab + GB * GS;
 
     const int b = blockIdx.z, g0 = blockIdx.y * GB;
     const int64_t t0 = (int64_t)blockIdx.x * TT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = wave_id();
-    const float* xb = x + (int64_t)b * T * C;
-    float* yb = y + (int64_t)b * T * C;
+    const float* xb = x + (int64_t)b * T_in * C_in;
+    float* yb = y + (int64_t)b * T_out * C_out;
 
-    // ---- slab load: thread = (time step inside a pass, 16-byte column piece): 16-byte global loads (GB*CG
-    // contiguous floats per time step), all passes in flight (at most two round trips), split, 4-byte LDS
-    // stores at per-thread constant offsets ----
+    // ---- slab load: thread = (input row inside a pass, 16-byte column piece): 16-byte global loads (GB*CIG contiguous
+    // floats per row), all passes in flight, split, 4-byte LDS stores ----
     {
         const int r0 = tid / CH4, c4 = tid - r0 * CH4;
         const bool active = r0 < RPP;
-        int so[2];
+        int so[2], sp[2];       // per channel pair: constant part of the LDS offset, row pitch
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int ch = c4 * 4 + 2 * q, gl = ch / CG;
-            so[q] = gl * SLAB + (ch - gl * CG);
+            const int ch = c4 * 4 + 2 * q, gl = ch / CIG, ci = ch - gl * CIG;
+            const int seg = (STRIDE == 1 && ci >= LY::nch(0)) ? 1 : 0;          // channel split (18 channels per group)
+            so[q] = gl * GS + (seg ? SL0 + ci - LY::nch(0) : ci);
+            sp[q] = seg ? P1 : P0;
         }
-        const float* xc = xb + g0 * CG + (active ? c4 * 4 : 0);
-        constexpr int NPASS = (TIN + RPP - 1) / RPP, UNR = NPASS > 12 ? (NPASS + 1) / 2 : NPASS;
+        const float* xc = xb + g0 * CIG + (active ? c4 * 4 : 0);
+        constexpr int NPASS = (TIN + RPP - 1) / RPP, UNR = NPASS > 20 ? (NPASS + 1) / 2 : NPASS;
         for (int p0 = 0; p0 < NPASS; p0 += UNR) {
             f32x4 v[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const int64_t t = t0 - PADT + r0 + (p0 + u) * RPP;
-                const int64_t tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
-                v[u] = *reinterpret_cast<const f32x4*>(xc + tc * C);
+                const int64_t t = t0 * STRIDE - PADT + r0 + (p0 + u) * RPP;
+                const int64_t tc = t < 0 ? 0 : (t >= T_in ? T_in - 1 : t);
+                v[u] = *reinterpret_cast<const f32x4*>(xc + tc * C_in);
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int ti = r0 + (p0 + u) * RPP;
-                const int64_t t = t0 - PADT + ti;
-                const bool in = t >= 0 && t < T;          // zero padding at the true ends of the batch item
+                const int64_t t = t0 * STRIDE - PADT + ti;
+                const bool in = t >= 0 && t < T_in;          // zero padding at the true ends of the batch item
+                // stride 2: even input rows -> segment 0, odd rows -> segment 1, row ti / 2 of its slab
+                const int row = STRIDE == 2 ? ti >> 1 : ti;
+                const int tbase = (STRIDE == 2 && (ti & 1)) ? SL0 : 0;
                 if (active && ti < TIN) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
@@ -313,21 +369,26 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
                         split_f16x3(in ? v[u][2 * q] : 0.f, h0, l0);
                         split_f16x3(in ? v[u][2 * q + 1] : 0.f, h1, l1);
                         const f16x2 hh = {h0, h1}, ll = {l0, l1};
-                        *reinterpret_cast<f16x2*>(s_hi + so[q] + ti * P) = hh;
-                        *reinterpret_cast<f16x2*>(s_lo + so[q] + ti * P) = ll;
+                        *reinterpret_cast<f16x2*>(s_hi + so[q] + tbase + row * sp[q]) = hh;
+                        *reinterpret_cast<f16x2*>(s_lo + so[q] + tbase + row * sp[q]) = ll;
                     }
                 }
             }
         }
-        // zeros in the pad channels of every row and behind the last row (finite bytes under zero weights)
+        // zeros in the pad channels of every row and behind the last row of each segment (finite bytes under zero weights)
         const f16x2 z2 = {(_Float16)0.f, (_Float16)0.f};
-        if (P > CG)
-            for (int i = tid; i < 2 * GB * TIN; i += 256)
 #pragma unroll
-                for (int c = CG; c < P; c += 2) *reinterpret_cast<f16x2*>(slab + (i / TIN) * SLAB + (i % TIN) * P + c) = z2;
-        for (int i = tid; i < GB * (SLAB - TIN * P); i += 256) {   // (2 GB arrays, two halves per store)
-            const int a = i / ((SLAB - TIN * P) / 2), r = i - a * ((SLAB - TIN * P) / 2);
-            *reinterpret_cast<f16x2*>(slab + a * SLAB + TIN * P + 2 * r) = z2;
+        for (int sg = 0; sg < LY::NSEG; ++sg) {
+            const int pt = sg ? P1 : P0, nc = LY::nch(sg), rows = LY::rows(sg, TT), sl = sg ? SL1 : SL0, base = sg ? SL0 : 0;
+            if (pt > nc)
+                for (int i = tid; i < 2 * GB * rows; i += 256) {
+                    _Float16* rp = slab + (i / rows) * GS + base + (i % rows) * pt;
+                    for (int c = nc; c < pt; c += 2) *reinterpret_cast<f16x2*>(rp + c) = z2;
+                }
+            const int tail2 = (sl - rows * pt) / 2;
+            if (tail2 > 0)
+                for (int i = tid; i < 2 * GB * tail2; i += 256)
+                    *reinterpret_cast<f16x2*>(slab + (i / tail2) * GS + base + rows * pt + 2 * (i % tail2)) = z2;
         }
     }
     __syncthreads();
@@ -351,50 +412,62 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
             wl[ks] = wf[(ks * 2 + 1) * 64];
         }
         const int ch0 = mt * 16 + 4 * kg;
-        const int nvalid = CG - ch0;                  // >= 4: four channels, 2: two, <= 0: none
+        const int nvalid = COG - ch0;                 // >= 4: four channels, 2: two, <= 0: none
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i < nvalid) bv[i] = bias[g * CG + ch0 + i];
-        const _Float16* hs = s_hi + gl * SLAB + (part * NBW * 16 + col) * P + 8 * kg;
-        const _Float16* ls = s_lo + gl * SLAB + (part * NBW * 16 + col) * P + 8 * kg;
-        int boff = 0;
-        f16x8 c0h = gconv_frag<P>(hs), c0l = gconv_frag<P>(ls);
-        f16x8 c1h = gconv_frag<P>(hs + 32), c1l = gconv_frag<P>(ls + 32);
-        // residual x of block tb is fetched XD blocks ahead; the block loop is unrolled by XD + 1 so the ring of
+            if (i < nvalid) bv[i] = bias[g * COG + ch0 + i];
+        const int tbeg = part * NBW, tend = (part + 1) * NBW;
+        // fragment of K chunk c for output column (16 tb + col): segment base + (16 tb + col) * pitch + 8 kg + 32 ks
+        const _Float16* hs = s_hi + gl * GS + 8 * kg;
+        const _Float16* ls = s_lo + gl * GS + 8 * kg;
+        int boff0 = (tbeg * 16 + col) * P0, boff1 = SL0 + (tbeg * 16 + col) * P1;
+        auto frag_off = [&](int c, int b0, int b1) { return c < NK0 ? b0 + 32 * c : b1 + 32 * (c - NK0); };
+        auto frag = [&](const _Float16* base, int c, int b0, int b1) {
+            return c < NK0 ? gconv_frag<P0>(base + frag_off(c, b0, b1)) : gconv_frag<P1>(base + frag_off(c, b0, b1));
+        };
+        f16x8 c0h = frag(hs, 0, boff0, boff1), c0l = frag(ls, 0, boff0, boff1);
+        f16x8 c1h = frag(hs, 1, boff0, boff1), c1l = frag(ls, 1, boff0, boff1);
+        // TDSBlock residual: x of block tb is fetched XD blocks ahead; the block loop is unrolled by XD + 1 so the ring of
         // in-flight registers is indexed statically.  Branch-free: every lane loads 16 bytes; a lane with two valid
         // channels loads from two floats earlier and keeps the upper half, a lane with none re-reads the group's first
-        // channels (all addresses stay inside the row); the choice is applied at the point of use, so no wait sits
-        // behind the load.
+        // channels (all addresses stay inside the row); the choice is applied at the point of use, so no wait sits behind
+        // the load.
         constexpr int XD = 3;
         static_assert(NBW % (XD + 1) == 0, "blocks per wave");
-        const int tbeg = part * NBW, tend = (part + 1) * NBW;
-        const int cbase = g * CG + ch0;
+        const int cbase = g * COG + ch0;
         const float* xcol = xb + cbase + (nvalid >= 4 ? 0 : (nvalid == 2 ? -2 : -ch0));
         auto load_x = [&](int tb) {
             int64_t t = t0 + tb * 16 + col;
-            t = t < T ? t : T - 1;
-            return *reinterpret_cast<const f32x4u*>(xcol + t * C);
+            t = t < T_out ? t : T_out - 1;
+            return *reinterpret_cast<const f32x4u*>(xcol + t * C_in);
         };
         f32x4 xr[XD + 1];
+        if (RESID) {
 #pragma unroll
-        for (int j = 0; j < XD; ++j) xr[j] = load_x(tbeg + j);
+            for (int j = 0; j < XD; ++j) xr[j] = load_x(tbeg + j);
+        }
         for (int tb0 = tbeg; tb0 < tend; tb0 += XD + 1) {
 #pragma unroll
             for (int j = 0; j <= XD; ++j) {
                 const int tb = tb0 + j;
-                xr[(j + XD) % (XD + 1)] = load_x(tb + XD < tend ? tb + XD : tb);
+                if (RESID) xr[(j + XD) % (XD + 1)] = load_x(tb + XD < tend ? tb + XD : tb);
                 f32x4 acc = bv, ax1 = {0.f, 0.f, 0.f, 0.f}, ax2 = {0.f, 0.f, 0.f, 0.f};
-                const int nboff = tb + 1 < tend ? boff + 16 * P : boff;
+                const bool more = tb + 1 < tend;
+                const int nb0 = more ? boff0 + 16 * P0 : boff0, nb1 = more ? boff1 + 16 * P1 : boff1;
                 f16x8 bh[3], bl[3];
                 bh[0] = c0h; bl[0] = c0l; bh[1] = c1h; bl[1] = c1l;
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
                     // fragments of K chunk ks + 2 (of the next block at the end) are read before the MFMAs of chunk ks
                     const int pk = ks + 2;
-                    const int po = pk < NKS ? boff + 32 * pk : nboff + 32 * (pk - NKS);
-                    bh[pk % 3] = gconv_frag<P>(hs + po);
-                    bl[pk % 3] = gconv_frag<P>(ls + po);
+                    if (pk < NKS) {
+                        bh[pk % 3] = frag(hs, pk, boff0, boff1);
+                        bl[pk % 3] = frag(ls, pk, boff0, boff1);
+                    } else {
+                        bh[pk % 3] = frag(hs, pk - NKS, nb0, nb1);
+                        bl[pk % 3] = frag(ls, pk - NKS, nb0, nb1);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], bh[ks % 3], acc, 0, 0, 0);
                     ax1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], bl[ks % 3], ax1, 0, 0, 0);
@@ -402,15 +475,20 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 c0h = bh[NKS % 3]; c0l = bl[NKS % 3]; c1h = bh[(NKS + 1) % 3]; c1l = bl[(NKS + 1) % 3];
-                boff = nboff;
+                boff0 = nb0;
+                boff1 = nb1;
                 const int64_t t = t0 + tb * 16 + col;
-                const f32x4 xs2 = {xr[j][2], xr[j][3], 0.f, 0.f};
-                const f32x4 xv = nvalid >= 4 ? xr[j] : xs2;
                 f32x4 o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = xv[i] + alpha * fmaxf(acc[i] + (ax1[i] + ax2[i]) * (1.0f / 2048.0f), 0.f);
-                if (t < T && nvalid > 0) {
-                    float* yp = yb + t * C + cbase;
+                for (int i = 0; i < 4; ++i) o[i] = acc[i] + (ax1[i] + ax2[i]) * (1.0f / 2048.0f);
+                if (RESID) {
+                    const f32x4 xs2 = {xr[j][2], xr[j][3], 0.f, 0.f};
+                    const f32x4 xv = nvalid >= 4 ? xr[j] : xs2;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = xv[i] + alpha * fmaxf(o[i], 0.f);
+                }
+                if (t < T_out && nvalid > 0) {
+                    float* yp = yb + t * C_out + cbase;
                     if (nvalid >= 4) *reinterpret_cast<f32x4u*>(yp) = o;
                     else { const f32x2u q2 = {o[0], o[1]}; *reinterpret_cast<f32x2u*>(yp) = q2; }
                     if (SPLIT) {
@@ -419,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
                         _Float16 h[4], l[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) split_f16x3(o[i], h[i], l[i]);
-                        _Float16* sp = ysplit + (((int64_t)b * T + t) * (C >> 5) + (cbase >> 5)) * 64 + (cbase & 31);
+                        _Float16* sp = ysplit + (((int64_t)b * T_out + t) * (C_out >> 5) + (cbase >> 5)) * 64 + (cbase & 31);
                         const f16x2 h01 = {h[0], h[1]}, l01 = {l[0], l[1]}, h23 = {h[2], h[3]}, l23 = {l[2], l[3]};
                         if (nvalid >= 4 && (cbase & 31) != 30) {
                             const f16x4u h4 = {h[0], h[1], h[2], h[3]}, l4 = {l[0], l[1], l[2], l[3]};
@@ -440,37 +518,39 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
     }
 }
 
-// reference Conv1d weight [C, CG, 21] -> MFMA A fragments [g][mt][ks][hi, lo][lane][8 halves]:
-// row = mt * 16 + (lane & 15) (output channel), k = 32 ks + 8 (lane >> 4) + i = tap * P + ci
-__global__ void pack_gconv_mfma_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int groups, int cg, int pitch,
-                                       int nks, int mt_n) {
-    const int64_t total = (int64_t)groups * mt_n * nks * 64 * 8;
+// reference Conv1d weight [C_out, C_in/G, 21] -> MFMA A fragments [g][mt][K chunk][hi, lo][lane][8 halves]:
+// row = mt * 16 + (lane & 15) (output channel); chunk c of segment s, k = 32 ks + 8 (lane >> 4) + i = j * pitch + cc
+// -> tap tap0 + j * stride, input channel choff + cc
+__global__ void pack_gconv_mfma_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, const GcPackDesc d) {
+    const int nks = d.nk[0] + d.nk[1];
+    const int64_t total = (int64_t)d.groups * d.mt_n * nks * 64 * 8;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int i = (int)(idx & 7), l = (int)((idx >> 3) & 63);
     int64_t r = idx >> 9;
-    const int ks = (int)(r % nks);
+    const int c = (int)(r % nks);
     r /= nks;
-    const int mt = (int)(r % mt_n), g = (int)(r / mt_n);
+    const int mt = (int)(r % d.mt_n), g = (int)(r / d.mt_n);
+    const int sg = c < d.nk[0] ? 0 : 1, ks = c - (sg ? d.nk[0] : 0);
     const int co = mt * 16 + (l & 15), k = 32 * ks + 8 * (l >> 4) + i;
-    const int tap = k / pitch, ci = k - tap * pitch;
+    const int j = k / d.pitch[sg], cc = k - j * d.pitch[sg];
     float v = 0.f;
-    if (co < cg && tap < KS && ci < cg) v = src[((int64_t)(g * cg + co) * cg + ci) * KS + tap];
+    if (co < d.cog && j < d.ntap[sg] && cc < d.nch[sg])
+        v = src[((int64_t)(g * d.cog + co) * d.cig + d.choff[sg] + cc) * KS + d.tap0[sg] + j * d.tapstep];
     _Float16 hi, lo;
     split_f16x3(v, hi, lo);
-    const int64_t base = ((((int64_t)(g * mt_n + mt) * nks + ks) * 2) * 64 + l) * 8 + i;
+    const int64_t base = ((((int64_t)(g * d.mt_n + mt) * nks + c) * 2) * 64 + l) * 8 + i;
     dst[base] = hi;
     dst[base + 64 * 8] = lo;
 }
 
-template <int CG, int P, int GB, int TT>
-static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias, float alpha, float* y, void* ysplit, int B, int64_t T,
-                            int C, int groups, hipStream_t s) {
-    constexpr int KTOT = (KS - 1) * P + CG, NKS = (KTOT + 31) / 32, TIN = TT + 2 * (KS / 2);
-    constexpr int SLAB = (TIN * P + (32 * NKS > KS * P ? 32 * NKS - KS * P : 0) + 7) & ~7;
-    constexpr size_t lds = (size_t)2 * GB * SLAB * sizeof(_Float16);
-    auto k0 = gconv_mfma_kernel<CG, P, GB, TT, false>;
-    auto k1 = gconv_mfma_kernel<CG, P, GB, TT, true>;
+template <int CIG, int COG, int STRIDE, bool RESID, int GB, int TT>
+static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias, float alpha, float* y, void* ysplit, int B,
+                            int64_t T_in, int64_t T_out, int C_in, int C_out, int groups, hipStream_t s) {
+    using LY = GcLayout<CIG, STRIDE>;
+    constexpr size_t lds = (size_t)2 * GB * (LY::slab(0, TT) + LY::slab(1, TT)) * sizeof(_Float16);
+    auto k0 = gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, false>;
+    auto k1 = gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, RESID>;     // (split output: TDSBlock conv only)
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
@@ -480,28 +560,28 @@ static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias
         }
         attr_set = true;
     }
-    dim3 grid((unsigned)cdiv(T, TT), (unsigned)(groups / GB), (unsigned)B);
-    ProfScope prof(PROF_GCONV_RES, 2.0 * (double)B * (double)T * C * CG * KS, s);
-    hipLaunchKernelGGL(ysplit ? k1 : k0, grid, dim3(256), lds, s, x, reinterpret_cast<const _Float16*>(wfrag), bias, alpha, y,
-                       reinterpret_cast<_Float16*>(ysplit), T, C);
+    dim3 grid((unsigned)cdiv(T_out, TT), (unsigned)(groups / GB), (unsigned)B);
+    ProfScope prof(RESID ? PROF_GCONV_RES : PROF_GCONV_S2, 2.0 * (double)B * (double)T_out * C_out * CIG * KS, s);
+    hipLaunchKernelGGL((ysplit && RESID) ? k1 : k0, grid, dim3(256), lds, s, x, reinterpret_cast<const _Float16*>(wfrag), bias, alpha, y,
+                       reinterpret_cast<_Float16*>(ysplit), T_in, T_out, C_in, C_out);
     TAL_CHECK_LAUNCH("gconv (fp16x3)");
     return TAL_OK;
 }
 
-size_t gconv_f16x3_weight_bytes(int C, int groups) {
-    if (groups <= 0 || C % groups) return 0;
-    const int cg = C / groups;
-    if (!gconv_mfma_pitch(cg) || groups % 4) return 0;
-    return (size_t)groups * ((cg + 15) / 16) * gconv_mfma_nks(cg) * 2 * 64 * 8 * sizeof(_Float16);
+size_t gconv_f16x3_weight_bytes(int C_in, int C_out, int groups, int stride) {
+    if (groups <= 0 || C_in % groups || C_out % groups) return 0;
+    GcPackDesc d;
+    if (!gconv_mfma_desc(C_in / groups, C_out / groups, stride, groups, d)) return 0;
+    return (size_t)groups * d.mt_n * (d.nk[0] + d.nk[1]) * 2 * 64 * 8 * sizeof(_Float16);
 }
 
-int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C, int groups, hipStream_t s) {
+int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C_in, int C_out, int groups, int stride, hipStream_t s) {
     TAL_CHECK_ARG(w_ref && w_frag, "tal_pack_gconv_f16x3_weight: null pointer");
-    TAL_CHECK_ARG(gconv_f16x3_weight_bytes(C, groups) > 0, "tal_pack_gconv_f16x3_weight: no fp16x3 kernel for C=%d groups=%d", C, groups);
-    const int cg = C / groups, mt_n = (cg + 15) / 16, nks = gconv_mfma_nks(cg);
-    const int64_t total = (int64_t)groups * mt_n * nks * 64 * 8;
-    hipLaunchKernelGGL(pack_gconv_mfma_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w_ref, reinterpret_cast<_Float16*>(w_frag),
-                       groups, cg, gconv_mfma_pitch(cg), nks, mt_n);
+    GcPackDesc d;
+    TAL_CHECK_ARG(groups > 0 && C_in % groups == 0 && C_out % groups == 0 && gconv_mfma_desc(C_in / groups, C_out / groups, stride, groups, d),
+                  "tal_pack_gconv_f16x3_weight: no fp16x3 kernel for %d -> %d channels, groups=%d, stride %d", C_in, C_out, groups, stride);
+    const int64_t total = (int64_t)groups * d.mt_n * (d.nk[0] + d.nk[1]) * 64 * 8;
+    hipLaunchKernelGGL(pack_gconv_mfma_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w_ref, reinterpret_cast<_Float16*>(w_frag), d);
     TAL_CHECK_LAUNCH("tal_pack_gconv_f16x3_weight");
     return TAL_OK;
 }
@@ -510,14 +590,26 @@ int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias
                            float* y, void* y_split, hipStream_t s) {
     TAL_CHECK_ARG(x && w_frag && bias && y, "tal_gconv_res_f16x3_fwd: null pointer");
     TAL_CHECK_ARG(x != y, "tal_gconv_res_f16x3_fwd: in-place not supported (halo reads)");
-    TAL_CHECK_ARG(gconv_f16x3_weight_bytes(C, groups) > 0, "tal_gconv_res_f16x3_fwd: no fp16x3 kernel for C=%d groups=%d", C, groups);
+    TAL_CHECK_ARG(gconv_f16x3_weight_bytes(C, C, groups, 1) > 0, "tal_gconv_res_f16x3_fwd: no fp16x3 kernel for C=%d groups=%d", C, groups);
     TAL_CHECK_ARG(B > 0 && T > 0, "tal_gconv_res_f16x3_fwd: bad shape");
     TAL_CHECK_ARG(!y_split || C % 32 == 0, "tal_gconv_res_f16x3_fwd: the split output needs C %% 32 == 0 (C=%d)", C);
     TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && C % 4 == 0, "tal_gconv_res_f16x3_fwd: x must be 16-byte aligned");
     const int cg = C / groups;
-    if (cg == 10) return launch_mfma_spec<10, 10, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, C, groups, s);
-    if (cg == 14) return launch_mfma_spec<14, 16, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, C, groups, s);
-    return launch_mfma_spec<18, 24, 2, 256>(x, w_frag, bias, alpha, y, y_split, B, T, C, groups, s);
+    if (cg == 10) return launch_mfma_spec<10, 10, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s);
+    if (cg == 14) return launch_mfma_spec<14, 14, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s);
+    return launch_mfma_spec<18, 18, 1, true, 2, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s);
+}
+
+int launch_gconv_s2_f16x3(const float* x, const void* w_frag, const float* bias, int B, int64_t T_in, int C_in, int C_out, int groups,
+                          float* y, hipStream_t s) {
+    TAL_CHECK_ARG(x && w_frag && bias && y, "tal_gconv_s2_f16x3_fwd: null pointer");
+    TAL_CHECK_ARG(gconv_f16x3_weight_bytes(C_in, C_out, groups, 2) > 0, "tal_gconv_s2_f16x3_fwd: no fp16x3 kernel for %d -> %d channels, groups=%d",
+                  C_in, C_out, groups);
+    TAL_CHECK_ARG(B > 0 && T_in >= KS, "tal_gconv_s2_f16x3_fwd: T_in=%lld shorter than the kernel", (long long)T_in);
+    TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && C_in % 4 == 0, "tal_gconv_s2_f16x3_fwd: x must be 16-byte aligned");
+    const int64_t T_out = (T_in - KS) / 2 + 1;
+    if (C_in / groups == 10) return launch_mfma_spec<10, 14, 2, false, 4, 128>(x, w_frag, bias, 0.f, y, nullptr, B, T_in, T_out, C_in, C_out, groups, s);
+    return launch_mfma_spec<14, 18, 2, false, 2, 128>(x, w_frag, bias, 0.f, y, nullptr, B, T_in, T_out, C_in, C_out, groups, s);
 }
 
 // reference Conv1d weight [C_out, CIG, K] -> packed [G][CIG][K][COG]

@@ -215,6 +215,10 @@ class TDS(nn.Module):
             keep.append(pw)
             d.down_w[i] = pw.data_ptr()
             d.down_b[i] = down.bias.data_ptr()
+            dwf = ops.pack_gconv_f16x3_weight(down.weight.detach(), down.groups, stride=2)
+            if dwf is not None:
+                keep.append(dwf)
+                d.down_w_frag[i] = dwf.data_ptr()
             for j, blk in enumerate(chain):
                 g = blk.conv[0]
                 gp = g.packed()

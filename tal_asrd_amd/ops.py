@@ -133,19 +133,31 @@ def gconv_res(x, w_packed, bias, alpha, groups):
     return y
 
 
-def pack_gconv_f16x3_weight(weight, groups):
-    """reference Conv1d weight [C, C/G, 21] -> fp16x3 MFMA operand fragments (opaque uint8 tensor), or None when the
-    width has no matrix-core kernel (tal_gconv_f16x3_weight_bytes == 0)."""
+def pack_gconv_f16x3_weight(weight, groups, stride=1):
+    """reference Conv1d weight [C_out, C_in/G, 21] -> fp16x3 MFMA operand fragments (opaque uint8 tensor), or None when
+    the shape has no matrix-core kernel (tal_gconv_f16x3_weight_bytes == 0)."""
     lib = N.lib()
     w = _f32c(weight, "pack_gconv_f16x3_weight")
-    c, cig, ks = w.shape
-    nbytes = lib.tal_gconv_f16x3_weight_bytes(c, groups)
-    if nbytes == 0 or ks != 21 or cig * groups != c:
+    c_out, cig, ks = w.shape
+    c_in = cig * groups
+    nbytes = lib.tal_gconv_f16x3_weight_bytes(c_in, c_out, groups, stride) if ks == 21 else 0
+    if nbytes == 0:
         return None
     frag = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    N.check(lib.tal_pack_gconv_f16x3_weight(N.ptr(w), N.ptr(frag), c, groups, N.stream_handle()),
+    N.check(lib.tal_pack_gconv_f16x3_weight(N.ptr(w), N.ptr(frag), c_in, c_out, groups, stride, N.stream_handle()),
             "tal_pack_gconv_f16x3_weight")
     return frag
+
+
+def gconv_s2_f16x3(x, w_frag, bias, c_out, groups):
+    """x [B, T, C_in] -> [B, (T-21)//2+1, C_out] (tal/asr/models.py:363-364) on the matrix cores (fp16x3 form)."""
+    lib = N.lib()
+    x = _f32c(x, "gconv_s2_f16x3")
+    B, T, c_in = x.shape
+    y = torch.empty(B, (T - 21) // 2 + 1, c_out, dtype=torch.float32, device=x.device)
+    N.check(lib.tal_gconv_s2_f16x3_fwd(N.ptr(x), N.ptr(w_frag), N.ptr(bias), B, T, c_in, c_out, groups, N.ptr(y),
+                                       N.stream_handle()), "tal_gconv_s2_f16x3_fwd")
+    return y
 
 
 def gconv_res_f16x3(x, w_frag, bias, alpha, groups, want_split=False):

@@ -44,7 +44,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(_native.TdsBlockW) == 6 * 8 + 8 + 3 * 8
     expect = 4 + 4 + 5 * 4 + 4 * 4          # ints
     expect = (expect + 7) // 8 * 8           # align for pointers
-    expect += 4 * 8 * 2 + 4 * 8 * C.sizeof(_native.TdsBlockW)
+    expect += 4 * 8 * 2 + 4 * 8 * C.sizeof(_native.TdsBlockW) + 4 * 8
     assert C.sizeof(_native.TdsDesc) == expect
 
 

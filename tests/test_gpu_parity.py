@@ -287,12 +287,33 @@ def test_gconv_res_f16x3_matches_float64(cg, T, B):
         assert torch.equal(ys, want)
 
 
+@pytest.mark.parametrize("cig,cog,T,B", [(10, 14, 300, 1), (14, 18, 277, 2), (10, 14, 1000, 2), (14, 18, 21, 1), (14, 18, 22, 1),
+                                        (10, 14, 555, 1)])
+def test_gconv_s2_f16x3_matches_float64(cig, cog, T, B):
+    """stride-2 resize conv on the matrix cores (even / odd input rows as two K segments): same tolerance as the fp32
+    VALU kernel, rows behind the output untouched."""
+    from tal_asrd_amd import ops
+    G = 80
+    g = torch.Generator().manual_seed(cig * 100 + cog + T)
+    x = torch.randn(B, G * cig, T, generator=g) * 2.0
+    w = torch.randn(G * cog, cig, 21, generator=g) / (21 * cig) ** 0.5
+    b = torch.randn(G * cog, generator=g)
+    ref = torch.nn.functional.conv1d(x.double(), w.double(), b.double(), stride=2, groups=G).permute(0, 2, 1)
+    wf = ops.pack_gconv_f16x3_weight(w.to(dev()), G, stride=2)
+    assert wf is not None
+    y = ops.gconv_s2_f16x3(x.permute(0, 2, 1).contiguous().to(dev()), wf, b.to(dev()), G * cog, G)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+
+
 def test_gconv_f16x3_unsupported_width_reports_zero_bytes():
     from tal_asrd_amd import _native as N
     lib = N.lib()
-    assert lib.tal_gconv_f16x3_weight_bytes(80 * 12, 80) == 0
-    assert lib.tal_gconv_f16x3_weight_bytes(8 * 4, 8) == 0
-    assert lib.tal_gconv_f16x3_weight_bytes(800, 80) > 0 and lib.tal_gconv_f16x3_weight_bytes(1440, 80) > 0
+    assert lib.tal_gconv_f16x3_weight_bytes(80 * 12, 80 * 12, 80, 1) == 0
+    assert lib.tal_gconv_f16x3_weight_bytes(8 * 4, 8 * 4, 8, 1) == 0
+    assert lib.tal_gconv_f16x3_weight_bytes(80, 800, 80, 2) == 0          # 1 -> 10 channels per group stays on the VALU
+    assert lib.tal_gconv_f16x3_weight_bytes(800, 800, 80, 1) > 0 and lib.tal_gconv_f16x3_weight_bytes(1440, 1440, 80, 1) > 0
+    assert lib.tal_gconv_f16x3_weight_bytes(800, 1120, 80, 2) > 0 and lib.tal_gconv_f16x3_weight_bytes(1120, 1440, 80, 2) > 0
 
 
 # ------------------------------------------------------------------ golden: small TDS / block through the module API

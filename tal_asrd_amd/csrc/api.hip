@@ -391,7 +391,17 @@ extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_
         const int P = head_argmax_partials();
         float* pv = reinterpret_cast<float*>(workspace);
         int32_t* pi = reinterpret_cast<int32_t*>(pv + (size_t)M * P);
-        rc = launch_head_argmax(feat, w_logit, b_logit, M, S, pv, pi, s);
+        // the speaker-logit weights as hi / lo fp16 split in the unused tail of the workspace (3 MB, one ~5 us pass per call):
+        // the arg-max GEMM then runs in the fp16x3 form of the dense layers
+        static const bool head_f32 = getenv("TAL_TDS_F32") != nullptr;
+        void* wsplit = nullptr;
+        const size_t used = ((size_t)M * P * 8 + 255) & ~(size_t)255;
+        if (!head_f32 && E % 32 == 0 && (reinterpret_cast<uintptr_t>(w_logit) & 15) == 0 && used + (size_t)S * E * 4 <= workspace_bytes) {
+            wsplit = reinterpret_cast<char*>(workspace) + used;
+            rc = launch_split_f16x3(w_logit, wsplit, S, E, s);
+            if (rc) return rc;
+        }
+        rc = launch_head_argmax(feat, w_logit, wsplit, b_logit, M, S, pv, pi, s);
         if (rc) return rc;
         ProfScope prof(PROF_OTHER, (double)M * P * 8.0, s);
         hipLaunchKernelGGL(argmax_partials_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, pv, pi, M, P, P, ids);

@@ -117,7 +117,7 @@ int launch_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, hipStream
 // A-stationary speaker-logit arg-max (csrc/head.hip): partials [M, head_argmax_partials()] for argmax_partials_kernel
 bool head_argmax_applicable(int64_t M, int S, int E);
 int head_argmax_partials();
-int launch_head_argmax(const float* feat, const float* w, const float* b, int64_t M, int S, float* part_val,
+int launch_head_argmax(const float* feat, const float* w, const void* w_split, const float* b, int64_t M, int S, float* part_val,
                        int32_t* part_idx, hipStream_t s);
 
 }  // namespace tal

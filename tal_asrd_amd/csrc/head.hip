@@ -28,6 +28,11 @@ __device__ __forceinline__ void* uniform_ptr(const void* p) {
     return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
 }
 
+// F16X3: W arrives as the hi / lo fp16 split of tal_split_f16x3_fwd (same bytes per row and 32-wide K block, so the
+// LDS-DMA stream and swizzle are unchanged), the feature strip is split once per row block into MFMA-ready fp16
+// fragments, and every fp32 product block becomes three v_mfma_f32_32x32x16_f16 with fp32 accumulation (the dense
+// layers' fp16x3 form: error below an fp32 fmaf chain, a sixth of the matrix-pipe time of the fp32 MFMAs).
+template <bool F16X3>
 __global__ __launch_bounds__(256, 2) void head_argmax_kernel(const float* __restrict__ feat, const float* __restrict__ W,
                                                             const float* __restrict__ bias, int64_t M, int S, int NT,
                                                             int64_t U, float* __restrict__ part_val,
@@ -60,14 +65,19 @@ __global__ __launch_bounds__(256, 2) void head_argmax_kernel(const float* __rest
         }
     };
 
-    f32x4 a[HK / 8];                 // this wave's 32 x 128 strip: a[kk] = A[row, 8 kk + 4 (lane >> 5) .. + 3]
+    f32x4 a[F16X3 ? 1 : HK / 8];     // this wave's 32 x 128 strip: a[kk] = A[row, 8 kk + 4 (lane >> 5) .. + 3]
+    f16x8 ah[F16X3 ? HK / 16 : 1], al[F16X3 ? HK / 16 : 1];   // fp16x3: (hi, lo) of A[row, 16 q + 8 (lane >> 5) .. + 7], q = 2 kt + g
     float best[16];
     int bidx[16];
-    f32x16 acc[HNSUB];
+    f32x16 acc[HNSUB], accx[F16X3 ? HNSUB : 1];
 #pragma unroll
     for (int j = 0; j < HNSUB; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < (F16X3 ? HNSUB : 1); ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accx[j][e] = 0.f;
 
     auto block_of = [&](int64_t u) {          // workgroup whose run contains unit u
         int64_t b = u * G / U;
@@ -84,9 +94,25 @@ __global__ __launch_bounds__(256, 2) void head_argmax_kernel(const float* __rest
         if (u == u0 || n == 0) {
             int64_t r = row0 + frow;
             r = r < M ? r : M - 1;
-            const float* ap = feat + r * HK + 4 * fhalf;
+            if (F16X3) {
+                const float* ap = feat + r * HK + 8 * fhalf;
 #pragma unroll
-            for (int kk = 0; kk < HK / 8; ++kk) a[kk] = *reinterpret_cast<const f32x4*>(ap + 8 * kk);
+                for (int q = 0; q < HK / 16; ++q) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(ap + 16 * q), v1 = *reinterpret_cast<const f32x4*>(ap + 16 * q + 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        _Float16 h, l;
+                        split_f16x3(v0[i], h, l);
+                        ah[q][i] = h; al[q][i] = l;
+                        split_f16x3(v1[i], h, l);
+                        ah[q][4 + i] = h; al[q][4 + i] = l;
+                    }
+                }
+            } else {
+                const float* ap = feat + r * HK + 4 * fhalf;
+#pragma unroll
+                for (int kk = 0; kk < HK / 8; ++kk) a[kk] = *reinterpret_cast<const f32x4*>(ap + 8 * kk);
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 best[e] = -INFINITY;
@@ -105,6 +131,28 @@ __global__ __launch_bounds__(256, 2) void head_argmax_kernel(const float* __rest
             else if (u + 1 < u1)
                 issue((int)((u + 1) % NT), 0, buf ^ 1);
             const float* Bs = lds + buf * (HBN * 32) + frow * 32;
+            if (F16X3) {
+                // a 128-byte W row of this K block is [32 hi | 32 lo]: 16-byte slot 2g + half (hi), 4 + 2g + half (lo)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int sh = ((2 * g + fhalf) ^ fsw) * 4, sl = ((4 + 2 * g + fhalf) ^ fsw) * 4;
+                    f16x8 bh[HNSUB], bl[HNSUB];
+#pragma unroll
+                    for (int j = 0; j < HNSUB; ++j) {
+                        bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * 32 + sh);
+                        bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * 32 + sl);
+                    }
+                    const f16x8 fah = ah[F16X3 ? kt * 2 + g : 0], fal = al[F16X3 ? kt * 2 + g : 0];
+#pragma unroll
+                    for (int j = 0; j < HNSUB; ++j) {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bh[j], acc[j], 0, 0, 0);
+                        accx[F16X3 ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bl[j], accx[F16X3 ? j : 0], 0, 0, 0);
+                        accx[F16X3 ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, bh[j], accx[F16X3 ? j : 0], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                continue;
+            }
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
                 const int sl = ((2 * k4 + fhalf) ^ fsw) * 4;
@@ -129,12 +177,13 @@ __global__ __launch_bounds__(256, 2) void head_argmax_kernel(const float* __rest
             const bool ok = col < S;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float v = acc[j][e] + bv[j];
+                const float v = (F16X3 ? fmaf(accx[F16X3 ? j : 0][e], 1.0f / 2048.0f, acc[j][e]) : acc[j][e]) + bv[j];
                 if (ok && v > best[e]) {
                     best[e] = v;
                     bidx[e] = col;
                 }
                 acc[j][e] = 0.f;
+                if (F16X3) accx[F16X3 ? j : 0][e] = 0.f;
             }
         }
         if (n == NT - 1 || u == u1 - 1) {
@@ -187,10 +236,11 @@ bool head_argmax_applicable(int64_t M, int S, int E) {
 
 int head_argmax_partials() { return HP; }
 
-int launch_head_argmax(const float* feat, const float* w, const float* b, int64_t M, int S, float* part_val,
+// w_split != nullptr: W as the hi / lo split of tal_split_f16x3_fwd -> the fp16x3 kernel; else w (fp32) -> the fp32 MFMA kernel
+int launch_head_argmax(const float* feat, const float* w, const void* w_split, const float* b, int64_t M, int S, float* part_val,
                        int32_t* part_idx, hipStream_t s) {
-    TAL_CHECK_ARG(feat && w && b && part_val && part_idx, "head_argmax: null pointer");
-    TAL_CHECK_ARG(((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(w)) & 15) == 0, "head_argmax: operands must be 16-byte aligned");
+    TAL_CHECK_ARG(feat && (w || w_split) && b && part_val && part_idx, "head_argmax: null pointer");
+    TAL_CHECK_ARG(((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(w_split)) & 15) == 0, "head_argmax: operands must be 16-byte aligned");
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -201,7 +251,11 @@ int launch_head_argmax(const float* feat, const float* w, const float* b, int64_
     const int NT = (int)cdiv(S, HBN);
     const int64_t U = cdiv(M, HBM) * NT;
     ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)S * HK, s);
-    hipLaunchKernelGGL(head_argmax_kernel, dim3((unsigned)(2 * cus)), dim3(256), 0, s, feat, w, b, M, S, NT, U, part_val, part_idx);
+    if (w_split)
+        hipLaunchKernelGGL(head_argmax_kernel<true>, dim3((unsigned)(2 * cus)), dim3(256), 0, s, feat, reinterpret_cast<const float*>(w_split), b, M,
+                           S, NT, U, part_val, part_idx);
+    else
+        hipLaunchKernelGGL(head_argmax_kernel<false>, dim3((unsigned)(2 * cus)), dim3(256), 0, s, feat, w, b, M, S, NT, U, part_val, part_idx);
     TAL_CHECK_LAUNCH("head_argmax");
     return TAL_OK;
 }

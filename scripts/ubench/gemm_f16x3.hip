@@ -87,7 +87,11 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_f16x3_kernel(const
 #pragma unroll
         for (int e = 0; e < 16; ++e) hh[j][e] = xx[j][e] = 0.f;
     const int frow = lane & 31, fsw = (frow >> 1) & 7, fhalf = lane >> 5;
+#ifdef DEPHASE      // timing experiment: the second workgroup of every CU starts half a tile late (its first tile is cut short)
+    const int nk = (blockIdx.x >= 256 && blockIdx.x < 512) ? K / BK / 2 : K / BK;
+#else
     const int nk = K / BK;
+#endif
     const long long c0 = clock64(), w0 = wall_clock64();
     issue(0, 0);
     // ABL (ablation bitmask, timing only -- results are wrong): 1 = no operand loads inside the loop, 2 = fragment

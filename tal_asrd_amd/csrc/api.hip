@@ -28,16 +28,19 @@ ProfScope::ProfScope(int cls, double work, hipStream_t stream) : slot(-1), s(str
     if (!g_prof_on || g_prof_n >= PROF_MAX) return;
     slot = g_prof_n++;
     if (slot >= g_prof_created) {
-        hipEventCreate(&g_prof_ev[slot][0]);
-        hipEventCreate(&g_prof_ev[slot][1]);
+        if (hipEventCreate(&g_prof_ev[slot][0]) != hipSuccess || hipEventCreate(&g_prof_ev[slot][1]) != hipSuccess) {
+            --g_prof_n;          // (measurement hook only: a launch without events is simply not timed)
+            slot = -1;
+            return;
+        }
         g_prof_created = slot + 1;
     }
     g_prof_cls[slot] = cls;
     g_prof_work[slot] = work;
-    hipEventRecord(g_prof_ev[slot][0], s);
+    (void)hipEventRecord(g_prof_ev[slot][0], s);
 }
 ProfScope::~ProfScope() {
-    if (slot >= 0) hipEventRecord(g_prof_ev[slot][1], s);
+    if (slot >= 0) (void)hipEventRecord(g_prof_ev[slot][1], s);
 }
 
 // Row-wise argmax, one wave per row; ties resolve to the lowest index (torch.argmax).
@@ -169,7 +172,10 @@ extern "C" int tal_prof_collect(int cls, double* total_ms, int64_t* launches, do
             return TAL_EHIP;
         }
         float t = 0.f;
-        hipEventElapsedTime(&t, g_prof_ev[i][0], g_prof_ev[i][1]);
+        if (hipEventElapsedTime(&t, g_prof_ev[i][0], g_prof_ev[i][1]) != hipSuccess) {
+            set_error("tal_prof_collect: cannot read the event pair of launch %d", i);
+            return TAL_EHIP;
+        }
         ms += t;
         work += g_prof_work[i];
         ++n;

@@ -3,14 +3,17 @@
 //   stride-2 "resize" conv, padding 0 ........ tal/asr/models.py:363-364
 //   TDSBlock grouped conv + ReLU + ReZero ..... tal/asr/models.py:304-308,329
 //
-// Activations are time-major [B, T, C].  A workgroup stages a [GB groups x C/G channels] x
-// [time tile + halo] slab of x into LDS, channel-major with an odd row pitch (conflict-free
-// both for the transposing store and for lanes that walk consecutive time steps).  Each
-// wave owns one group at a time: a lane accumulates all C_out/G output channels of R time
-// steps, so the weights of a group are wave-uniform and travel through SGPRs (s_load +
-// v_fmac with a scalar operand) while the x taps come from LDS: no per-FMA LDS weight
-// traffic.  The fp32 VALU rate equals the fp32 MFMA rate on gfx950 and a group's
-// 10/14/18-wide block does not fill a 16- or 32-wide MFMA tile, so this stays on the VALU.
+// Activations are time-major [B, T, C].  Three kernels:
+//   gconv_mfma_kernel   long inputs, 10 / 14 / 18 channels per group (and the stride-2 convs between them): on the fp16
+//                       matrix cores in the fp16x3 form, through a Hankel view of a time-major LDS slab (second half of
+//                       this file);
+//   gconv_s2_c1_kernel  the first resize conv (1 mel bin per group -> 10 channels): store-bound, channel-major lanes;
+//   gconv_kernel        fp32 VALU kernel for everything else (short inputs, TAL_TDS_F32=1, other widths): a workgroup
+//                       stages a [GB groups x C/G channels] x [time tile + halo] slab of x into LDS, channel-major with
+//                       an odd row pitch (conflict-free both for the transposing store and for lanes that walk
+//                       consecutive time steps); each wave owns one group at a time and a lane accumulates all C_out/G
+//                       output channels of R time steps, so the weights of a group are wave-uniform and travel through
+//                       SGPRs (s_load + v_fmac with a scalar operand) while the x taps come from LDS.
 #include "common.h"
 
 namespace tal {

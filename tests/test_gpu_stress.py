@@ -83,6 +83,54 @@ def test_gconv_random_shapes():
         np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, err_msg=str((cig, cog, T, B)))
 
 
+def test_gconv_f16x3_random_shapes():
+    """matrix-core grouped convs (TDSBlock conv with fused residual, stride-2 resize convs) on odd time axes: tile and
+    block boundaries of the 256- / 128-step tiles, inputs shorter than the halo, two batch items, guard rows."""
+    from tal_asrd_amd import ops
+    rng = np.random.default_rng(23)
+    G = 80
+    for _ in range(12):
+        cg = int(rng.choice([10, 14, 18]))
+        T = int(rng.choice([1, 2, 9, 10, 11, 15, 16, 17, 63, 255, 256, 257, 271, 300, 513, 777]))
+        B = int(rng.integers(1, 3))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn(B, G * cg, T, generator=g) * 3.0
+        w = torch.randn(G * cg, cg, 21, generator=g) / (21 * cg) ** 0.5
+        b = torch.randn(G * cg, generator=g)
+        ref = x.double() + 0.4 * torch.relu(torch.nn.functional.conv1d(x.double(), w.double(), b.double(), padding=10, groups=G))
+        wf = ops.pack_gconv_f16x3_weight(w.to(dev()), G)
+        y = ops.gconv_res_f16x3(x.permute(0, 2, 1).contiguous().to(dev()), wf, b.to(dev()), 0.4, G)
+        np.testing.assert_allclose(y.cpu().double().numpy(), ref.permute(0, 2, 1).numpy(), atol=3e-5, rtol=1e-5,
+                                   err_msg=str((cg, T, B)))
+    for _ in range(10):
+        cig, cog = [(10, 14), (14, 18)][int(rng.integers(0, 2))]
+        T = int(rng.choice([21, 22, 23, 24, 53, 54, 275, 276, 277, 278, 300, 511, 531, 1000]))
+        B = int(rng.integers(1, 3))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn(B, G * cig, T, generator=g) * 3.0
+        w = torch.randn(G * cog, cig, 21, generator=g) / (21 * cig) ** 0.5
+        b = torch.randn(G * cog, generator=g)
+        ref = torch.nn.functional.conv1d(x.double(), w.double(), b.double(), stride=2, groups=G).permute(0, 2, 1)
+        wf = ops.pack_gconv_f16x3_weight(w.to(dev()), G, stride=2)
+        y = ops.gconv_s2_f16x3(x.permute(0, 2, 1).contiguous().to(dev()), wf, b.to(dev()), G * cog, G)
+        np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), atol=3e-5, rtol=1e-5, err_msg=str((cig, cog, T, B)))
+
+
+def test_first_resize_conv_channel_major():
+    """the 1 -> 10 channels-per-group conv (channel-major lanes, coalesced stores) against float64, incl. the shortest input."""
+    from tal_asrd_amd import ops
+    G = 80
+    g = torch.Generator().manual_seed(99)
+    for T, B in ((21, 1), (533, 2), (1000, 1)):
+        x = torch.randn(B, T, G, generator=g).to(dev())
+        w = torch.randn(G * 10, 1, 21, generator=g).to(dev())
+        b = torch.randn(G * 10, generator=g).to(dev())
+        wp = ops.pack_gconv_weight(w, G)
+        y = ops.gconv_s2(x, wp, b, G * 10, G)
+        ref = torch.nn.functional.conv1d(x.cpu().double().permute(0, 2, 1), w.cpu().double(), b.cpu().double(), stride=2, groups=G).permute(0, 2, 1)
+        np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+
+
 def test_logmel_random_lengths():
     from oracle import tal_oracle as O
     from tal_asrd_amd import LogMelSpec

@@ -300,7 +300,7 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
         const int io = (ia + 1) % 4;
         float* a = (last_stage && d->depths[i] == 0) ? y : buf[io];
         // stride-2 resize conv: on the matrix cores for long inputs when the fragments are there (10 -> 14, 14 -> 18 per group)
-        if (!force_f32 && d->down_w_frag[i] && (int64_t)B * To > 512 && gconv_f16x3_weight_bytes(cin, c, d->groups, 2) > 0)
+        if (!force_f32 && d->down_w_frag[i] && (int64_t)B * To > 512 && gconv_f16x3_weight_bytes(cin, c, d->groups, 2) > 0 && gconv_f16x3_fits(Tc, cin))
             rc = launch_gconv_s2_f16x3(cur, d->down_w_frag[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s);
         else
             rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s);
@@ -315,7 +315,7 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
             float* x1s = buf[(ia + 3) % 4];
             float* outp = (last_stage && j == d->depths[i] - 1) ? y : buf[ia];
             const bool f16x3 = !force_f32 && bw.fc0_w_split && bw.fc3_w_split && M > 512 && c % 160 == 0;
-            const bool conv_mfma = f16x3 && bw.conv_w_frag && gconv_f16x3_weight_bytes(c, c, d->groups, 1) > 0;
+            const bool conv_mfma = f16x3 && bw.conv_w_frag && gconv_f16x3_weight_bytes(c, c, d->groups, 1) > 0 && gconv_f16x3_fits(To, c);
             // x1 = x + rw * relu(gconv(x))            : a -> x1
             // (The matrix-core kernel can also emit x1 as the hi / lo split; measured on the 1-hour shapes that fused store
             //  costs +0.35 / +0.21 / +0.14 ms per launch -- 8-byte pieces that fill 32-byte sectors only partially -- against

@@ -108,6 +108,7 @@ int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, i
 int launch_gconv_res(const float* x, const float* wp, const float* bias, float alpha, int B, int64_t T, int C,
                      int groups, float* y, hipStream_t s);
 size_t gconv_f16x3_weight_bytes(int C_in, int C_out, int groups, int stride);
+bool gconv_f16x3_fits(int64_t T, int C);
 int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C_in, int C_out, int groups, int stride, hipStream_t s);
 int launch_gconv_s2_f16x3(const float* x, const void* w_frag, const float* bias, int B, int64_t T_in, int C_in, int C_out, int groups,
                           float* y, hipStream_t s);

@@ -405,31 +405,36 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
             so[q] = gl * GS + (seg ? SL0 + ci - LY::nch(0) : ci);
             sp[q] = seg ? P1 : P0;
         }
-        const float* xc = xb + g0 * CIG + (active ? c4 * 4 : 0);
+        // Buffer loads over this batch item ([T_in, C_in] floats): a row before the first or past the last one is out of
+        // the descriptor's range and reads as zeros -- the conv's zero padding without clamps or selects.  (The pass offset
+        // has to travel in the lane offset: a scalar offset is not part of the range check.)
+        __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)(T_in * C_in * 4), 0x00020000);
+        const int64_t row0 = t0 * STRIDE - PADT + r0;
+        const bool row_ok = row0 > -(int64_t)(1 << 20);       // (always: keeps the 32-bit offset arithmetic visibly in range)
+        const int voff = (int)((row0 * C_in + g0 * CIG + (active ? c4 * 4 : 0)) * 4);
         constexpr int NPASS = (TIN + RPP - 1) / RPP, UNR = NPASS > 20 ? (NPASS + 1) / 2 : NPASS;
         for (int p0 = 0; p0 < NPASS; p0 += UNR) {
             f32x4 v[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int64_t t = t0 * STRIDE - PADT + r0 + (p0 + u) * RPP;
-                const int64_t tc = t < 0 ? 0 : (t >= T_in ? T_in - 1 : t);
-                v[u] = *reinterpret_cast<const f32x4*>(xc + tc * C_in);
-            }
+            for (int u = 0; u < UNR; ++u)
+                v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff + (p0 + u) * RPP * C_in * 4, 0, 0));
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int ti = r0 + (p0 + u) * RPP;
-                const int64_t t = t0 * STRIDE - PADT + ti;
-                const bool in = t >= 0 && t < T_in;          // zero padding at the true ends of the batch item
                 // stride 2: even input rows -> segment 0, odd rows -> segment 1, row ti / 2 of its slab
                 const int row = STRIDE == 2 ? ti >> 1 : ti;
                 const int tbase = (STRIDE == 2 && (ti & 1)) ? SL0 : 0;
-                if (active && ti < TIN) {
+                if (active && row_ok && ti < TIN) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        _Float16 h0, l0, h1, l1;
-                        split_f16x3(in ? v[u][2 * q] : 0.f, h0, l0);
-                        split_f16x3(in ? v[u][2 * q + 1] : 0.f, h1, l1);
-                        const f16x2 hh = {h0, h1}, ll = {l0, l1};
+                        // hi = fp16(x), lo = fp16((x - hi) * 2^11) on a channel pair (x clamped to the fp16 range first:
+                        // |lo| <= 2^15 then needs no clamp of its own; identical to split_f16x3 for |x| <= 65504)
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        const f32x2 xc2 = {__builtin_amdgcn_fmed3f(v[u][2 * q], -65504.f, 65504.f),
+                                           __builtin_amdgcn_fmed3f(v[u][2 * q + 1], -65504.f, 65504.f)};
+                        const f16x2 hh = __builtin_convertvector(xc2, f16x2);
+                        const f32x2 hf = __builtin_convertvector(hh, f32x2);
+                        const f16x2 ll = __builtin_convertvector((xc2 - hf) * 2048.f, f16x2);
                         *reinterpret_cast<f16x2*>(s_hi + so[q] + tbase + row * sp[q]) = hh;
                         *reinterpret_cast<f16x2*>(s_lo + so[q] + tbase + row * sp[q]) = ll;
                     }
@@ -629,6 +634,9 @@ static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias
     return TAL_OK;
 }
 
+// the slab loads address one batch item ([T, C] floats) through a buffer descriptor with 32-bit byte offsets
+bool gconv_f16x3_fits(int64_t T, int C) { return T * C * 4 + (int64_t)300 * C * 4 < ((int64_t)1 << 31); }
+
 size_t gconv_f16x3_weight_bytes(int C_in, int C_out, int groups, int stride) {
     if (groups <= 0 || C_in % groups || C_out % groups) return 0;
     GcPackDesc d;
@@ -655,6 +663,7 @@ int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias
     TAL_CHECK_ARG(B > 0 && T > 0, "tal_gconv_res_f16x3_fwd: bad shape");
     TAL_CHECK_ARG(!y_split || C % 32 == 0, "tal_gconv_res_f16x3_fwd: the split output needs C %% 32 == 0 (C=%d)", C);
     TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && C % 4 == 0, "tal_gconv_res_f16x3_fwd: x must be 16-byte aligned");
+    TAL_CHECK_ARG(gconv_f16x3_fits(T, C), "tal_gconv_res_f16x3_fwd: one batch item must stay below 2 GiB (T=%lld, C=%d)", (long long)T, C);
     const int cg = C / groups;
     if (cg == 10) return launch_mfma_spec<10, 10, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s);
     if (cg == 14) return launch_mfma_spec<14, 14, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s);
@@ -668,6 +677,7 @@ int launch_gconv_s2_f16x3(const float* x, const void* w_frag, const float* bias,
                   C_in, C_out, groups);
     TAL_CHECK_ARG(B > 0 && T_in >= KS, "tal_gconv_s2_f16x3_fwd: T_in=%lld shorter than the kernel", (long long)T_in);
     TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && C_in % 4 == 0, "tal_gconv_s2_f16x3_fwd: x must be 16-byte aligned");
+    TAL_CHECK_ARG(gconv_f16x3_fits(T_in, C_in), "tal_gconv_s2_f16x3_fwd: one batch item must stay below 2 GiB (T=%lld, C=%d)", (long long)T_in, C_in);
     const int64_t T_out = (T_in - KS) / 2 + 1;
     if (C_in / groups == 10) return launch_mfma_spec<10, 14, 2, false, 4, 128>(x, w_frag, bias, 0.f, y, nullptr, B, T_in, T_out, C_in, C_out, groups, s);
     return launch_mfma_spec<14, 18, 2, false, 2, 128>(x, w_frag, bias, 0.f, y, nullptr, B, T_in, T_out, C_in, C_out, groups, s);

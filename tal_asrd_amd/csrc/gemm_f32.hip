@@ -883,7 +883,8 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
             // cost of a candidate in rounds: the slices' own rounds + their scratch traffic (each slice
             // writes and the fix-up re-reads a 128x160 fp32 tile, ~4 TB/s) relative to one round's duration
             // (measured: 4.45 us per K step + ~14 us per tile, scripts/bench_gemm_fit.py)
-            const double round_us = 4.45 * nk + 14.0;
+            // (fp16x3 form: 1.56 us per K step + ~10.5 us per tile, scripts/ubench/gemm_f16x3.hip)
+            const double round_us = g.f16x3 ? 1.56 * nk + 10.5 : 4.45 * nk + 14.0;
             double best = 0.97;
             for (int sp = 2; sp <= 8 && sp <= nk / 4; ++sp) {
                 if ((size_t)rem * sp * 128 * 160 * sizeof(float) > g.splitk_ws_bytes) break;

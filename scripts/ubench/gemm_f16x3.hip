@@ -86,6 +86,17 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_f16x3_kernel(const
     for (int j = 0; j < NSUB; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) hh[j][e] = xx[j][e] = 0.f;
+#ifdef W2X2
+    // 2 x 2 wave layout, wave tile 64 x 80 as 4 x 5 tiles of v_mfma_f32_16x16x32_f16: 18 fragment reads per K step
+    // instead of 24 (each A fragment serves 5 N tiles, each B fragment 4 M tiles), same MFMA cycles (60 x 16)
+    static_assert(WAVES == 4, "2 x 2 layout");
+    f32x4 c1[4][5], c2[4][5];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b) c1[a][b] = c2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wm2 = w >> 1, wn2 = w & 1, r16 = lane & 15, kg16 = lane >> 4;
+#endif
     const int frow = lane & 31, fsw = (frow >> 1) & 7, fhalf = lane >> 5;
 #ifdef DEPHASE      // timing experiment: the second workgroup of every CU starts half a tile late (its first tile is cut short)
     const int nk = (blockIdx.x >= 256 && blockIdx.x < 512) ? K / BK / 2 : K / BK;
@@ -105,6 +116,40 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_f16x3_kernel(const
         const int kb = (ABL & 2) ? 0 : (kt & 1);
         const float* Asl = lds + kb * (ROWS * 32) + (w * 32 + frow) * 32;
         const float* Bsl = lds + kb * (ROWS * 32) + (BM + frow) * 32;
+#ifdef W2X2
+        {
+            // a 128-byte row of this K block is [32 hi | 32 lo]; lane (row r16, k group kg16) takes k = 8 kg16 .. + 7:
+            // logical slot kg16 (hi), 4 + kg16 (lo), at physical slot s ^ ((row >> 1) & 7)
+            const float* A2 = lds + kb * (ROWS * 32) + (wm2 * 64 + r16) * 32;
+            const float* B2 = lds + kb * (ROWS * 32) + (BM + wn2 * 80 + r16) * 32;
+            const int sw = (r16 >> 1) & 7;                       // rows 16 a + r16: (row >> 1) & 7 = ((8 a) + (r16 >> 1)) & 7 = sw
+            const int shi = ((kg16) ^ sw) * 4, slo = ((4 + kg16) ^ sw) * 4;
+            h8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                ah[a] = *reinterpret_cast<const h8*>(A2 + a * 16 * 32 + shi);
+                al[a] = *reinterpret_cast<const h8*>(A2 + a * 16 * 32 + slo);
+            }
+            bh[0] = *reinterpret_cast<const h8*>(B2 + shi);
+            bl[0] = *reinterpret_cast<const h8*>(B2 + slo);
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                if (b + 1 < 5) {
+                    bh[(b + 1) & 1] = *reinterpret_cast<const h8*>(B2 + (b + 1) * 16 * 32 + shi);
+                    bl[(b + 1) & 1] = *reinterpret_cast<const h8*>(B2 + (b + 1) * 16 * 32 + slo);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    c1[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b & 1], c1[a][b], 0, 0, 0);
+                    c2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b & 1], c2[a][b], 0, 0, 0);
+                    c2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b & 1], c2[a][b], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            continue;
+        }
+#endif
         // flattened (g, j) stages q = 5 g + j: stage q issues the B fragments of stage q + 2 (and the A fragments of the
         // next g at q = 3) before its three MFMAs, so every LDS read has ~200 cycles of MFMA work between issue and use
         h8 ahi[2], alo[2], bhi[3], blo[3];
@@ -151,6 +196,21 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_f16x3_kernel(const
         clk[2 * blockIdx.x] = (long long)(clock64() - c0);
         clk[2 * blockIdx.x + 1] = (long long)(wall_clock64() - w0);
     }
+#ifdef W2X2
+    // 16x16 C layout: col = lane & 15, rows 4 (lane >> 4) + i
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            const int col = n0 + wn2 * 80 + b * 16 + r16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t row = m0 + wm2 * 64 + a * 16 + 4 * kg16 + i;
+                if (row < M && col < N) C[row * N + col] = c1[a][b][i] + c2[a][b][i] * (1.0f / 2048.0f);
+            }
+        }
+    return;
+#endif
     const int colb = lane & 31, rowb = 4 * (lane >> 5);
 #pragma unroll
     for (int j = 0; j < NSUB; ++j) {

@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seconds", type=float, default=3600.0, help="clip length per segment")
     ap.add_argument("--segments", type=int, default=1, help="segments (independent B=1 calls) per GPU per step")
+    ap.add_argument("--batched", action="store_true", help="process the segments of a step as ONE [segments, L] call "
+                    "(one reference call: the log-mel mean then couples the batch, tal/asr/models.py:52)")
     ap.add_argument("--cpu-seconds", type=float, default=300.0, help="clip length of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event timing")
@@ -145,6 +147,8 @@ def main():
     frames = 1 + L // 160
     clips = [torch.from_numpy(synth.synth_audio_batch(1, L, 1234 + rank * args.segments + i)).to(dev)
              for i in range(args.segments)]
+    if args.batched:
+        clips = [torch.cat(clips, dim=0)]
     torch.cuda.synchronize()
     # PCIe-inclusive figure (reported beside `value`, never as `value`): one pinned-host -> device copy
     h2d_ms = None
@@ -228,10 +232,10 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if os.environ.get("TAL_TDS_F32") else "f32 (dense layers: 3 x f16 MFMA hi/lo split, f32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "%d x %.0f s 16 kHz clip per GPU, each a whole-episode B=1 call "
+            "config": {"workload": (("%d x %.0f s 16 kHz clips per GPU as one batched call " if args.batched else
+                                     "%d x %.0f s 16 kHz clip per GPU, each a whole-episode B=1 call ") % (args.segments, args.seconds)) +
                                    "(BASELINE.json configs[2]; SDModel path of tal/baseline/reconcile.py:76-85: "
-                                   "log-mel -> TDS 80-800-1120-1440 -> 128-d feat + argmax over 6008 speakers)"
-                                   % (args.segments, args.seconds),
+                                   "log-mel -> TDS 80-800-1120-1440 -> 128-d feat + argmax over 6008 speakers)",
                        "frames_per_gpu_per_step": args.segments * frames, "weights": "synthetic deterministic",
                        "audio_resident_in_hbm": True},
         }

@@ -139,12 +139,13 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_f16x3_kernel(const
                     bl[(b + 1) & 1] = *reinterpret_cast<const h8*>(B2 + (b + 1) * 16 * 32 + slo);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // (no accumulator twice in a row: a 4-pass MFMA that reads the previous one's result stalls the pipe)
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    c1[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b & 1], c1[a][b], 0, 0, 0);
-                    c2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b & 1], c2[a][b], 0, 0, 0);
-                    c2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b & 1], c2[a][b], 0, 0, 0);
-                }
+                for (int a = 0; a < 4; ++a) c1[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b & 1], c1[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) c2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b & 1], c2[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) c2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b & 1], c2[a][b], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             continue;

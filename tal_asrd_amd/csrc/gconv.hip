@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
         // has to travel in the lane offset: a scalar offset is not part of the range check.)
         __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)(T_in * C_in * 4), 0x00020000);
         const int64_t row0 = t0 * STRIDE - PADT + r0;
-        const bool row_ok = row0 > -(int64_t)(1 << 20);       // (always: keeps the 32-bit offset arithmetic visibly in range)
+        // (32-bit byte offset: launch_* checks that a batch item stays below 2 GiB; a negative row wraps to an offset past the range)
         const int voff = (int)((row0 * C_in + g0 * CIG + (active ? c4 * 4 : 0)) * 4);
         constexpr int NPASS = (TIN + RPP - 1) / RPP, UNR = NPASS > 20 ? (NPASS + 1) / 2 : NPASS;
         for (int p0 = 0; p0 < NPASS; p0 += UNR) {
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
                 // stride 2: even input rows -> segment 0, odd rows -> segment 1, row ti / 2 of its slab
                 const int row = STRIDE == 2 ? ti >> 1 : ti;
                 const int tbase = (STRIDE == 2 && (ti & 1)) ? SL0 : 0;
-                if (active && row_ok && ti < TIN) {
+                if (active && ti < TIN) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         // hi = fp16(x), lo = fp16((x - hi) * 2^11) on a channel pair (x clamped to the fp16 range first:

@@ -271,18 +271,32 @@ int tal_beam_topk(const float* logprobs, const float* row_score, const uint8_t* 
                   int cur_beam, int V, int k, float* out_val, int64_t* out_idx, void* stream);
 
 /* ------------------------------------------------------------------ *
- * Attention-weighted pooling of diarization features per generated token,
- * tal/utils/aligned_to_wder_format.py:150-178,203-214 (consumes the `attention` and
- * `chunkStart` alignments of generate_unaligned together with SDModel features / ids).
+ * Attention-weighted pooling of diarization features and speaker votes per generated token / word /
+ * utterance: tal/utils/aligned_to_wder_format.py:150-214 (unaligned), :321-353 (aligned).  Consumes the
+ * `attention` and `chunkStart` alignments of generate_unaligned together with SDModel features / ids.
  *   attn [N, S], chunk_start int64 [N], feat [T, E], ids int32 [T]
- *   pool: out[n] = sum_s attn[n,s] * feat[chunk_start[n] + s]   (s truncated at T, as aw[:len(chunk)])
- *   vote: out_id[n] = speaker id with the largest summed attention inside the window
- *         (out_weight [N] = that sum, may be NULL)
+ *   window of token n = the python slice x[cs : cs + S] (negative starts wrap from the end, ends are clamped;
+ *   attention is truncated to the slice length, as aw[:len(chunk)])
+ *   pool: out[n] = sum_s attn[n,s] * feat[window(n)][s]; half_mode != 0 reproduces the reference's arithmetic:
+ *         attention and features rounded to fp16 (`.half()`), fp32 accumulation, fp16-rounded result
+ *   vote: out_id[n] = speaker id with the largest summed attention inside the window (lowest position on ties;
+ *         out_weight [N] = that sum, may be NULL)
+ *   vote_groups: the same vote over the tokens [group_offsets[g], group_offsets[g+1]) of each of G groups (one word,
+ *         :150-196): float64 sums; half_mode rounds the attention to fp16 first (then the sums are exact and
+ *         order-independent); ties go to the id whose first appearance is LAST (sorted(...)[-1] over a dict in
+ *         insertion order); empty group -> -1.  ids outside [0, num_ids) are ignored; num_ids * 12 bytes of LDS.
+ *   majority_vote: most frequent id in the python slice ids[ranges[2g] : ranges[2g+1]] (:330-333,
+ *         Counter.most_common(1): ties go to the id that appears first); empty range -> -1.
  * ------------------------------------------------------------------ */
 int tal_attn_pool_fwd(const float* attn, const int64_t* chunk_start, const float* feat, int64_t T,
-                      int E, int N, int S, float* out, void* stream);
+                      int E, int N, int S, int half_mode, float* out, void* stream);
 int tal_attn_vote_fwd(const float* attn, const int64_t* chunk_start, const int32_t* ids, int64_t T,
                       int N, int S, int32_t* out_id, float* out_weight, void* stream);
+int tal_attn_vote_groups_fwd(const float* attn, const int64_t* chunk_start, const int32_t* ids, int64_t T,
+                             int S, const int64_t* group_offsets, int G, int num_ids, int half_mode,
+                             int32_t* out_id, double* out_weight, void* stream);
+int tal_majority_vote_fwd(const int32_t* ids, int64_t T, const int64_t* ranges, int G, int num_ids,
+                          int32_t* out_id, double* out_count, void* stream);
 
 /* ------------------------------------------------------------------ *
  * GRU cell of UIS-RNN's CoreRNN, tal/diarization/uisrnn/uisrnn.py:20-39 (torch.nn.GRU,

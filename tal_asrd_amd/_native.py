@@ -79,7 +79,9 @@ SIGNATURES = {
     "tal_greedy_pick_fwd": (_i, [_p, _i, _p, _i, _i64, _i, _p, _p, _p]),
     "tal_log_softmax_rows": (_i, [_p, _i64, _i, _p, _p]),
     "tal_beam_topk": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
-    "tal_attn_pool_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p]),
+    "tal_attn_pool_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i, _p, _p]),
+    "tal_attn_vote_groups_fwd": (_i, [_p, _p, _p, _i64, _i, _p, _i, _i, _i, _p, _p, _p]),
+    "tal_majority_vote_fwd": (_i, [_p, _i64, _p, _i, _i, _p, _p, _p]),
     "tal_attn_vote_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _p, _p, _p]),
     "tal_gru_cell_workspace_bytes": (_sz, [_i, _i]),
     "tal_gru_cell_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),

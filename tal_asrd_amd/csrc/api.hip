@@ -367,9 +367,16 @@ extern "C" int tal_linear_f16x3_fwd(const void* x_split, const void* w_split, co
 // ---------------------------------------------------------------------------------------
 // Diarization head
 // ---------------------------------------------------------------------------------------
+static int sd_head_part_ld(int S) {
+    const int64_t a = cdiv(S, 32), b = 4 * cdiv(S, 128);
+    return (int)(a > b ? a : b);
+}
+
 extern "C" size_t tal_sd_head_workspace_bytes(int64_t M, int S) {
-    // (value, index) partials of the fused arg-max: one pair per row and per 32 columns at most
-    return (size_t)(M > 0 ? M : 1) * (size_t)cdiv(S, 32) * 8;
+    // (value, index) partials of the fused arg-max: one pair per row and per 32-column wave slice.  The small-M
+    // kernel (32 x 128 tile, 4 waves side by side) writes 4 slots per 128-column tile, the last tile included
+    // even when it is partly past S, hence the second term.
+    return (size_t)(M > 0 ? M : 1) * (size_t)sd_head_part_ld(S) * 8;
 }
 
 extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_embed, const float* b_embed, int E,
@@ -416,7 +423,7 @@ extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_
     }
     // logits are never materialised: the dense layer's epilogue reduces each row of its tile to a
     // (max, arg-max) pair, a tiny second kernel merges the pairs of a row's column tiles
-    const int ld = (int)cdiv(S, 32);
+    const int ld = sd_head_part_ld(S);
     GemmArgs g = {};
     g.A = feat; g.W = w_logit; g.bias = b_logit;
     g.M = M; g.N = S; g.K = E;

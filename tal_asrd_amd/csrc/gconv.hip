@@ -245,7 +245,8 @@ int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, i
     TAL_CHECK_ARG(B > 0 && T_in >= KS, "tal_gconv_s2_fwd: T_in=%lld shorter than the kernel", (long long)T_in);
     const int64_t T_out = (T_in - KS) / 2 + 1;
     const int cig = C_in / groups, cog = C_out / groups;
-    if (cig == 1 && cog == 10 && groups % 20 == 0 && C_in % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !getenv("TAL_GCONV_C1_GENERIC")) {
+    static const bool c1_generic = getenv("TAL_GCONV_C1_GENERIC") != nullptr;
+    if (cig == 1 && cog == 10 && groups % 20 == 0 && C_in % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !c1_generic) {
         // channel-major lanes: coalesced 256-byte stores (0.29 -> 0.16 ms on the 1-hour shape)
         constexpr int NG = 20, TT = 256;
         dim3 grid((unsigned)cdiv(T_out, TT), (unsigned)(groups / NG), (unsigned)B);

@@ -832,7 +832,8 @@ static void launch_glds(const GemmArgs& g, int mode, bool splitk, dim3 grid, hip
 
 int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
     TAL_CHECK_ARG(g.A && g.W && (g.Y || mode == 4), "gemm: null pointer");
-    TAL_CHECK_ARG(mode != 4 || (g.part_val && g.part_idx && g.part_ld >= (int)cdiv(g.N, 32)), "gemm: mode 4 needs partial buffers");
+    TAL_CHECK_ARG(mode != 4 || (g.part_val && g.part_idx && g.part_ld >= gemm_mode4_partials(g.M, g.N)),
+                  "gemm: mode 4 needs partial buffers with part_ld >= %d", gemm_mode4_partials(g.M, g.N));
     TAL_CHECK_ARG(g.M >= 0 && g.N > 0 && g.K > 0, "gemm: bad shape M=%lld N=%d K=%d", (long long)g.M, g.N, g.K);
     TAL_CHECK_ARG(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0, "gemm: K=%d lda=%lld ldw=%lld must be multiples of 4", g.K, (long long)g.lda, (long long)g.ldw);
     TAL_CHECK_ARG(mode >= 0 && mode <= 4, "gemm: mode %d", mode);
@@ -854,9 +855,12 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
     dim3 grid((unsigned)nb, (unsigned)nbatch);
     ProfScope prof(PROF_GEMM, 2.0 * (double)g.M * (double)g.N * (double)g.K * nbatch, s);
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) == 0;
+    // ablation switches, read once per process (a decode step is ~60 launches: no getenv on the launch path)
+    static const bool no_splitk4 = getenv("TAL_GEMM_NO_SPLITK4") != nullptr, no_glds = getenv("TAL_GEMM_NO_GLDS") != nullptr,
+                      no_tail = getenv("TAL_GEMM_NO_SPLITK_TAIL") != nullptr;
     // small problems are latency-bound (a K step costs one L2 round trip, not its 16 MFMAs): a
     // 128-deep K slab quarters the number of dependent round trips
-    if (small && mode != 4 && aligned16 && !getenv("TAL_GEMM_NO_SPLITK4")) {
+    if (small && mode != 4 && aligned16 && !no_splitk4) {
         GemmArgs h = g;
         h.tiles_n = (int)cdiv(g.N, 32);
         const int64_t nb2 = cdiv(g.M, 32) * h.tiles_n;
@@ -866,7 +870,7 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
         launch_tile<1, 1, 128>(g, mode, grid, s);
     else if (small)
         launch_tile<1, 1, 32>(g, mode, grid, s);
-    else if (g.K % BK == 0 && aligned16 && !getenv("TAL_GEMM_NO_GLDS")) {
+    else if (g.K % BK == 0 && aligned16 && !no_glds) {
         // (a 128 x 96 tile -- 10.3 instead of 6.2 rounds on the 1-hour stage-3 shape -- was measured at
         //  +2 %, inside run-to-run noise: the 160-wide tile stays)
         // Stream-K-lite: 2 workgroups per CU are resident, so a launch proceeds in rounds of 2*CUs
@@ -879,7 +883,7 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
         const int64_t rem = nb % slots, full = nb - rem;
         const int nk = g.K / BK;
         int split = 0;
-        if (rem > 0 && full > 0 && nbatch == 1 && mode <= 3 && g.splitk_ws && !getenv("TAL_GEMM_NO_SPLITK_TAIL")) {
+        if (rem > 0 && full > 0 && nbatch == 1 && mode <= 3 && g.splitk_ws && !no_tail) {
             // cost of a candidate in rounds: the slices' own rounds + their scratch traffic (each slice
             // writes and the fix-up re-reads a 128x160 fp32 tile, ~4 TB/s) relative to one round's duration
             // (measured: 4.45 us per K step + ~14 us per tile, scripts/bench_gemm_fit.py)

@@ -225,13 +225,16 @@ __global__ __launch_bounds__(256, 2) void head_argmax_kernel(const float* __rest
 bool head_argmax_applicable(int64_t M, int S, int E) {
     if (E != HK || S < HBN) return false;
     const int64_t units = cdiv(M, HBM) * cdiv(S, HBN);
-    int cus = 256;
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-        cus = p.multiProcessorCount;
+    static const bool no_astationary = getenv("TAL_HEAD_NO_ASTATIONARY") != nullptr;
+    static int cus = 0;           // (one query per process: hipGetDeviceProperties costs tens of microseconds per call)
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+                  ? p.multiProcessorCount : 256;
+    }
     // every workgroup needs a run of at least half a row block's N tiles, so that a row block spans <= HP workgroups
-    return units >= (int64_t)2 * cus * ((cdiv(S, HBN) + 1) / 2) && !getenv("TAL_HEAD_NO_ASTATIONARY");
+    return units >= (int64_t)2 * cus * ((cdiv(S, HBN) + 1) / 2) && !no_astationary;
 }
 
 int head_argmax_partials() { return HP; }

@@ -60,11 +60,21 @@ def _kpm_u8(mask, B, S, device):
     return m.to(torch.uint8).contiguous()
 
 
+def _check_memory(memory, B, E, what):
+    """The kernels stride the memory / its K, V^T caches per batch item of `tgt`: a memory with another batch size
+    (e.g. `speaker_out`, which the reference's beam search does not repeat, system.py:168-171) would be read out
+    of bounds, where the reference raises a shape error inside nn.MultiheadAttention."""
+    if memory.dim() != 3 or memory.shape[0] != B or memory.shape[2] != E:
+        raise N.NativeError("%s: memory must be [batch=%d, src_len, d_model=%d], got %s"
+                            % (what, B, E, tuple(memory.shape)))
+
+
 def cross_kv(layer, memory):
     """(K [B,S,E], V^T [B,E,S4]) of `memory` for this layer's cross-attention, cached per memory tensor."""
     lib = N.lib()
     key = (memory.data_ptr(), memory._version, tuple(memory.shape),
-           layer.multihead_attn.in_proj_weight.data_ptr(), layer.multihead_attn.in_proj_weight._version)
+           layer.multihead_attn.in_proj_weight.data_ptr(), layer.multihead_attn.in_proj_weight._version,
+           layer.multihead_attn.in_proj_bias.data_ptr(), layer.multihead_attn.in_proj_bias._version)
     cached = getattr(layer, "_tal_kv", None)
     if cached is not None and cached[0] == key:
         return cached[1], cached[2]
@@ -83,6 +93,7 @@ def run_layer(layer, tgt, memory, tgt_mask=None, kpm=None, want_weights=True, ca
     tgt = ops._f32c(tgt, "decoder layer (tgt)")
     memory = ops._f32c(memory, "decoder layer (memory)")
     B, U, E = tgt.shape
+    _check_memory(memory, B, E, "decoder layer")
     S = memory.shape[1]
     H = layer.nhead
     FF = layer.linear1.out_features
@@ -162,7 +173,9 @@ def _stack_structs(stack):
 
 def _stack_kv(stack, memory):
     """Per-layer cached cross-attention K / V^T pointer arrays for `memory`."""
-    key = (memory.data_ptr(), memory._version, tuple(memory.shape))
+    key = (memory.data_ptr(), memory._version, tuple(memory.shape)) + tuple(
+        (l.multihead_attn.in_proj_weight.data_ptr(), l.multihead_attn.in_proj_weight._version,
+         l.multihead_attn.in_proj_bias.data_ptr(), l.multihead_attn.in_proj_bias._version) for l in stack.layers)
     cached = getattr(stack, "_tal_stack_kv", None)
     if cached is None or cached[0] != key:
         ks, vts = [], []
@@ -184,6 +197,7 @@ def _run_stack(model, stack, y_prev, memory, mask, causal, check_tokens=True):
     h = _embed(model, y_prev, check_tokens)
     memory = ops._f32c(memory, "decode(memory)")
     B, U, E = h.shape
+    _check_memory(memory, B, E, "decode")
     S = memory.shape[1]
     kpm = _kpm_u8(mask, B, S, h.device)
     tm = causal_mask(U, h.device) if causal else None

@@ -188,21 +188,54 @@ class TDS(nn.Module):
                 nn.Sequential(*[TDSBlock(sizes[i], kernel_size, input_size, dropout=dropout)
                                 for _ in range(depths[i - 1])]))
             for i in range(1, len(sizes))])
-        self._desc = None
-        self._desc_key = None
-        self._keep = None
+        self._plist = None
+        self._descs = {}        # (first, last) -> tal_tds_desc
+        self._packs = {}        # stage -> packed / split weights (kept alive here)
+        self._desc_key = None   # parameter versions the caches were built for
+
+    def _apply(self, fn, *a, **kw):
+        self._plist = None          # .to() / .cuda() may replace the Parameter objects
+        return super()._apply(fn, *a, **kw)
+
+    def _param_key(self):
+        # (walking the module tree costs ~200 us per call, the cached list ~15 us: it matters for 30-second clips)
+        if self._plist is None:
+            self._plist = list(self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in self._plist)
+
+    def _stage_pack(self, s):
+        """Kernel-side weight forms of stage s (resize conv + its TDSBlocks), built once per parameter version and
+        shared by every descriptor that covers the stage (forward / extract / aggregate)."""
+        if s in self._packs:
+            return self._packs[s]
+        down, chain = self.blocks[s][0], self.blocks[s][1]
+        c = self.sizes[s + 1]
+        pack = {"down_w": down.packed(), "down_frag": ops.pack_gconv_f16x3_weight(down.weight.detach(), down.groups, stride=2),
+                "blocks": []}
+        rws = torch.stack([blk.resweight.detach().reshape(()) for blk in chain]).cpu().tolist() if len(chain) else []
+        for blk, rw in zip(chain, rws):
+            g = blk.conv[0]
+            b = {"conv_w": g.packed(), "rw": float(rw), "fc0_split": None, "fc3_split": None, "conv_frag": None}
+            if c % 160 == 0:
+                # hi / lo fp16 splits of the two pointwise weights: long inputs run these layers in the fp16x3
+                # form (include/tal_asrd.h), fp32-equivalent results at ~2.4x the fp32 matrix rate
+                b["fc0_split"] = ops.split_f16x3(blk.fc[0].weight.detach().reshape(c, c))
+                b["fc3_split"] = ops.split_f16x3(blk.fc[3].weight.detach().reshape(c, c))
+                # ... and the grouped conv as fp16x3 MFMA operand fragments (widths 10 / 14 / 18 per group)
+                b["conv_frag"] = ops.pack_gconv_f16x3_weight(g.weight.detach(), g.groups)
+            pack["blocks"].append(b)
+        self._packs[s] = pack
+        return pack
 
     def _descriptor(self, first=0, last=None):
-        """Build (and cache) the tal_tds_desc for stages [first, last)."""
+        """Build (and cache per (first, last)) the tal_tds_desc for stages [first, last)."""
         last = len(self.sizes) - 1 if last is None else last
-        key = [first, last]
-        for p in self.parameters():
-            key.append((p.data_ptr(), p._version))
-        key = tuple(key)
-        if self._desc is not None and self._desc_key == key:
-            return self._desc
+        key = self._param_key()
+        if key != self._desc_key:          # a parameter changed (load_state_dict, .to(device)): drop every cached form
+            self._descs, self._packs, self._desc_key = {}, {}, key
+        if (first, last) in self._descs:
+            return self._descs[(first, last)]
         d = N.TdsDesc()
-        keep = []
         d.n_stages = last - first
         d.groups = self.input_size
         for s in range(first, last + 1):
@@ -210,38 +243,24 @@ class TDS(nn.Module):
         for s in range(first, last):
             i = s - first
             down, chain = self.blocks[s][0], self.blocks[s][1]
+            pack = self._stage_pack(s)
             d.depths[i] = len(chain)
-            pw = down.packed()
-            keep.append(pw)
-            d.down_w[i] = pw.data_ptr()
+            d.down_w[i] = pack["down_w"].data_ptr()
             d.down_b[i] = down.bias.data_ptr()
-            dwf = ops.pack_gconv_f16x3_weight(down.weight.detach(), down.groups, stride=2)
-            if dwf is not None:
-                keep.append(dwf)
-                d.down_w_frag[i] = dwf.data_ptr()
-            for j, blk in enumerate(chain):
+            if pack["down_frag"] is not None:
+                d.down_w_frag[i] = pack["down_frag"].data_ptr()
+            for j, (blk, b) in enumerate(zip(chain, pack["blocks"])):
                 g = blk.conv[0]
-                gp = g.packed()
-                keep.append(gp)
                 bw = d.blocks[i][j]
-                bw.conv_w, bw.conv_b = gp.data_ptr(), g.bias.data_ptr()
+                bw.conv_w, bw.conv_b = b["conv_w"].data_ptr(), g.bias.data_ptr()
                 bw.fc0_w, bw.fc0_b = blk.fc[0].weight.data_ptr(), blk.fc[0].bias.data_ptr()
                 bw.fc3_w, bw.fc3_b = blk.fc[3].weight.data_ptr(), blk.fc[3].bias.data_ptr()
-                bw.resweight = float(blk.resweight.detach())
-                c = self.sizes[s + 1]
-                if c % 160 == 0:
-                    # hi / lo fp16 splits of the two pointwise weights: long inputs run these layers in the fp16x3
-                    # form (include/tal_asrd.h), fp32-equivalent results at ~2.4x the fp32 matrix rate
-                    w0s = ops.split_f16x3(blk.fc[0].weight.detach().reshape(c, c))
-                    w3s = ops.split_f16x3(blk.fc[3].weight.detach().reshape(c, c))
-                    keep += [w0s, w3s]
-                    bw.fc0_w_split, bw.fc3_w_split = w0s.data_ptr(), w3s.data_ptr()
-                    # ... and the grouped conv as fp16x3 MFMA operand fragments (widths 10 / 14 / 18 per group)
-                    wf = ops.pack_gconv_f16x3_weight(g.weight.detach(), g.groups)
-                    if wf is not None:
-                        keep.append(wf)
-                        bw.conv_w_frag = wf.data_ptr()
-        self._desc, self._desc_key, self._keep = d, key, keep
+                bw.resweight = b["rw"]
+                if b["fc0_split"] is not None:
+                    bw.fc0_w_split, bw.fc3_w_split = b["fc0_split"].data_ptr(), b["fc3_split"].data_ptr()
+                if b["conv_frag"] is not None:
+                    bw.conv_w_frag = b["conv_frag"].data_ptr()
+        self._descs[(first, last)] = d
         return d
 
     def forward_time_major(self, x, first=0, last=None):

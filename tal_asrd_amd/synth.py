@@ -203,3 +203,21 @@ def uisrnn_sequence(n_obs: int, obs_dim: int, n_speakers: int, seed: int, noise:
         cur = (cur + int(rng.randint(1, n_speakers))) % n_speakers
     labels = labels[:n_obs]
     return cent[labels] + noise * rng.randn(n_obs, obs_dim), labels
+
+
+# ----------------------------------------------------------------------------------------------
+# Synthetic text side.  The reference's sentencepiece model (`taltoken-cased.model`) does not ship,
+# so token ids are turned into text by a deterministic piece table with sentencepiece's conventions:
+# a piece either starts a word (leading U+2581, decoded as a space) or continues one.
+# ----------------------------------------------------------------------------------------------
+def token_piece(t: int) -> str:
+    """Piece of token id t: about two thirds of the ids start a word."""
+    t = int(t)
+    starts_word = ((t * 2654435761) >> 7) % 3 != 0
+    return ("▁" if starts_word else "") + "t%d" % t
+
+
+def decode_pieces(tokens) -> str:
+    """sentencepiece-style DecodeIds over the synthetic piece table (leading space stripped)."""
+    s = "".join(token_piece(t) for t in tokens).replace("▁", " ")
+    return s[1:] if s.startswith(" ") else s

@@ -47,12 +47,41 @@ class System:
     """Holds the model and the decode-time arguments the reference reads from `self.args`
     (spk_weight, lm_weight) and `self.tokenizer` (eos_token_id)."""
 
-    def __init__(self, model, spk_weight=0.0, eos_token_id=1, bos_token_id=0, pad_token_id=2):
+    def __init__(self, model, spk_weight=0.0, eos_token_id=1, bos_token_id=0, pad_token_id=2, tokenizer=None):
         self.model = model
         self.args = SimpleNamespace(spk_weight=spk_weight, lm_weight=0.0)
-        self.tokenizer = SimpleNamespace(eos_token_id=eos_token_id, bos_token_id=bos_token_id,
-                                         pad_token_id=pad_token_id)
+        self.tokenizer = tokenizer if tokenizer is not None else SimpleNamespace(
+            eos_token_id=eos_token_id, bos_token_id=bos_token_id, pad_token_id=pad_token_id)
         self.lm = None
+
+    # ------------------------------------------------------------------ episode -> utterance dicts
+    @torch.no_grad()
+    def transcribe_unaligned(self, audio_x, audio_lens, prime=None, **kw):
+        """The unaligned branch of `System.test_step` (tal/asr/system.py:654-707) for one episode: sliding-window
+        decode primed with EOS ("First token is always EOS"), `tokenizer.decode_speakers` on the generated stream
+        without its last token, and per utterance the attention rows / window starts / tokens of
+        `alignments[last_split : split + 1]`.  Needs a tokenizer with `decode_speakers` (tal_asrd_amd.tokenizer).
+        -> (utterance dicts as pickled by the reference into out/test_result.pkl, generated, alignments)."""
+        if prime is None:
+            prime = torch.full((1, 1), self.tokenizer.eos_token_id, dtype=torch.int64, device=audio_x.device)
+        generated, alignments = self.generate_unaligned(audio_x, prime, audio_lens, chunk_size=357, **kw)
+        hyp = generated[0]
+        if hyp is None or len(hyp) <= 1:
+            return [], generated, alignments
+        hyp = hyp[:-1].tolist()
+        utts, split_indices = self.tokenizer.decode_speakers(hyp)
+        utts = [{"utterance": text, "speakerId": sid} for text, sid in utts]
+        last_split_i = 0
+        for utt, split_i in zip(utts, split_indices):
+            assert split_i - last_split_i > 0
+            relevant = alignments[last_split_i:split_i + 1]
+            assert len(relevant) > 0
+            chunk_starts, weights = zip(*relevant)
+            utt["attention"] = torch.cat(weights, dim=0)
+            utt["chunkStart"] = torch.cat(chunk_starts, dim=0)
+            utt["utteranceTokens"] = hyp[last_split_i:split_i + 1]
+            last_split_i = split_i
+        return utts, generated, alignments
 
     # ------------------------------------------------------------------ aligned: batched beam search
     @torch.no_grad()

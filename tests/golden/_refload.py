@@ -139,8 +139,12 @@ def load_reference():
                                     "tal/diarization/uisrnn/%s.py" % sub))
     uis_pkg.uisrnn = _load("wildspeech.diarization.uisrnn.uisrnn", "tal/diarization/uisrnn/uisrnn.py")
 
+    # the tokenizer base class (decode_speakers, tal/asr/tokenizers/__init__.py:103-138) under its own name: the
+    # package name above stays a stand-in because its sentencepiece sub-module needs a model file that does not ship
+    tokenizers = _load("wildspeech_asr_tokenizers_base", "tal/asr/tokenizers/__init__.py")
+
     ns = types.SimpleNamespace(models=asr.models, modules=ws.modules, util=asr.util,
                                system=asr.system, uisrnn=uis_pkg.uisrnn,
-                               transcribe=asr.transcribe)
+                               transcribe=asr.transcribe, tokenizers=tokenizers)
     _loaded["ns"] = ns
     return ns

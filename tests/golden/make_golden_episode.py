@@ -1,0 +1,503 @@
+"""Record the configs[4] fixture (BASELINE.json: full joint decode of an episode -> speaker-change
+indices -> WDER) from the reference's OWN code.  BUILD-CONTAINER ONLY (imports /root/reference).
+
+    python tests/golden/make_golden_episode.py [--seconds 3600] [--stage decode|wder|all]
+
+Chain, every link executed by the reference's code where it lies:
+  1. System.test_step (tal/asr/system.py:625-742, unaligned branch) on a stand-in `self` carrying the
+     reference ASRModel filled with the synthetic weights -> System.generate_unaligned (:254-524) over the
+     whole episode -> _Tokenizer.decode_speakers (tal/asr/tokenizers/__init__.py:103-138) -> utterance
+     dicts with 'attention' / 'chunkStart' / 'utteranceTokens' (:696-707) -> out/test_result.pkl.
+  2. the reference SDModel on the same audio (tal/baseline/reconcile.py:76-85 get_speaker_ids arithmetic)
+     -> per-encoder-frame 128-d features and arg-max speaker ids.
+  3. tal/utils/aligned_to_wder_format.py run as the script it is (runpy, --unaligned with and without
+     --word-level) -> wder_ready pickles.
+  4. tal/wder.py corpus_wder on them.
+Stand-ins (import plumbing the image lacks, stated in DESIGN.md section 4): the sentencepiece model ->
+tal_asrd_amd.synth.token_piece; nltk.word_tokenize -> str.split (identical on the synthetic [a-z0-9]+
+words); editdistance.eval -> Levenshtein distance (unique value); edit_distance.SequenceMatcher -> the
+library's published algorithm restated from memory in `_edit_distance_standin` (its tie-breaking is
+therefore PARITY-UNPINNED); torch.device('cuda') -> cpu; hdbscan / skopt -> never called.
+The heavy intermediate results are cached under /tmp/tal_golden_cache (not committed).
+"""
+import argparse
+import json
+import os
+import pickle
+import runpy
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from tests.golden._refload import load_reference, _mod, _load, REF  # noqa: E402
+from tests.golden.make_golden import fill, _asr_model, rows  # noqa: E402
+from tal_asrd_amd import synth  # noqa: E402
+
+torch.set_grad_enabled(False)
+CACHE = "/tmp/tal_golden_cache"
+EP = "ep-synth-2468"
+SEED = 2468
+VOCAB = 10000
+
+
+# ------------------------------------------------------------------------------------------------
+# stand-ins
+# ------------------------------------------------------------------------------------------------
+def make_tokenizer(ns):
+    base = ns.tokenizers._Tokenizer
+
+    class SynthTokenizer(base):
+        def __init__(self, cache_path=None, **kw):
+            super().__init__(cache_path, **kw)
+            self._eot_token_id = 0          # as the reference's sentencepiece Tokenizer (sentencepiece.py:29)
+
+        def __len__(self):
+            return VOCAB
+
+        def _encode(self, sentence, **kw):
+            raise NotImplementedError
+
+        def decode_list(self, tokens):
+            # tal/asr/tokenizers/sentencepiece.py:57-85 with DecodeIds -> synth.decode_pieces
+            out, buf = "", []
+            for x in tokens:
+                clear = x == self.eot_token_id or x >= len(self)
+                if clear:
+                    if buf:
+                        out += synth.decode_pieces(buf)
+                    buf = []
+                if x == self.eot_token_id:
+                    out += "<EOT>"
+                elif x >= len(self):
+                    out += "<S{}>".format(x - len(self))
+                else:
+                    buf.append(x)
+            if buf:
+                out += synth.decode_pieces(buf)
+            return out
+
+    return SynthTokenizer
+
+
+def _levenshtein(a, b):
+    a, b = list(a), list(b)
+    prev = list(range(len(b) + 1))
+    for i in range(1, len(a) + 1):
+        cur = [i] + [0] * len(b)
+        ai = a[i - 1]
+        for j in range(1, len(b) + 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (0 if ai == b[j - 1] else 1))
+        prev = cur
+    return prev[-1]
+
+
+def _edit_distance_standin():
+    """edit_distance (belambert/edit-distance 1.0.x) SequenceMatcher.get_opcodes, restated from memory of the
+    published code: dynamic programme over (distance, matches) with the default `highest_match_action`
+    (prefer the step with the most matches; equal/replace first, then insert, then delete), single-step
+    opcodes [tag, i0, i1, j0, j1] read back from the back-pointer table."""
+    def highest_match_action(ic, dc, sc, im, dm, sm, cost):
+        best_action = None
+        lowest_cost = float("inf")
+        max_match = max(im, dm, sm)
+        if max_match == sm and cost == 0:
+            best_action = "equal"
+        elif max_match == sm and cost == 1:
+            best_action = "replace"
+        elif max_match == im and ic < lowest_cost:
+            best_action = "insert"
+        elif max_match == dm and dc < lowest_cost:
+            best_action = "delete"
+        return best_action
+
+    class SequenceMatcher:
+        def __init__(self, a=None, b=None):
+            self.a, self.b = list(a), list(b)
+
+        def get_opcodes(self):
+            a, b = self.a, self.b
+            m, n = len(a), len(b)
+            d = [[0] * (n + 1) for _ in range(m + 1)]
+            mt = [[0] * (n + 1) for _ in range(m + 1)]
+            bp = [[None] * (n + 1) for _ in range(m + 1)]
+            for i in range(1, m + 1):
+                d[i][0] = i
+                bp[i][0] = ["delete", i - 1, i, 0, 0]
+            for j in range(1, n + 1):
+                d[0][j] = j
+                bp[0][j] = ["insert", 0, 0, j - 1, j]
+            for i in range(1, m + 1):
+                for j in range(1, n + 1):
+                    cost = 0 if a[i - 1] == b[j - 1] else 1
+                    sc, ic, dc = d[i - 1][j - 1] + cost, d[i][j - 1] + 1, d[i - 1][j] + 1
+                    im, dm, sm = mt[i][j - 1], mt[i - 1][j], mt[i - 1][j - 1] + (1 - cost)
+                    act = highest_match_action(ic, dc, sc, im, dm, sm, cost)
+                    if act in ("equal", "replace"):
+                        d[i][j], mt[i][j], bp[i][j] = sc, sm, [act, i - 1, i, j - 1, j]
+                    elif act == "insert":
+                        d[i][j], mt[i][j], bp[i][j] = ic, im, ["insert", i - 1, i - 1, j - 1, j]
+                    else:
+                        d[i][j], mt[i][j], bp[i][j] = dc, dm, ["delete", i - 1, i, j - 1, j - 1]
+            ops = []
+            i, j = m, n
+            while i > 0 or j > 0:
+                op = bp[i][j]
+                ops.append(op)
+                if op[0] in ("equal", "replace"):
+                    i, j = i - 1, j - 1
+                elif op[0] == "insert":
+                    j -= 1
+                else:
+                    i -= 1
+            return ops[::-1]
+
+    return SequenceMatcher
+
+
+def install_text_standins(ns):
+    Tok = make_tokenizer(ns)
+    _mod("nltk", word_tokenize=lambda s: s.split())
+    _mod("nltk.tokenize", word_tokenize=lambda s: s.split(),
+         TweetTokenizer=type("TweetTokenizer", (), {"tokenize": lambda self, s: s.split()}))
+    _mod("editdistance", eval=_levenshtein)
+    _mod("edit_distance", SequenceMatcher=_edit_distance_standin())
+    _mod("hdbscan", HDBSCAN=None)
+    sk = _mod("skopt", gp_minimize=None)
+    sk.space = _mod("skopt.space", Real=None, Integer=None)
+    sk.utils = _mod("skopt.utils", use_named_args=None)
+    sys.modules["wildspeech.asr.tokenizers.sentencepiece"].Tokenizer = Tok
+    return Tok
+
+
+# ------------------------------------------------------------------------------------------------
+# stages
+# ------------------------------------------------------------------------------------------------
+def episode_audio(seconds):
+    L = int(seconds * 16000)
+    a = synth.synth_audio_batch(1, L, SEED)
+    return a.astype(np.float16).astype(np.float32)     # system.py:285 casts the waveform to half
+
+
+def stage_decode(ns, seconds, tag):
+    """1. + 2.: the reference decode of the whole episode and the reference SD pass."""
+    os.makedirs(CACHE, exist_ok=True)
+    path = os.path.join(CACHE, "episode_%s.pkl" % tag)
+    if os.path.exists(path):
+        with open(path, "rb") as f:
+            return pickle.load(f)
+    Tok = install_text_standins(ns)
+    System = ns.system.System
+    model = _asr_model(ns)
+    tok = Tok()
+    audio = episode_audio(seconds)
+    L = audio.shape[1]
+    captured = {}
+
+    def gen_unaligned(x, y, lens, chunk_size=357):
+        t0 = time.time()
+        g, al = System.generate_unaligned(me, x, y, lens, chunk_size=chunk_size)
+        captured["generated"], captured["alignments"], captured["decode_s"] = g, al, time.time() - t0
+        return g, al
+
+    placeholder_ref = [{"episode": EP, "utterance": "placeholder", "speaker": 0, "role": "host", "utterance_start": 0.0}]
+    me = types.SimpleNamespace(model=model, lm=None, tokenizer=tok, test_index={0: (None, placeholder_ref)},
+                               test_outputs=[], generate_unaligned=gen_unaligned, logger=None,
+                               args=types.SimpleNamespace(unaligned=True, spk_weight=0.0, lm_weight=0.0, num_speakers=0,
+                                                          beam_size=1))
+    cwd = os.getcwd()
+    work = os.path.join(CACHE, "work_%s" % tag)
+    os.makedirs(os.path.join(work, "out"), exist_ok=True)
+    os.chdir(work)
+    try:
+        y = torch.full((1, 4), tok.eos_token_id, dtype=torch.long)    # "First token is always EOS" (system.py:654)
+        batch = (torch.from_numpy(audio), torch.tensor([L]), y, torch.ones(1, 4, dtype=torch.bool), None, [0])
+        System.test_step(me, batch, 0)
+    finally:
+        os.chdir(cwd)
+    ref_utts, hyp_utts = me.test_outputs[0]
+    print("decode: %d tokens, %d utterances, %.1f s" % (captured["generated"].shape[1], len(hyp_utts), captured["decode_s"]))
+
+    # 2. reference SDModel on the same audio (reconcile.py:76-85 without the GPU-era .half())
+    sdm = fill(ns.models.SDModel())
+    enc = sdm.encode(torch.from_numpy(audio), None)
+    feat = sdm.spk_embed_proj(enc["encoder_out"])
+    ids = sdm.decode(enc).argmax(dim=-1)
+    res = {"L": L, "generated": captured["generated"].numpy(),
+           "chunk_start": np.asarray([int(c[0]) for c, _ in captured["alignments"]], dtype=np.int64),
+           "attn": np.stack([a.numpy()[0] for _, a in captured["alignments"]]).astype(np.float32),
+           "hyp_utts": [{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in u.items()} for u in hyp_utts],
+           "sd_feat": feat[0].numpy().astype(np.float32), "sd_ids": ids[0].numpy().astype(np.int32),
+           "decode_s": captured["decode_s"]}
+    with open(path, "wb") as f:
+        pickle.dump(res, f)
+    return res
+
+
+def synth_reference_transcript(hyp_utts):
+    """A deterministic 'ground truth' for the scorer: the hypothesis word stream with ~6 % deletions, ~6 %
+    substitutions and ~4 % insertions, cut into turns of 5-12 words over 4 rotating speakers."""
+    words = [w for u in hyp_utts for w in u["utterance"].split()]
+    h = synth.hash_uniform("episode/ref-perturb", 2 * len(words) + 16)
+    out = []
+    for k, w in enumerate(words):
+        r = (h[2 * k] + 1.0) * 0.5
+        if r < 0.06:
+            continue
+        out.append("x%d" % k if r < 0.12 else w)
+        if r > 0.96:
+            out.append("y%d" % k)
+    utts, k, t, spk = [], 0, 0, 0
+    while k < len(out):
+        n = 5 + int((h[2 * t + 1] + 1.0) * 0.5 * 8)
+        utts.append({"episode": EP, "utterance": " ".join(out[k:k + n]), "speaker": "spk%d" % spk,
+                     "role": "host" if spk == 0 else "subject", "utterance_start": float(t)})
+        k += n
+        t += 1
+        spk = (spk + 1 + (t % 3 == 0)) % 4
+    return utts
+
+
+def stage_wder(ns, dec, tag):
+    """3. + 4.: aligned_to_wder_format.py as a script, then tal/wder.py corpus_wder."""
+    install_text_standins(ns)
+    work = os.path.join(CACHE, "work_%s" % tag)
+    os.makedirs(work, exist_ok=True)
+    hyp_all = [{k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in u.items()}
+               for u in dec["hyp_utts"]]
+    ref_utts = synth_reference_transcript(dec["hyp_utts"])
+    p = lambda n: os.path.join(work, n)
+    # The script stacks the attention rows of an utterance (aligned_to_wder_format.py:203-213); a token whose recorded
+    # chunkStart lies past T' - 357 (the recorded value is the post-advance, pre-clamp one, system.py:400,468,480) yields
+    # a shorter slice and torch.stack raises.  The fixture records that the reference raises on the full list and
+    # scores the list without the affected utterance(s).
+    Tp = dec["sd_feat"].shape[0]
+    keep = [i for i, u in enumerate(dec["hyp_utts"]) if int(np.max(u["chunkStart"])) <= Tp - 357]
+    dropped = [i for i in range(len(hyp_all)) if i not in keep]
+    print("utterances whose windows run past the episode end (dropped for scoring):", dropped)
+    with open(p("hyp_speaker_ids.pkl"), "wb") as f:
+        pickle.dump({EP: dec["sd_ids"].tolist()}, f)
+    with open(p("hyp_speaker_features.pkl"), "wb") as f:
+        pickle.dump({EP: dec["sd_feat"]}, f)
+    with open(p("role_map.json"), "w") as f:
+        json.dump({"0": "host"}, f)
+    real_device = torch.device
+    out = {"kept": keep, "raises_on_full": None}
+    wder = _load("wildspeech.wder", "tal/wder.py")
+    wder.tqdm = lambda it, **kw: it                     # (tal/wder.py:267 uses tqdm without importing it)
+    for mode, extra in (("utt", []), ("word", ["--word-level"])):
+        argv = ["aligned_to_wder_format", "--in-file", p("test_result.pkl"), "--out-file", p("wder_ready_%s.pkl" % mode),
+                "--speaker-id-hyp", p("hyp_speaker_ids.pkl"), "--speaker-feat-hyp", p("hyp_speaker_features.pkl"),
+                "--role-map", p("role_map.json"), "--cache-path", "unused", "--unaligned", "--workers", "1"] + extra
+        def run_script(hyp_list):
+            with open(p("test_result.pkl"), "wb") as f:
+                pickle.dump([(ref_utts, hyp_list)], f)
+            old = sys.argv
+            sys.argv = argv
+            torch.device = lambda *a, **k: real_device("cpu")      # the script hard-codes torch.device('cuda')
+            try:
+                runpy.run_path(os.path.join(REF, "tal/utils/aligned_to_wder_format.py"), run_name="__main__")
+            finally:
+                torch.device = real_device
+                sys.argv = old
+        if dropped and mode == "utt":
+            try:
+                import contextlib, io
+                with contextlib.redirect_stdout(io.StringIO()):
+                    run_script(hyp_all)
+                out["raises_on_full"] = False
+            except RuntimeError as e:
+                out["raises_on_full"] = True
+                print("reference raises on the full list:", str(e)[:100])
+        run_script([hyp_all[i] for i in keep])
+        with open(p("wder_ready_%s.pkl" % mode), "rb") as f:
+            wder_input = pickle.load(f)
+        refs, hyps = wder_input[0]
+        # tal/wder.py scores (utterance, speaker) pairs (:313-352); the role this script appends is consumed by other
+        # tools (apply_role_names*, wder_search*), so it is dropped here
+        pairs = [([(u, s) for u, s, _ in refs], [(u, s) for u, s, _ in hyps])]
+        res = wder.corpus_wder(pairs, wer_only=False, workers=1)
+        ref_spk_t, hyp_spk_t, overall_wder, asr_dist_t, n_words_t, overall_wer = res
+        out[mode] = {"hyps": hyps, "refs": refs, "wder": float(overall_wder), "wer": float(overall_wer),
+                     "asr_dist": [int(x) for x in asr_dist_t], "n_words": [int(x) for x in n_words_t]}
+        print(mode, "WDER %.6f WER %.6f (%d hyp entries)" % (overall_wder, overall_wer, len(hyps)))
+    return ref_utts, out
+
+
+def write_fixture(dec, ref_utts, wd, name):
+    hyp = dec["hyp_utts"]
+    kept = wd["kept"]
+    N = dec["attn"].shape[0]
+    r = rows(N, 160)
+    attn = dec["attn"]
+    S = attn.shape[1]
+    progress = (attn * (np.arange(S, dtype=np.float32) / np.float32(S))[None]).sum(-1).astype(np.float32)
+    utt_emb = np.stack([np.asarray(e.float().mean(0)) for _, (e, _), _ in wd["utt"]["hyps"]]).astype(np.float32)
+    # per-utterance token embeddings are [n_tokens, 128] halves; the fixture keeps every utterance's mean and the
+    # full matrices of 12 sampled utterances; per-word: the voted speaker id of every word + 200 sampled embeddings
+    ur = rows(len(wd["utt"]["hyps"]), 12)
+    word_hyps = wd["word"]["hyps"]
+    wr = rows(len(word_hyps), 200)
+    arrays = dict(
+        audio_seed=SEED, audio_len=dec["L"], generated=dec["generated"].astype(np.int32),
+        chunk_start=dec["chunk_start"].astype(np.int32), progress=progress, attn_rows=r, attn_sample=attn[r],
+        split_tokens=np.asarray([len(u["utteranceTokens"]) for u in hyp], dtype=np.int32),
+        sd_ids=dec["sd_ids"], sd_feat_rows=rows(dec["sd_feat"].shape[0], 64),
+        sd_feat_sample=dec["sd_feat"][rows(dec["sd_feat"].shape[0], 64)],
+        utt_emb_mean=utt_emb, utt_rows=ur,
+        word_spk=np.asarray([s for _, (_, s), _ in word_hyps], dtype=np.int32), word_rows=wr,
+        word_emb_sample=np.stack([np.asarray(word_hyps[i][1][0].float().mean(0)) for i in wr]).astype(np.float32),
+        wder_utt=wd["utt"]["wder"], wer_utt=wd["utt"]["wer"], wder_word=wd["word"]["wder"], wer_word=wd["word"]["wer"],
+        asr_dist=np.asarray(wd["word"]["asr_dist"]), n_words=np.asarray(wd["word"]["n_words"]),
+        kept_utts=np.asarray(kept, dtype=np.int32), raises_on_full=int(bool(wd["raises_on_full"])),
+    )
+    for i in ur:
+        arrays["utt_emb_%d" % i] = np.asarray(wd["utt"]["hyps"][i][1][0].float()).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    text = {"episode": EP, "hyp_utterances": [u["utterance"] for u in hyp],
+            "word_strs": [w for w, _, _ in word_hyps], "ref_utts": ref_utts}
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(text, f)
+    for ext in (".npz", ".json"):
+        print("wrote %s%s (%.1f KB)" % (name, ext, os.path.getsize(os.path.join(HERE, name + ext)) / 1024))
+
+
+def _jsonable(x):
+    if isinstance(x, (np.ndarray,)):
+        return x.tolist()
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (np.floating,)):
+        return float(x)
+    if isinstance(x, (list, tuple)):
+        return [_jsonable(v) for v in x]
+    return x
+
+
+def unit_wder(ns):
+    """Small known-answer fixtures from the reference's own tal/wder.py functions (wder_unit.json)."""
+    install_text_standins(ns)
+    W = _load("wildspeech.wder", "tal/wder.py")
+    W.tqdm = lambda it, **kw: it
+    rng = np.random.RandomState(7)
+    out = {"sequence_match": [], "convert": [], "wder": [], "corpus": None}
+    for n, k1, k2, strings in ((40, 3, 3, False), (60, 4, 6, False), (25, 5, 2, True), (10, 1, 1, False), (80, 7, 7, True)):
+        s1 = rng.randint(0, k1, size=n).tolist()
+        s2 = rng.randint(0, k2, size=n).tolist()
+        if strings:
+            s1 = ["spk%d" % v for v in s1]
+        r, c, acc = W.compute_sequence_match(s1, s2)
+        out["sequence_match"].append({"seq1": s1, "seq2": s2, "rows": _jsonable(r), "cols": _jsonable(c), "accuracy": float(acc)})
+    emb = lambda v: np.full(3, float(v))
+    conv_cases = [
+        ("ids", [("a b c", 4), ("d e", 9), ("f", 4)], False),
+        ("none_fill", [("a b", None), ("c", 3), ("d e", None), ("f", 3)], False),
+        ("all_none", [("a b", None), ("c d", None)], False),
+        ("strings", [("hello there", "jack"), ("general kenobi", "margaret"), ("bold one", "jack")], False),
+        ("emb_id_tuples", [("a b", (emb(1), 5)), ("c", (emb(2), None)), ("d e f", (emb(3), 7)), ("g", (emb(4), 5))], False),
+        ("wer_only", [("a b", (emb(1), 5)), ("c", (emb(2), 6))], True),
+    ]
+    for name, utts, wer_only in conv_cases:
+        words, n = W.convert_to_wder_format(utts, wer_only=wer_only, tokenizer=str.split)
+        out["convert"].append({"name": name, "wer_only": wer_only,
+                               "utts": [[u, (None if s is None else (s if not isinstance(s, tuple) else ["emb", s[1]]))] for u, s in utts],
+                               "words": [[w, _jsonable(k) if not isinstance(k, tuple) else "tuple"] for w, k in words], "n": int(n)})
+    vocab = ["w%d" % i for i in range(12)]
+    for n_ref, n_hyp, nspk in ((30, 28, 2), (50, 55, 3), (12, 12, 2), (40, 25, 4), (8, 14, 2)):
+        ref = [(vocab[v], "R%d" % s) for v, s in zip(rng.randint(0, 12, n_ref), np.sort(rng.randint(0, nspk, n_ref)))]
+        # hypothesis: the reference words with random edits, speakers relabelled + noise
+        hyp = []
+        for w, s in ref:
+            r = rng.rand()
+            if r < 0.12:
+                continue
+            hyp.append((vocab[rng.randint(0, 12)] if r < 0.3 else w, (int(s[1:]) + (rng.rand() < 0.2)) % nspk + 10))
+            if r > 0.9:
+                hyp.append((vocab[rng.randint(0, 12)], 10))
+        hyp = hyp[:n_hyp] if len(hyp) > n_hyp else hyp
+        wer, dist, n = W.calculate_wer(ref, hyp)
+        sm = sys.modules["edit_distance"].SequenceMatcher(a=[w for w, _ in ref], b=[w for w, _ in hyp])
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            wer2, dist2, n2, wder, rl, hl = W.calculate_wder(0, ref, hyp)
+        out["wder"].append({"ref": ref, "hyp": hyp, "wer": float(wer), "dist": int(dist), "n_ref": int(n), "wder": float(wder),
+                            "ref_labels": _jsonable(rl), "hyp_labels": _jsonable(hl),
+                            "opcodes": [[t, int(a), int(b), int(c), int(d)] for t, a, b, c, d in sm.get_opcodes()]})
+    pairs = [([("the cat sat down", "A"), ("on the mat", "B"), ("and slept", "A")],
+              [("the cat sat", 3), ("down on a mat", 8), ("and slept well", 3)]),
+             ([("hello there", "jack")], []),
+             ([("one two three four", 0), ("five six", 1)], [("one too three", (emb(0), 4)), ("four five six", (emb(1), 2))])]
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref_t, hyp_t, owder, dist_t, n_t, ower = W.corpus_wder(pairs, wer_only=False, workers=1, tokenizer=str.split)
+    out["corpus"] = {"pairs": [[[[u, s] for u, s in r], [[u, (s if not isinstance(s, tuple) else ["emb", s[1]])] for u, s in h]] for r, h in pairs],
+                     "overall_wder": float(owder), "overall_wer": float(ower), "asr_dist": _jsonable(dist_t), "n_words": _jsonable(n_t)}
+    with open(os.path.join(HERE, "wder_unit.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote wder_unit.json")
+
+
+def unit_pool(ns):
+    """Known-answer fixtures from the reference's own get_hyp_dict_wder (tal/utils/aligned_to_wder_format.py:65-224)
+    on random attention / features, incl. an episode shorter than the window with negative (wrapping) starts."""
+    Tok = install_text_standins(ns)
+    real_device = torch.device
+    mod = _load("wildspeech.utils_aligned_to_wder_format", "tal/utils/aligned_to_wder_format.py")
+    mod.ep = EP                                # the function reads the script's global `ep` (:74,162)
+    tok = Tok()
+    rng = np.random.RandomState(3)
+    arrays, meta = {}, []
+    cases = [("long", 1000, 23, None), ("short_wrap", 300, 9, -57), ("short_zero", 300, 6, 0)]
+    for name, T, ntok, fixed_cs in cases:
+        feat = rng.randn(T, 128).astype(np.float32)
+        ids = rng.randint(0, 9, size=T).astype(np.int32)
+        attn = rng.rand(ntok, 357).astype(np.float32) ** 6
+        attn /= attn.sum(-1, keepdims=True)
+        cs = np.sort(rng.randint(0, T - 357, size=ntok)) if fixed_cs is None else np.full(ntok, fixed_cs)
+        toks = [1] + rng.randint(3, 10000, size=ntok - 1).tolist()
+        hyp = {"utterance": tok.decode(toks), "speakerId": None, "attention": torch.from_numpy(attn),
+               "chunkStart": torch.from_numpy(cs.astype(np.int64)), "utteranceTokens": toks}
+        torch.device = lambda *a, **k: real_device("cpu")
+        try:
+            _, utt = mod.get_hyp_dict_wder(0, hyp, {}, tok, {EP: feat}, {EP: ids.tolist()}, word_level=False)
+            _, words = mod.get_hyp_dict_wder(0, hyp, {}, tok, {EP: feat}, {EP: ids.tolist()}, word_level=True)
+        finally:
+            torch.device = real_device
+        arrays.update({name + "_feat": feat, name + "_ids": ids, name + "_attn": attn, name + "_cs": cs.astype(np.int64),
+                       name + "_tokens": np.asarray(toks), name + "_utt_emb": utt[0][1][0].float().numpy(),
+                       name + "_word_spk": np.asarray([w[1][1] for w in words], dtype=np.int32),
+                       name + "_word_emb": np.concatenate([w[1][0].float().numpy() for w in words]) if words else np.zeros((0, 128), np.float32),
+                       name + "_word_ntok": np.asarray([w[1][0].shape[0] for w in words], dtype=np.int32)})
+        meta.append({"name": name, "T": T, "utterance": utt[0][0], "role": utt[0][2], "words": [w[0] for w in words]})
+    # aligned branch arithmetic (:321-333): majority vote over ids[st:e]
+    from collections import Counter
+    ids = rng.randint(0, 5, size=400).astype(np.int32)
+    ranges = np.asarray([[0, 10], [5, 6], [100, 399], [390, 450], [7, 7], [-20, 400]], dtype=np.int64)
+    votes = [Counter(ids.tolist()[a:b]).most_common(1)[0][0] if ids.tolist()[a:b] else -1 for a, b in ranges]
+    arrays.update({"major_ids": ids, "major_ranges": ranges, "major_votes": np.asarray(votes, dtype=np.int32)})
+    np.savez_compressed(os.path.join(HERE, "pool_unit.npz"), **arrays)
+    with open(os.path.join(HERE, "pool_unit.json"), "w") as f:
+        json.dump(meta, f)
+    print("wrote pool_unit.npz / pool_unit.json")
+
+
+if __name__ == "__main__":
+    if "--unit" in sys.argv:
+        ns = load_reference()
+        unit_wder(ns)
+        unit_pool(ns)
+        sys.exit(0)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=3600.0)
+    ap.add_argument("--name", default="episode_1h")
+    a = ap.parse_args()
+    ns = load_reference()
+    tag = "%ds" % int(a.seconds)
+    dec = stage_decode(ns, a.seconds, tag)
+    ref_utts, wd = stage_wder(ns, dec, tag)
+    write_fixture(dec, ref_utts, wd, a.name)

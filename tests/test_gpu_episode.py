@@ -1,0 +1,107 @@
+"""BASELINE.json configs[4] end to end on the GPU, against a fixture recorded from the reference's OWN code on
+the same 1-hour synthetic episode (tests/golden/make_golden_episode.py): System.test_step -> generate_unaligned
+(tal/asr/system.py:254-524,654-707) -> _Tokenizer.decode_speakers -> SDModel features / ids
+(tal/baseline/reconcile.py:76-85) -> tal/utils/aligned_to_wder_format.py (--unaligned, utterance and word level)
+-> tal/wder.py corpus_wder.
+
+Bar: token stream, window trajectory, speaker-change (EOS) indices, per-frame speaker ids, word segmentation and
+voted speaker ids IDENTICAL; attention rows within 1e-4; pooled embeddings within fp16 resolution (the reference
+pools in half precision); WER / WDER identical."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import GOLDEN, golden, has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+EP = "ep-synth-2468"
+
+
+def _load(model, weights, device):
+    own = model.state_dict()
+    for k, v in weights.items():
+        own[k] = torch.from_numpy(np.array(v, copy=True))
+    model.load_state_dict(own)
+    return model.to(device)
+
+
+@pytest.fixture(scope="module")
+def episode(asr_weights, sd_weights):
+    """One decode of the whole episode + one SD pass, shared by the tests below."""
+    from tal_asrd_amd import ASRModel, SDModel, synth
+    from tal_asrd_amd.system import System
+    from tal_asrd_amd.tokenizer import SynthTokenizer
+    g = golden("episode_1h")
+    with open(os.path.join(GOLDEN, "episode_1h.json")) as f:
+        text = json.load(f)
+    dev = torch.device("cuda:0")
+    L = int(g["audio_len"])
+    audio = synth.synth_audio_batch(1, L, int(g["audio_seed"])).astype(np.float16).astype(np.float32)  # system.py:285
+    audio = torch.from_numpy(audio).to(dev)
+    asr = _load(ASRModel("2x", num_speakers=6008, vocab_size=10000, use_speaker_head=True), asr_weights, dev)
+    system = System(asr, tokenizer=SynthTokenizer(10000))
+    utts, generated, alignments = system.transcribe_unaligned(audio, torch.tensor([L]))
+    del asr
+    sdm = _load(SDModel(), sd_weights, dev)
+    feat, ids = sdm.speaker_ids(audio)
+    return dict(g=g, text=text, utts=utts, generated=generated, alignments=alignments, feat=feat[0], ids=ids[0],
+                tok=system.tokenizer)
+
+
+def test_episode_decode_trajectory_identical(episode):
+    g = episode["g"]
+    gen = episode["generated"].cpu().numpy()
+    assert gen.shape == g["generated"].shape
+    np.testing.assert_array_equal(gen, g["generated"])
+    cs = np.array([int(c[0]) for c, _ in episode["alignments"]])
+    np.testing.assert_array_equal(cs, g["chunk_start"])
+    attn = np.stack([a.numpy()[0] for _, a in episode["alignments"]])
+    np.testing.assert_allclose(attn[g["attn_rows"]], g["attn_sample"], atol=1e-4, rtol=0)
+    S = attn.shape[1]
+    progress = (attn * (np.arange(S, dtype=np.float32) / np.float32(S))[None]).sum(-1)
+    np.testing.assert_allclose(progress, g["progress"], atol=1e-4, rtol=0)
+    # utterance split = speaker-change indices
+    assert [len(u["utteranceTokens"]) for u in episode["utts"]] == g["split_tokens"].tolist()
+    assert [u["utterance"] for u in episode["utts"]] == episode["text"]["hyp_utterances"]
+
+
+def test_episode_speaker_ids_identical(episode):
+    g = episode["g"]
+    np.testing.assert_array_equal(episode["ids"].cpu().numpy(), g["sd_ids"])       # 0 mismatches over 44,983 frames
+    np.testing.assert_allclose(episode["feat"][torch.from_numpy(g["sd_feat_rows"])].cpu().numpy(), g["sd_feat_sample"],
+                               atol=1e-4, rtol=0)
+
+
+def test_episode_wder_identical(episode):
+    from tal_asrd_amd import wder as W
+    from tal_asrd_amd.wder_format import strip_roles, unaligned_to_wder
+    g, text = episode["g"], episode["text"]
+    ref_utts = text["ref_utts"]
+    feats, ids = {EP: episode["feat"]}, {EP: episode["ids"]}
+    if int(g["raises_on_full"]):
+        with pytest.raises(RuntimeError, match="stack expects each tensor to be equal size"):
+            unaligned_to_wder([(ref_utts, episode["utts"])], feats, ids, {0: "host"}, episode["tok"])
+    kept = [episode["utts"][i] for i in g["kept_utts"].tolist()]
+    # utterance level: one embedding row per token, speaker id None (no speaker tokens in this vocabulary)
+    out = unaligned_to_wder([(ref_utts, kept)], feats, ids, {0: "host"}, episode["tok"], word_level=False)
+    (refs, hyps), = out
+    assert [h[0] for h in hyps] == [u["utterance"] for u in kept]
+    means = np.stack([h[1][0].numpy().mean(0) for h in hyps])
+    np.testing.assert_allclose(means, g["utt_emb_mean"], rtol=2e-3, atol=2e-4)
+    for i in g["utt_rows"].tolist():
+        np.testing.assert_allclose(hyps[i][1][0].numpy(), g["utt_emb_%d" % i], rtol=2e-3, atol=2e-4)
+    owder, ower, _, _, _ = W.corpus_wder(strip_roles(out))
+    assert (owder, ower) == (float(g["wder_utt"]), float(g["wer_utt"]))
+    # word level: words and attention-voted speaker ids from the separate diarizer
+    out = unaligned_to_wder([(ref_utts, kept)], feats, ids, {0: "host"}, episode["tok"], word_level=True, num_ids=6008)
+    (refs, hyps), = out
+    assert [h[0] for h in hyps] == text["word_strs"]
+    assert [h[1][1] for h in hyps] == g["word_spk"].tolist()
+    sample = np.stack([hyps[i][1][0].numpy().mean(0) for i in g["word_rows"].tolist()])
+    np.testing.assert_allclose(sample, g["word_emb_sample"], rtol=2e-3, atol=2e-4)
+    owder, ower, _, dists, ns = W.corpus_wder(strip_roles(out))
+    assert (owder, ower) == (float(g["wder_word"]), float(g["wer_word"]))
+    assert dists == g["asr_dist"].tolist() and ns == g["n_words"].tolist()

@@ -145,6 +145,24 @@ def test_logmel_random_lengths():
         np.testing.assert_allclose(got, O.logmel_f64(audio), atol=2e-4, rtol=0, err_msg=str((B, L)))
 
 
+@pytest.mark.parametrize("M", [100, 512])
+@pytest.mark.parametrize("S", [130, 160, 161, 225])
+def test_sd_head_fused_argmax_partial_slots(M, S):
+    """Small-M fused arg-max: the 32 x 128 tile kernel writes 4 partial slots per 128-column tile, so the partial row
+    must hold 4 * ceil(S / 128) of them (S % 128 in [1, 96] used to overrun a ceil(S / 32)-wide row)."""
+    from tal_asrd_amd import ops
+    g = torch.Generator().manual_seed(1000 * M + S)
+    x = torch.randn(M, 96, generator=g).to(dev())
+    we = (torch.randn(128, 96, generator=g) / 10).to(dev())
+    be = torch.randn(128, generator=g).to(dev())
+    wl = (torch.randn(S, 128, generator=g) / 11).to(dev())
+    bl = torch.randn(S, generator=g).to(dev())
+    _, logits, ids_ref = ops.sd_head(x, we, be, wl, bl, want_logits=True, want_ids=True)
+    _, _, ids = ops.sd_head(x, we, be, wl, bl, want_logits=False, want_ids=True)
+    assert torch.equal(ids, ids_ref)
+    assert torch.equal(ids.long().cpu(), logits.argmax(-1).cpu())
+
+
 def test_sd_head_random_shapes():
     from tal_asrd_amd import ops
     rng = np.random.default_rng(5)

@@ -263,6 +263,38 @@ int tal_log_softmax_rows(const float* x, int64_t M, int N, float* out, void* str
  * (may be NULL) also receives the token as int64, e.g. the next slot of a device-resident prefix. */
 int tal_greedy_pick_fwd(const float* logits, int V, const float* attn_rows, int n_layers,
                         int64_t layer_stride, int S, float* out, int64_t* token_out, void* stream);
+/* One whole step of System.generate_unaligned's greedy loop (tal/asr/system.py:332-411) in one call: embed the live prefix
+ * tokens[history_start : n_gen] (models.py:218-223), run the n_layers decoder layers against the cached cross-attention
+ * K / V^T of the current encoder window (tal_cross_kv_fwd), the tied LM head on the last position, and the pick of
+ * tal_greedy_pick_fwd; the new token is appended at tokens[n_gen].  picked_dev receives {token as int32 bits, attention
+ * row [S]}.  With sync != 0 the result is also copied to picked_host (pinned host memory) and the call returns when it
+ * has landed -- the one entry point of this library that waits for the stream; the loop steers on the host
+ * (.item() at system.py:408-411 in the reference).  Short prefixes (<= 64 tokens) run on the latency-oriented kernels
+ * (8 launches per layer), longer ones on the batched-GEMM layer.  Batch 1, like the reference's loop. */
+typedef struct tal_greedy_ctx {
+    const tal_decoder_layer_w* layers;   /* n_layers structs */
+    int32_t n_layers, E, H, FF, V, E0, S, max_len;   /* E0 = embed_size (0: no factorised embedding), S = window frames */
+    const float* emb;        /* embedding.weight [V, E0 or E] (= lm_head.weight, tied) */
+    const float* proj;       /* embedding_proj.weight [E, E0] or NULL */
+    const float* proj_t;     /* its transpose [E0, E] (tal_transpose_fwd) or NULL */
+    const float* pe;         /* pos_dec_encoder.pe [max_len, E] */
+    const float* const* k_cache;    /* n_layers device pointers: K [1, S, E] of the window */
+    const float* const* vt_cache;   /* n_layers device pointers: V^T [1, E, pad4(S)] */
+    const uint8_t* mem_kpm;  /* [1, S] key-padding mask of the window or NULL */
+    int64_t* tokens;         /* device-resident prefix buffer (capacity > n_gen) */
+    void* workspace;         /* tal_greedy_step_workspace_bytes(max prefix length, ...) */
+    size_t workspace_bytes;
+    float* picked_dev;       /* [1 + S] */
+    float* picked_host;      /* pinned host [1 + S], or NULL when sync == 0 */
+    uint32_t* tickets;       /* 256 words, ZERO before the first call (the kernels leave them zero): arrival tickets of the
+                              * kernels that merge partial results in-launch (key-split cross-attention, LM head + pick);
+                              * NULL: the unmerged forms (more launches).  One context per stream. */
+} tal_greedy_ctx;
+size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H, int FF, int V, int E0, int n_layers);
+int tal_greedy_step_fwd(const tal_greedy_ctx* c, int64_t history_start, int64_t n_gen, int sync, void* stream);
+/* HOST helper (no device work, `row` is a host pointer): ngram_repeat_mask(row, n).sum() of tal/asr/util.py:5-17, the
+ * repetition detector System.generate_unaligned evaluates once per generated token (system.py:418-421). */
+int64_t tal_ngram_repeat_count(const int64_t* row, int64_t len, int n);
 /* Beam-search candidate selection of System.generate (system.py:141-160): per batch item the
  * top-k of (logprobs[row, v] + row_score[row]) over its cur_beam rows x V tokens, rows with
  * row_done != 0 masked to -inf.  logprobs [B*cur_beam, V]; row_score / row_done [B*cur_beam]

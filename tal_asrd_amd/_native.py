@@ -36,6 +36,15 @@ class DecoderLayerW(C.Structure):
                [("resweight", C.c_float), ("resweight_src", C.c_float)]
 
 
+class GreedyCtx(C.Structure):
+    _fields_ = [("layers", C.c_void_p), ("n_layers", C.c_int32), ("E", C.c_int32), ("H", C.c_int32), ("FF", C.c_int32),
+                ("V", C.c_int32), ("E0", C.c_int32), ("S", C.c_int32), ("max_len", C.c_int32),
+                ("emb", C.c_void_p), ("proj", C.c_void_p), ("proj_t", C.c_void_p), ("pe", C.c_void_p),
+                ("k_cache", C.c_void_p), ("vt_cache", C.c_void_p), ("mem_kpm", C.c_void_p), ("tokens", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("picked_dev", C.c_void_p),
+                ("picked_host", C.c_void_p), ("tickets", C.c_void_p)]
+
+
 # name -> (restype, argtypes); must list every symbol include/tal_asrd.h declares
 # (tests/test_abi.py checks header <-> table <-> library).
 _i, _i64, _sz, _f, _p = C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_void_p
@@ -76,6 +85,9 @@ SIGNATURES = {
     "tal_decoder_stack_fwd": (_i, [_p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "tal_lm_head_fwd": (_i, [_p, _i64, _i64, _i, _p, _i, _p, _i, _p, _p, _sz, _p]),
     "tal_transpose_fwd": (_i, [_p, _i, _i, _p, _p]),
+    "tal_greedy_step_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "tal_greedy_step_fwd": (_i, [C.POINTER(GreedyCtx), _i64, _i64, _i, _p]),
+    "tal_ngram_repeat_count": (_i64, [_p, _i64, _i]),
     "tal_greedy_pick_fwd": (_i, [_p, _i, _p, _i, _i64, _i, _p, _p, _p]),
     "tal_log_softmax_rows": (_i, [_p, _i64, _i, _p, _p]),
     "tal_beam_topk": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),

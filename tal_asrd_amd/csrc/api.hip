@@ -149,6 +149,31 @@ using namespace tal;
 
 extern "C" int tal_version(void) { return 100; /* 0.1.0 */ }
 
+// Host-side helper of the decode loop (no device work): ngram_repeat_mask(row, n).sum() of tal/asr/util.py:5-17 -- the number
+// of positions covered by an n-gram that already occurred earlier in the row; like the reference, n-gram starts run to
+// len - n - 1.  Called once per generated token (system.py:418-421), where the Python set-of-tuples form costs more than
+// the GPU step it sits beside.
+extern "C" int64_t tal_ngram_repeat_count(const int64_t* row, int64_t len, int n) {
+    if (!row || n <= 0 || len - n <= 0) return 0;
+    const int64_t starts = len - n;
+    int64_t covered_until = 0, count = 0;
+    for (int64_t j = 0; j < starts; ++j) {
+        bool seen = false;
+        for (int64_t i = 0; i < j && !seen; ++i) {
+            if (row[i] != row[j]) continue;
+            bool eq = true;
+            for (int k = 1; k < n && eq; ++k) eq = row[i + k] == row[j + k];
+            seen = eq;
+        }
+        if (seen) {
+            const int64_t lo = j > covered_until ? j : covered_until;
+            if (j + n > lo) count += j + n - lo;
+            covered_until = j + n;
+        }
+    }
+    return count;
+}
+
 extern "C" const char* tal_last_error(void) { return g_err; }
 
 extern "C" int tal_prof_enable(int on) {

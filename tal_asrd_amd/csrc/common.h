@@ -43,6 +43,34 @@ __device__ __forceinline__ void split_f16x3(float x, _Float16& hi, _Float16& lo)
     lo = (_Float16)fminf(fmaxf((x - (float)hi) * 2048.f, -65504.f), 65504.f);
 }
 
+// In-launch hand-off between workgroups (split-K / key-split merges): the payload is written with agent-scope relaxed
+// atomic stores (`sc1`, write-through: visible to every XCD without a cache write-back), the writer drains them
+// (s_waitcnt vmcnt(0)) and takes a ticket; the last arriver reads with agent-scope relaxed atomic loads (they bypass the
+// non-coherent caches).  A __threadfence() here costs a whole-L2 write-back + invalidate (~10 us measured).
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// N agent-scope 16-byte loads issued back to back, then ONE wait: rows p + i * stride (floats).  Inline asm because
+// __hip_atomic_load stops at 8 bytes and a 4-byte sc1 load per element makes a merge 4x as many memory transactions.
+template <int N>
+__device__ __forceinline__ void ld_agent_x4(const float* p, size_t stride, f32x4 (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v[i]) : "v"(p + i * stride) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));      // uses of v[i] stay behind the wait
+}
+__device__ __forceinline__ unsigned take_ticket(unsigned* word) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void reset_ticket(unsigned* word) {
+    __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // wave-uniform wave index inside the workgroup, provably uniform to the compiler
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
@@ -120,5 +148,50 @@ bool head_argmax_applicable(int64_t M, int S, int E);
 int head_argmax_partials();
 int launch_head_argmax(const float* feat, const float* w, const void* w_split, const float* b, int64_t M, int S, float* part_val,
                        int32_t* part_idx, hipStream_t s);
+
+// ---- latency-oriented kernels of the decode step (csrc/decode_small.hip) ----
+struct SkinnyArgs {
+    const float* A;
+    const float* W;
+    const float* bias;
+    const float* res;
+    float* Y;
+    int M, N, K;
+    int64_t lda, ldw, ldy, ldres;
+    float alpha;
+    int scale_cols;   // mode 3: alpha applies to columns < scale_cols only (0 = all)
+    // columns >= vt_begin (a multiple of 16) go to Yt[b][col - vt_begin][u] for row m = b * U + u
+    float* Yt;
+    int vt_begin, U;
+    int64_t ldt, vt_bs;
+    // split K over `ksplit` workgroups per tile (deep layers: one CU pulls only ~25-60 GB/s): raw partial tiles go to
+    // sk_part [ksplit][tiles][512], the last workgroup to arrive at a tile (ticket on sk_tickets[tile], left at zero) adds
+    // them in split order and applies the epilogue -> deterministic.
+    int ksplit;
+    float* sk_part;
+    unsigned* sk_tickets;
+};
+
+struct AttnArgs {
+    const float* q;      // [B][U][..] rows of pitch ldq (already scaled by hd^-0.5), head h at column h * hd
+    const float* k;      // [B][S][..] rows of pitch ldk
+    const float* vt;     // [B][E][ldvt]: V^T without bias (added after P.V: softmax rows sum to one)
+    const float* vbias;  // [E] or NULL
+    const float* mask;   // additive [U][S] or NULL
+    const uint8_t* kpm;  // [B][S], non-zero = ignore, or NULL
+    float* ctx;          // [B][U][..] rows of pitch ldc
+    float* probs;        // per-head probabilities [B][H][U - prob_row0][S] of the rows >= prob_row0, or NULL
+    int64_t ldq, q_bs, ldk, k_bs, ldvt, vt_bs, ldc, c_bs;
+    int U, S, H, prob_row0;
+};
+
+bool skinny_gemm_applicable(const SkinnyArgs& g);
+int launch_skinny_gemm(const SkinnyArgs& g, int mode, hipStream_t s);
+bool attn_small_applicable(int U, int S, int hd);
+int launch_attn_small(const AttnArgs& g, int B, int hd, hipStream_t s);
+size_t attn_split_scratch_floats(int B, int U, int S, int H, int hd);
+int attn_split_tickets(int B, int U, int H);
+int launch_attn_split(const AttnArgs& g, int B, int hd, float* scratch, unsigned* tickets, hipStream_t s);
+int launch_head_average(const float* probs, float* avg, int B, int H, int U, int S, hipStream_t s);
 
 }  // namespace tal

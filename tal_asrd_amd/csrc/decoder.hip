@@ -194,15 +194,26 @@ __global__ __launch_bounds__(256) void log_softmax_row_block_kernel(const float*
 // arithmetic (and summation order) of log_softmax_row_block_kernel + argmax_row_block_kernel, and the new token's
 // cross-attention row averaged over the layers in numpy's order, ((l0 + l1) + l2) + ... then / n_layers.
 // out[0] = token (int32 bits), out[1 .. S] = attention.
+// The rows may come per head (H > 1, rows head_stride apart): a layer's row is then (sum over heads in head order) * (1 / H),
+// the arithmetic of the softmax kernels' head average.
 __global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restrict__ x, int N, const float* __restrict__ attn,
-                                                         int n_layers, int64_t layer_stride, int S, float* __restrict__ out,
-                                                         int64_t* __restrict__ token_out) {
+                                                         int n_layers, int64_t layer_stride, int H, int64_t head_stride, int S,
+                                                         float* __restrict__ out, int64_t* __restrict__ token_out) {
     __shared__ float red[4];
     __shared__ int redi[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float inv_h = 1.0f / (float)H;
     for (int i = threadIdx.x; i < S; i += 256) {
-        float a = attn[i];
-        for (int l = 1; l < n_layers; ++l) a += attn[l * layer_stride + i];
+        float a = 0.f;
+        for (int l = 0; l < n_layers; ++l) {
+            const float* r = attn + l * layer_stride + i;
+            float al = r[0];
+            if (H > 1) {
+                for (int h = 1; h < H; ++h) al += r[h * head_stride];
+                al *= inv_h;
+            }
+            a = l == 0 ? al : a + al;
+        }
         out[1 + i] = a / (float)n_layers;
     }
     float m = -INFINITY;
@@ -253,6 +264,211 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restric
         bi = bi == 0x7fffffff ? 0 : bi;
         out[0] = __int_as_float(bi);
         if (token_out) *token_out = bi;          // appended to the device-side prefix: the next step needs no upload
+    }
+}
+
+// Tied factorised LM head of the last position + the greedy pick in ONE launch (models.py:243-246, system.py:355-411):
+// every workgroup recomputes t = P^T h (E0 x E, 128 KB, L2-resident), takes 128 vocabulary rows (logit = emb[v] . t),
+// reduces them to its (max, first arg-max), and the last workgroup to arrive (ticket on a zeroed, self-resetting word)
+// merges the partials in workgroup order -- lowest index on ties, as torch.argmax -- and writes the token plus the
+// layer- / head-averaged attention row.  arg max of log_softmax(x) is taken as arg max of x (the same index unless two
+// logits lie within an ulp of each other).
+constexpr int LMP_ROWS = 128;
+__global__ __launch_bounds__(256) void lm_pick_kernel(const float* __restrict__ h, const float* __restrict__ proj_t, int E, int K0,
+                                                     const float* __restrict__ emb, int V, const float* __restrict__ attn,
+                                                     int n_layers, int64_t layer_stride, int H, int64_t head_stride, int S,
+                                                     float* __restrict__ partial, unsigned* __restrict__ ticket_word,
+                                                     float* __restrict__ out, int64_t* __restrict__ token_out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [E] h | [K0] t | [128] logits
+    float* hs = sm;
+    float* ts = sm + E;
+    float* lg = ts + K0;
+    __shared__ unsigned ticket;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // Everything this workgroup reads from memory is requested up front (h, P^T, its 128 embedding rows): the dependent
+    // chain is one round trip, then arithmetic.  Sixteen lanes share a row, so one load instruction covers 4 rows x 256
+    // contiguous bytes (a lane-per-row mapping touches 64 cache lines per instruction and the line rate sets the time).
+    // Fast path: E = 512, K0 = 64 (the reference's '2x' model with the factorised embedding); otherwise plain loops.
+    const int l16 = tid & 15, grp = tid >> 4;
+    const bool fast = proj_t && E == 512 && K0 == 64;
+    f32x4 pv[4][8], ev[8];
+    if (fast) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                pv[ps][c] = *reinterpret_cast<const f32x4*>(proj_t + (int64_t)(grp + 16 * ps) * 512 + (l16 + 16 * c) * 4);
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int v = blockIdx.x * LMP_ROWS + grp + 16 * ps;
+            ev[ps] = *reinterpret_cast<const f32x4*>(emb + (int64_t)(v < V ? v : V - 1) * 64 + l16 * 4);
+        }
+    }
+    for (int i = tid; i < E; i += 256) hs[i] = h[i];
+    __syncthreads();
+    if (fast) {
+        float a[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            a[ps] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(hs + (l16 + 16 * c) * 4);
+                a[ps] = fmaf(pv[ps][c].x, hv.x, a[ps]); a[ps] = fmaf(pv[ps][c].y, hv.y, a[ps]);
+                a[ps] = fmaf(pv[ps][c].z, hv.z, a[ps]); a[ps] = fmaf(pv[ps][c].w, hv.w, a[ps]);
+            }
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) a[ps] += __shfl_xor(a[ps], off, 64);
+        if (l16 == 0)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) ts[grp + 16 * ps] = a[ps];
+    } else if (proj_t) {
+        // t[j] = sum_d h[d] proj_t[j][d]: four threads per j, a quarter of E each (E % 16 == 0)
+        const int q = tid & 3, Eq = E >> 2;
+        for (int j = tid >> 2; j < K0; j += 64) {
+            const float* pr = proj_t + (int64_t)j * E + q * Eq;
+            float a = 0.f;
+            for (int d = 0; d < Eq; d += 4) {
+                const f32x4 p4 = *reinterpret_cast<const f32x4*>(pr + d);
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(hs + q * Eq + d);
+                a = fmaf(p4.x, hv.x, a); a = fmaf(p4.y, hv.y, a); a = fmaf(p4.z, hv.z, a); a = fmaf(p4.w, hv.w, a);
+            }
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            if (q == 0) ts[j] = a;
+        }
+    } else {
+        for (int i = tid; i < K0; i += 256) ts[i] = hs[i];
+    }
+    __syncthreads();
+    if (fast) {
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(ts + l16 * 4);
+        float a[8];
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            a[ps] = ev[ps].x * tv.x;
+            a[ps] = fmaf(ev[ps].y, tv.y, a[ps]); a[ps] = fmaf(ev[ps].z, tv.z, a[ps]); a[ps] = fmaf(ev[ps].w, tv.w, a[ps]);
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) a[ps] += __shfl_xor(a[ps], off, 64);
+        if (l16 == 0)
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int v = blockIdx.x * LMP_ROWS + grp + 16 * ps;
+                lg[grp + 16 * ps] = v < V ? a[ps] : -INFINITY;
+            }
+    } else {   // two threads per row, half of K0 each (K0 % 8 == 0)
+        const int r = tid >> 1, half = tid & 1, Kh = K0 >> 1;
+        const int v = blockIdx.x * LMP_ROWS + r;
+        float a = 0.f;
+        if (v < V) {
+            const float* er = emb + (int64_t)v * K0 + half * Kh;
+            for (int d = 0; d < Kh; d += 4) {
+                const f32x4 e4 = *reinterpret_cast<const f32x4*>(er + d);
+                const f32x4 tv = *reinterpret_cast<const f32x4*>(ts + half * Kh + d);
+                a = fmaf(e4.x, tv.x, a); a = fmaf(e4.y, tv.y, a); a = fmaf(e4.z, tv.z, a); a = fmaf(e4.w, tv.w, a);
+            }
+        }
+        a += __shfl_xor(a, 1, 64);
+        if (half == 0) lg[r] = v < V ? a : -INFINITY;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float best = lg[lane];
+        int bi = lane;
+        const float o = lg[lane + 64];
+        if (o > best) { best = o; bi = lane + 64; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) {
+            st_agent(&partial[2 * blockIdx.x], best);
+            st_agent(&partial[2 * blockIdx.x + 1], __int_as_float(blockIdx.x * LMP_ROWS + bi));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) ticket = take_ticket(ticket_word);
+    __syncthreads();
+    if (ticket != gridDim.x - 1) return;
+    if (tid == 0) reset_ticket(ticket_word);
+    // attention row of the new token: mean over layers of (mean over heads), summed in layer / head order.
+    // (fixed-trip loops with every load issued first: a run-time-bounded loop of loads is a serial chain of round trips)
+    const float inv_h = 1.0f / (float)H;
+    constexpr int RMAX = 32;                              // n_layers * H rows held in registers per position
+    const int nrow = n_layers * H;
+    for (int i = tid; i < S; i += 256) {
+        float a = 0.f;
+        if (nrow <= RMAX) {
+            float rv[RMAX];
+#pragma unroll
+            for (int k = 0; k < RMAX; ++k) {
+                const int l = k / H, hh = k - l * H;
+                rv[k] = k < nrow ? attn[l * layer_stride + hh * head_stride + i] : 0.f;
+            }
+            float al = 0.f;
+#pragma unroll
+            for (int k = 0; k < RMAX; ++k)
+                if (k < nrow) {
+                    const int l = k / H, hh = k - l * H;
+                    al = hh == 0 ? rv[k] : al + rv[k];
+                    if (hh == H - 1) {
+                        if (H > 1) al *= inv_h;
+                        a = l == 0 ? al : a + al;
+                    }
+                }
+        } else {
+            for (int l = 0; l < n_layers; ++l) {
+                const float* r = attn + l * layer_stride + i;
+                float al = r[0];
+                if (H > 1) {
+                    for (int hh = 1; hh < H; ++hh) al += r[hh * head_stride];
+                    al *= inv_h;
+                }
+                a = l == 0 ? al : a + al;
+            }
+        }
+        out[1 + i] = a / (float)n_layers;
+    }
+    if (tid < 64) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        constexpr int PJ = 4;                             // up to 256 workgroups' partials, all loads in flight
+        float pvv[PJ], pii[PJ];
+#pragma unroll
+        for (int k = 0; k < PJ; ++k) {
+            const int j = lane + 64 * k;
+            pvv[k] = j < (int)gridDim.x ? ld_agent(partial + 2 * j) : -INFINITY;
+            pii[k] = j < (int)gridDim.x ? ld_agent(partial + 2 * j + 1) : __int_as_float(0x7fffffff);
+        }
+#pragma unroll
+        for (int k = 0; k < PJ; ++k) {                    // ascending workgroup = ascending index: lowest index wins ties
+            const int idx = __float_as_int(pii[k]);
+            if (pvv[k] > best || (pvv[k] == best && idx < bi)) { best = pvv[k]; bi = idx; }
+        }
+        for (int j = lane + 64 * PJ; j < (int)gridDim.x; j += 64) {
+            const float v = ld_agent(partial + 2 * j);
+            const int idx = __float_as_int(ld_agent(partial + 2 * j + 1));
+            if (v > best || (v == best && idx < bi)) { best = v; bi = idx; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) {
+            bi = bi == 0x7fffffff ? 0 : bi;
+            out[0] = __int_as_float(bi);
+            if (token_out) *token_out = bi;
+        }
     }
 }
 
@@ -405,6 +621,99 @@ static LayerWs carve(float* base, int B, int U, int S, int E, int H, int FF) {
     return w;
 }
 
+// ---- the same layer on the latency-oriented kernels (csrc/decode_small.hip): 8 launches instead of 13 ----------------
+static SkinnyArgs skinny(const float* A, int64_t lda, const float* W, const float* bias, const float* res, float* Y, int64_t ldy,
+                         int M, int N, int K, float alpha) {
+    SkinnyArgs g = {};
+    g.A = A; g.W = W; g.bias = bias; g.res = res; g.Y = Y;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldw = K; g.ldy = ldy; g.ldres = ldy;
+    g.alpha = alpha;
+    return g;
+}
+
+static bool small_layer_applicable(int B, int U, int S, int E, int H, int FF, bool have_kv_cache) {
+    static const bool off = getenv("TAL_DECODE_NO_SMALL") != nullptr;
+    return !off && have_kv_cache && (int64_t)B * U <= 64 && E % 64 == 0 && FF % 64 == 0 && E % H == 0 &&
+           attn_small_applicable(U, S, E / H) && attn_small_applicable(U, U, E / H);
+}
+
+// probs_last != NULL: the cross-attention writes the per-head probabilities of the LAST prefix row only, [B][H][1][S]
+// (all the greedy loop reads); xattn_avg != NULL: the head-averaged weights of every row, [B][U][S].
+// scratch of the kernels that merge partial results in-launch (key-split attention, LM head + pick): the ticket words
+// must be zero before the first launch; every kernel leaves them zero
+struct DecodeScratch {
+    float* part;         // attn_split_scratch_floats(...) floats
+    unsigned* tickets;   // TAL_GREEDY_TICKETS words; the last one belongs to the pick
+};
+constexpr int TAL_GREEDY_TICKETS = 256;
+
+static int decoder_layer_small(const tal_decoder_layer_w* w, const float* tgt, int B, int U, int S, int E, int H, int FF,
+                               const float* tgt_mask, const uint8_t* mem_kpm, const float* ck, const float* cvt, float* out,
+                               float* xattn_avg, float* probs_last, const LayerWs& ws, hipStream_t s,
+                               const DecodeScratch* sk = nullptr) {
+    const int M = B * U, hd = E / H;
+    const int64_t U4 = pad4(U), S4 = pad4(S);
+    const float qscale = 1.0f / sqrtf((float)hd);
+    // self attention: q | k | v^T in one launch (q scaled; v goes out transposed per batch item, bias folded after P.V)
+    float* qkv = ws.mha.q;                       // [M][3E]; the v columns of it are never written
+    SkinnyArgs g = skinny(tgt, E, w->sa_in_w, w->sa_in_b, nullptr, qkv, 3 * E, M, 3 * E, E, qscale);
+    g.scale_cols = E;
+    g.Yt = ws.mha.vt; g.vt_begin = 2 * E; g.U = U; g.ldt = U4; g.vt_bs = (int64_t)E * U4;
+    // (the v bias is part of the packed bias and so goes into V^T here; P . (V + b) = P . V + b because rows of P sum to 1)
+    int rc = launch_skinny_gemm(g, 3, s);
+    if (rc) return rc;
+    AttnArgs a = {};
+    a.q = qkv; a.ldq = 3 * E; a.q_bs = (int64_t)U * 3 * E;
+    a.k = qkv + E; a.ldk = 3 * E; a.k_bs = (int64_t)U * 3 * E;
+    a.vt = ws.mha.vt; a.ldvt = U4; a.vt_bs = (int64_t)E * U4;
+    a.vbias = nullptr;                            // already inside V^T
+    a.mask = tgt_mask; a.kpm = nullptr;
+    a.ctx = ws.mha.ctx; a.ldc = E; a.c_bs = (int64_t)U * E;
+    a.U = U; a.S = U; a.H = H;
+    rc = launch_attn_small(a, B, hd, s);
+    if (rc) return rc;
+    rc = launch_skinny_gemm(skinny(ws.mha.ctx, E, w->sa_out_w, w->sa_out_b, tgt, ws.x1, E, M, E, E, w->resweight), 2, s);
+    if (rc) return rc;
+    // cross attention over the cached K / V^T of the encoder window
+    float* qc = ws.mha.q;
+    rc = launch_skinny_gemm(skinny(ws.x1, E, w->ca_in_w, w->ca_in_b, nullptr, qc, E, M, E, E, qscale), 3, s);
+    if (rc) return rc;
+    AttnArgs c = {};
+    c.q = qc; c.ldq = E; c.q_bs = (int64_t)U * E;
+    c.k = ck; c.ldk = E; c.k_bs = (int64_t)S * E;
+    c.vt = cvt; c.ldvt = S4; c.vt_bs = (int64_t)E * S4;
+    c.vbias = w->ca_in_b + 2 * E;
+    c.mask = nullptr; c.kpm = mem_kpm;
+    c.ctx = ws.mha.ctx; c.ldc = E; c.c_bs = (int64_t)U * E;
+    c.U = U; c.S = S; c.H = H;
+    if (xattn_avg) { c.probs = ws.mha.scores; c.prob_row0 = 0; }
+    else if (probs_last) { c.probs = probs_last; c.prob_row0 = U - 1; }
+    // long key axis + scratch available: cut the keys over workgroups (8x the CUs pulling K / V^T)
+    if (sk && S > 64 && attn_split_tickets(B, U, H) <= 64)
+        rc = launch_attn_split(c, B, hd, sk->part, sk->tickets, s);
+    else
+        rc = launch_attn_small(c, B, hd, s);
+    if (rc) return rc;
+    if (xattn_avg) {
+        rc = launch_head_average(ws.mha.scores, xattn_avg, B, H, U, S, s);
+        if (rc) return rc;
+    }
+    rc = launch_skinny_gemm(skinny(ws.mha.ctx, E, w->ca_out_w, w->ca_out_b, ws.x1, ws.x2, E, M, E, E, w->resweight_src), 2, s);
+    if (rc) return rc;
+    // feed-forward
+    rc = launch_skinny_gemm(skinny(ws.x2, E, w->lin1_w, w->lin1_b, nullptr, ws.ff, FF, M, FF, E, 0.f), 1, s);
+    if (rc) return rc;
+    SkinnyArgs f2 = skinny(ws.ff, FF, w->lin2_w, w->lin2_b, ws.x2, out, E, M, E, FF, w->resweight);
+    if (sk && FF >= 2048 && FF % 256 == 0 && (E / 16) * ((M + 31) / 32) <= TAL_GREEDY_TICKETS - 64) {
+        // K = FF is deep: four workgroups per tile, each pulling a quarter of the operands (tickets 64 .. 254)
+        f2.ksplit = 4;
+        f2.sk_part = sk->part;
+        f2.sk_tickets = sk->tickets + 64;
+    }
+    return launch_skinny_gemm(f2, 2, s);
+}
+
 }  // namespace tal
 
 using namespace tal;
@@ -466,6 +775,8 @@ extern "C" int tal_decoder_layer_fwd(const tal_decoder_layer_w* w, const float* 
     }
     hipStream_t s = (hipStream_t)stream;
     LayerWs ws = carve(reinterpret_cast<float*>(workspace), B, U, S, E, H, FF);
+    if (small_layer_applicable(B, U, S, E, H, FF, k_cache && vt_cache))
+        return decoder_layer_small(w, tgt, B, U, S, E, H, FF, tgt_mask, mem_kpm, k_cache, vt_cache, out, xattn_avg, nullptr, ws, s);
     // self attention over the prefix: q|k in one launch, V^T, scores/softmax/PV, out-proj + ReZero
     int rc = project_q_or_qk(w->sa_in_w, w->sa_in_b, tgt, (int64_t)B * U, E, H, 2, ws.mha.q, s);
     if (rc) return rc;
@@ -554,7 +865,7 @@ extern "C" int tal_greedy_pick_fwd(const float* logits, int V, const float* attn
                                    int S, float* out, int64_t* token_out, void* stream) {
     TAL_CHECK_ARG(logits && attn_rows && out && V > 0 && S > 0 && n_layers > 0, "tal_greedy_pick_fwd: bad argument");
     hipLaunchKernelGGL(greedy_pick_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, V, attn_rows, n_layers,
-                       layer_stride, S, out, token_out);
+                       layer_stride, 1, (int64_t)0, S, out, token_out);
     TAL_CHECK_LAUNCH("tal_greedy_pick_fwd");
     return TAL_OK;
 }
@@ -568,5 +879,109 @@ extern "C" int tal_log_softmax_rows(const float* x, int64_t M, int N, float* out
         hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, M,
                            N, out);
     TAL_CHECK_LAUNCH("tal_log_softmax_rows");
+    return TAL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One step of the sliding-window greedy decode (System.generate_unaligned, tal/asr/system.py:332-411) as ONE call:
+// embed the live prefix -> decoder stack against the cached K / V^T of the encoder window -> tied LM head on the last
+// position -> token = argmax(log_softmax) + the new token's layer- and head-averaged cross-attention row -> append the
+// token to the device-resident prefix -> (sync != 0) copy {token, row} to pinned host memory and wait.
+// ---------------------------------------------------------------------------------------------------------------
+static size_t up64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+extern "C" size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H, int FF, int V, int E0, int n_layers) {
+    if (U_max <= 0 || S <= 0 || E <= 0 || H <= 0 || FF <= 0 || V <= 0 || n_layers <= 0) return 0;
+    size_t f = carve(nullptr, 1, U_max, S, E, H, FF).total_floats;
+    f += 2 * up64((size_t)U_max * E);                        // embedded prefix, stack output
+    f += up64((size_t)n_layers * (size_t)U_max * S);         // attention rows: per-head last rows [L][H][S] or averaged [L][U][S]
+    f += up64((size_t)n_layers * H * S);
+    f += up64((size_t)(E0 > 0 ? E0 : E)) + up64((size_t)V);   // LM head intermediate, logits
+    {   // key-split attention records / split-K partial tiles (used one after the other)
+        const size_t a = attn_split_scratch_floats(1, U_max < 64 ? U_max : 64, S, H, E / H), b = (size_t)4 * (E / 16) * 2 * 512;
+        f += up64(a > b ? a : b);
+    }
+    f += up64((size_t)2 * cdiv(V, LMP_ROWS));                 // pick partials
+    return f * sizeof(float);
+}
+
+extern "C" int tal_greedy_step_fwd(const tal_greedy_ctx* c, int64_t history_start, int64_t n_gen, int sync, void* stream) {
+    TAL_CHECK_ARG(c && c->layers && c->emb && c->pe && c->k_cache && c->vt_cache && c->tokens && c->workspace && c->picked_dev,
+                  "tal_greedy_step_fwd: null pointer");
+    const int E = c->E, H = c->H, FF = c->FF, S = c->S, V = c->V, E0 = c->E0, L = c->n_layers;
+    const int64_t U64 = n_gen - history_start;
+    TAL_CHECK_ARG(history_start >= 0 && U64 >= 1 && U64 <= c->max_len, "tal_greedy_step_fwd: prefix [%lld, %lld) must hold 1..%d tokens",
+                  (long long)history_start, (long long)n_gen, c->max_len);
+    TAL_CHECK_ARG(!sync || c->picked_host, "tal_greedy_step_fwd: sync needs the pinned host buffer");
+    const int U = (int)U64;
+    if (c->workspace_bytes < tal_greedy_step_workspace_bytes(U, S, E, H, FF, V, E0, L)) {
+        set_error("tal_greedy_step_fwd: workspace %zu < %zu bytes", c->workspace_bytes, tal_greedy_step_workspace_bytes(U, S, E, H, FF, V, E0, L));
+        return TAL_ENOMEM;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* base = reinterpret_cast<float*>(c->workspace);
+    LayerWs ws = carve(base, 1, U, S, E, H, FF);
+    float* p = base + ws.total_floats;
+    float* h0 = p; p += up64((size_t)U * E);
+    float* h1 = p; p += up64((size_t)U * E);
+    float* avg = p; p += up64((size_t)L * U * S);
+    float* probs = p; p += up64((size_t)L * H * S);
+    float* lm_t = p; p += up64((size_t)(E0 > 0 ? E0 : E));
+    float* logits = p; p += up64((size_t)V);
+    DecodeScratch sk = {p, c->tickets};
+    {
+        const size_t a = attn_split_scratch_floats(1, U < 64 ? U : 64, S, H, E / H), b = (size_t)4 * (E / 16) * 2 * 512;
+        p += up64(a > b ? a : b);
+    }
+    float* pick_part = p;
+    int rc = tal_embed_tokens_fwd(c->tokens + history_start, 1, U, c->emb, V, E0 > 0 ? E0 : E, E0 > 0 ? c->proj : nullptr, E, c->pe,
+                                  c->max_len, h0, stream);
+    if (rc) return rc;
+    const bool small = small_layer_applicable(1, U, S, E, H, FF, true);
+    const float* cur = h0;
+    for (int l = 0; l < L; ++l) {
+        TAL_CHECK_ARG(c->k_cache[l] && c->vt_cache[l], "tal_greedy_step_fwd: layer %d has no cached K / V^T", l);
+        if (small)
+            rc = decoder_layer_small(&c->layers[l], cur, 1, U, S, E, H, FF, nullptr, c->mem_kpm, c->k_cache[l], c->vt_cache[l], h1,
+                                     nullptr, probs + (size_t)l * H * S, ws, s, c->tickets ? &sk : nullptr);
+        else
+            rc = tal_decoder_layer_fwd(&c->layers[l], cur, 1, U, nullptr, S, E, H, FF, nullptr, c->mem_kpm, c->k_cache[l],
+                                       c->vt_cache[l], h1, avg + (size_t)l * U * S, base, ws.total_floats * sizeof(float), stream);
+        if (rc) return rc;
+        cur = h1;
+    }
+    // tied factorised LM head on the last position (models.py:243-246; system.py:355-361 reads only that row)
+    const float* hl = cur + (size_t)(U - 1) * E;
+    const int K0 = E0 > 0 ? E0 : E;
+    if (c->tickets && E % 16 == 0 && K0 % 8 == 0 && (reinterpret_cast<uintptr_t>(c->emb) & 15) == 0 &&
+        (!c->proj_t || (reinterpret_cast<uintptr_t>(c->proj_t) & 15) == 0)) {
+        const float* rows = small ? probs : avg + (size_t)(U - 1) * S;
+        hipLaunchKernelGGL(lm_pick_kernel, dim3((unsigned)cdiv(V, LMP_ROWS)), dim3(256), (size_t)(E + K0 + LMP_ROWS) * sizeof(float), s, hl,
+                           E0 > 0 ? c->proj_t : nullptr, E, K0, c->emb, V, rows, L, small ? (int64_t)H * S : (int64_t)U * S,
+                           small ? H : 1, small ? (int64_t)S : (int64_t)0, S, pick_part, c->tickets + (TAL_GREEDY_TICKETS - 1),
+                           c->picked_dev, c->tokens + n_gen);
+        TAL_CHECK_LAUNCH("tal_greedy_step_fwd(lm head + pick)");
+    } else {
+    if (E0 > 0) {
+        rc = tal_lm_head_fwd(hl, 1, E, E, c->proj_t, E0, c->emb, V, logits, lm_t, (size_t)E0 * sizeof(float), stream);
+    } else {
+        rc = tal_lm_head_fwd(hl, 1, E, E, nullptr, E, c->emb, V, logits, nullptr, 0, stream);
+    }
+    if (rc) return rc;
+    if (small)
+        hipLaunchKernelGGL(greedy_pick_kernel, dim3(1), dim3(256), 0, s, logits, V, probs, L, (int64_t)H * S, H, (int64_t)S, S,
+                           c->picked_dev, c->tokens + n_gen);
+    else
+        hipLaunchKernelGGL(greedy_pick_kernel, dim3(1), dim3(256), 0, s, logits, V, avg + (size_t)(U - 1) * S, L, (int64_t)U * S, 1,
+                           (int64_t)0, S, c->picked_dev, c->tokens + n_gen);
+    TAL_CHECK_LAUNCH("tal_greedy_step_fwd(pick)");
+    }
+    if (sync) {
+        if (hipMemcpyAsync(c->picked_host, c->picked_dev, (size_t)(1 + S) * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            set_error("tal_greedy_step_fwd: device-to-host copy failed: %s", hipGetErrorString(hipGetLastError()));
+            return TAL_EHIP;
+        }
+    }
     return TAL_OK;
 }

@@ -43,6 +43,76 @@ def _beam_topk(logprobs, scores, done, B, cur_beam, k):
     return vals, idx
 
 
+class _GreedySession:
+    """Device-side state of the sliding-window greedy loop for tal_greedy_step_fwd: the decoder's layer structs, the
+    embedding / LM-head tensors, one workspace sized for the longest prefix, the {token, attention row} result buffer
+    and its pinned host mirror.  `set_window` points it at the cached cross-attention K / V^T of an encoder window."""
+
+    def __init__(self, model, gen_dev, max_positions):
+        from . import decoder as D
+        lib = N.lib()
+        self.lib = lib
+        self.model = model
+        stack = model.decoder
+        layer0 = stack.layers[0]
+        emb = model.embedding.weight
+        self.ctx = c = N.GreedyCtx()
+        self._arr = D._stack_structs(stack)
+        c.layers = C.cast(self._arr, C.c_void_p)
+        c.n_layers = len(stack.layers)
+        c.E = layer0.linear1.in_features
+        c.H = layer0.nhead
+        c.FF = layer0.linear1.out_features
+        c.V = emb.shape[0]
+        c.E0 = model.embed_size or 0
+        c.max_len = min(int(max_positions), model.pos_dec_encoder.pe.shape[0])
+        c.emb = emb.data_ptr()
+        if model.embed_size:
+            self._proj_t = D._proj_t(model)
+            c.proj, c.proj_t = model.embedding_proj.weight.data_ptr(), self._proj_t.data_ptr()
+        c.pe = model.pos_dec_encoder.pe.data_ptr()
+        self.dev = emb.device
+        self._stream = N.stream_handle()          # the stream current at construction carries every step
+        self._tickets = torch.zeros(256, dtype=torch.int32, device=emb.device)   # arrival tickets, self-resetting
+        c.tickets = self._tickets.data_ptr()
+        self.S = -1
+        self.ws = None
+        self._ctx_ref = C.byref(self.ctx)
+        self.set_tokens(gen_dev)
+
+    def set_tokens(self, gen_dev):
+        self.gen_dev = gen_dev
+        self.ctx.tokens = gen_dev.data_ptr()
+
+    def set_window(self, window):
+        from . import decoder as D
+        mem, mask = window["encoder_out"], window["encoder_padding_mask"]
+        D._check_memory(mem, 1, self.ctx.E, "generate_unaligned")
+        self._kv = D._stack_kv(self.model.decoder, mem)            # (K pointer array, V^T pointer array), cached per window
+        self.ctx.k_cache = C.cast(self._kv[0], C.c_void_p)
+        self.ctx.vt_cache = C.cast(self._kv[1], C.c_void_p)
+        self._kpm = D._kpm_u8(mask, 1, mem.shape[1], self.dev)
+        self.ctx.mem_kpm = None if self._kpm is None else self._kpm.data_ptr()
+        S = mem.shape[1]
+        if S != self.S:
+            c = self.ctx
+            self.S = c.S = S
+            nws = self.lib.tal_greedy_step_workspace_bytes(c.max_len, S, c.E, c.H, c.FF, c.V, c.E0, c.n_layers)
+            self.ws = ops._ws(nws, self.dev)
+            c.workspace, c.workspace_bytes = self.ws.data_ptr(), nws
+            self.picked_dev = torch.empty(1 + S, dtype=torch.float32, device=self.dev)
+            self.picked_host = torch.empty(1 + S, dtype=torch.float32).pin_memory()
+            self.picked_np = self.picked_host.numpy()
+            c.picked_dev, c.picked_host = self.picked_dev.data_ptr(), self.picked_host.data_ptr()
+
+    def step(self, history_start, n_gen):
+        """-> (token, attention row [S] float32 copy); the token is also appended at gen_dev[n_gen] on the device."""
+        rc = self.lib.tal_greedy_step_fwd(self._ctx_ref, history_start, n_gen, 1, self._stream)
+        if rc:
+            N.check(rc, "tal_greedy_step_fwd")
+        return int(self.picked_np[:1].view(np.int32)[0]), self.picked_np[1:].copy()
+
+
 class System:
     """Holds the model and the decode-time arguments the reference reads from `self.args`
     (spk_weight, lm_weight) and `self.tokenizer` (eos_token_id)."""
@@ -174,20 +244,28 @@ class System:
         enc, mask = encoder_out["encoder_out"], encoder_out["encoder_padding_mask"]
         encoder_len = int((~mask).sum(dim=-1).cpu().item())
         eos = self.tokenizer.eos_token_id
-        gen = generated.detach().cpu().numpy().astype(np.int64)[0].tolist()
-        alignments = []            # (chunk_start as recorded by the reference, attention row)
+        # Host bookkeeping in flat buffers (the loop body runs ~5000 times per hour of audio next to a ~0.3 ms GPU step):
+        # the token stream in a numpy array of length n, the alignment records as two parallel lists.
+        prime = generated.detach().cpu().numpy().astype(np.int64)[0]
+        gen = np.empty(max(4096, 2 * prime.size), dtype=np.int64)
+        n = prime.size
+        gen[:n] = prime
+        rec_cs, rec_attn = [], []            # chunk_start as recorded by the reference; attention row
         chunk_start = 0
         history_start = 0
         highest_progress = 0
         num_no_improve = 0
         window_time = 0
         window_key, window = None, None
-        layers = model.decoder.layers
-        gen_dev = torch.empty(max(1024, 2 * len(gen)), dtype=torch.int64, device=dev)
+        gen_dev = torch.empty(max(1024, 2 * n), dtype=torch.int64, device=dev)
         dev_len = -1
+        session, session_window = None, None
+        ngram_count = N.lib().tal_ngram_repeat_count
+        gen_addr = gen.ctypes.data
+        attn_range, attn_range_S = None, -1
         for it in range(max_iters):
-            history = gen[history_start:]
-            assert len(history) <= max_positions, "Cannot exceed max context length"
+            hist_len = n - history_start             # the model input of this step (before the new token is appended)
+            assert hist_len <= max_positions, "Cannot exceed max context length"
             # encoder window [chunk_start, chunk_start + chunk_size) -- python slice semantics as in the
             # reference's slice_tensor; re-materialised only when the window moves so that the
             # cross-attention K / V^T cache of every layer keeps hitting
@@ -195,38 +273,58 @@ class System:
                 sl = slice(chunk_start, chunk_start + chunk_size)
                 window = {"encoder_out": enc[:, sl].contiguous(), "encoder_padding_mask": mask[:, sl].contiguous()}
                 window_key = chunk_start
-            # the prefix lives on the device: the kernel that picks a token appends it, and the host list is
+            # the prefix lives on the device: the kernel that picks a token appends it, and the host copy is
             # uploaded again only after the control flow below rewrote it (roll-back, forced EOS)
-            n_gen = len(gen)
+            n_gen = n
             if gen_dev.numel() < n_gen + 1:
                 gen_dev = torch.empty(2 * (n_gen + 1), dtype=torch.int64, device=dev)
                 dev_len = -1
+            if gen.size < n_gen + 1:
+                gen = np.concatenate([gen, np.empty(gen.size, dtype=np.int64)])
+                gen_addr = gen.ctypes.data
             if dev_len != n_gen:
-                gen_dev[:n_gen] = torch.tensor(gen, dtype=torch.int64)
+                gen_dev[:n_gen] = torch.from_numpy(gen[:n_gen])
                 dev_len = n_gen
-            y = gen_dev[history_start:n_gen].view(1, -1)
-            logits = asr_decode(model, y, window, causal=False, last_only=True, check_tokens=(it == 0))  # [1, V]
-            if it == 0 and bool(torch.isnan(logits).any()):
-                raise Exception("Logits contain nans!")
-            # token = argmax(log_softmax(logits)) and the attention of the new token averaged over layers (heads
-            # are already averaged by the softmax kernel): one launch, one D2H copy (system.py:366-399 does the
-            # same arithmetic with a log_softmax, an argmax, a .cpu() per quantity and a numpy mean)
-            all_w = model.decoder.src_attn_weights_all                                  # [n_layers, B, U, S]
-            S_w = all_w.shape[-1]
-            picked = torch.empty(1 + S_w, dtype=torch.float32, device=dev)
-            N.check(N.lib().tal_greedy_pick_fwd(N.ptr(logits), logits.shape[-1], N.ptr(all_w[0, 0, -1]), all_w.shape[0],
-                                                all_w.stride(0), S_w, N.ptr(picked), N.ptr(gen_dev[n_gen:]),
-                                                N.stream_handle()), "tal_greedy_pick_fwd")
-            picked = picked.cpu().numpy()
-            token = int(picked[:1].view(np.int32)[0])
-            gen.append(token)
-            dev_len = n_gen + 1
-            attn = picked[1:].astype(np.float32)
-            record = [chunk_start, torch.from_numpy(attn.copy()).unsqueeze(0)]
-            alignments.append(record)
-            assert len(alignments) == len(gen) - 1
+            if it == 0:
+                # first step through the module API: validates the priming tokens (nn.Embedding raises on out-of-range
+                # ids) and the logits (system.py:363-364)
+                y = gen_dev[history_start:n_gen].view(1, -1)
+                logits = asr_decode(model, y, window, causal=False, last_only=True, check_tokens=True)  # [1, V]
+                if bool(torch.isnan(logits).any()):
+                    raise Exception("Logits contain nans!")
+                # token = argmax(log_softmax(logits)) and the attention of the new token averaged over layers (heads
+                # are already averaged by the softmax kernel): one launch, one D2H copy (system.py:366-399 does the
+                # same arithmetic with a log_softmax, an argmax, a .cpu() per quantity and a numpy mean)
+                all_w = model.decoder.src_attn_weights_all                                  # [n_layers, B, U, S]
+                S_w = all_w.shape[-1]
+                picked = torch.empty(1 + S_w, dtype=torch.float32, device=dev)
+                N.check(N.lib().tal_greedy_pick_fwd(N.ptr(logits), logits.shape[-1], N.ptr(all_w[0, 0, -1]), all_w.shape[0],
+                                                    all_w.stride(0), S_w, N.ptr(picked), N.ptr(gen_dev[n_gen:]),
+                                                    N.stream_handle()), "tal_greedy_pick_fwd")
+                picked = picked.cpu().numpy()
+                token = int(picked[:1].view(np.int32)[0])
+                attn = picked[1:].astype(np.float32)
+            else:
+                # every later step is ONE C call (tal_greedy_step_fwd): embed -> decoder stack on the window's cached
+                # K / V^T -> LM head of the last position -> pick + append on the device -> {token, attention row}
+                # in pinned host memory
+                if session is None:
+                    session = _GreedySession(model, gen_dev, max_positions)
+                if session.gen_dev is not gen_dev:
+                    session.set_tokens(gen_dev)
+                if session_window is not window:
+                    session.set_window(window)
+                    session_window = window
+                token, attn = session.step(history_start, n_gen)
+            gen[n] = token
+            n += 1
+            dev_len = n
+            rec_cs.append(chunk_start)
+            rec_attn.append(attn)
+            assert len(rec_cs) == n - 1
             S = attn.shape[0]
-            attn_range = (np.arange(S, dtype=np.float32) / np.float32(S)).astype(np.float32)
+            if S != attn_range_S:
+                attn_range, attn_range_S = (np.arange(S, dtype=np.float32) / np.float32(S)).astype(np.float32), S
             prct_progress = float(np.sum(attn * attn_range, dtype=np.float32))
             if prct_progress > highest_progress:
                 num_no_improve = 0
@@ -235,37 +333,45 @@ class System:
             else:
                 num_no_improve += 1
             is_stalling = num_no_improve >= stall_patience
-            rep_count = int(ngram_repeat_mask([history], rep_n).sum())
+            # ngram_repeat_mask(model_input, rep_n).sum() over the step's input (tal/asr/util.py:5-17, system.py:418-421)
+            rep_count = ngram_count(gen_addr + 8 * history_start, hist_len, rep_n)
             is_repeating = rep_count > rep_n * 2
             is_last_chunk = encoder_len - chunk_start <= chunk_size
             reset_window = is_stalling or is_repeating
+            record_kept = True
             if not is_last_chunk:
                 if reset_window:
                     chunk_start += int(chunk_size * skip_prct)
                     if is_repeating:
                         rollback = 2 * rep_n
-                        gen = gen[:-(rollback - 1)]
-                        alignments = alignments[:-(rollback - 1)]
-                    gen[-1] = eos
+                        n -= rollback - 1
+                        del rec_cs[-(rollback - 1):]
+                        del rec_attn[-(rollback - 1):]
+                        record_kept = False            # this step's record is among the ones rolled back
+                    gen[n - 1] = eos
                     dev_len = -1                   # the device copy of the prefix is stale
-                    history_start = len(gen) - 1
+                    history_start = n - 1
                     highest_progress = 0
                     window_time = 0
                 elif prct_progress > thresh_prct:
-                    history_size = len(gen) - history_start
+                    history_size = n - history_start
                     chunk_start += int(chunk_size * shift_prct)
                     history_start += int(np.floor(np.float32(shift_prct / thresh_prct) * np.float32(history_size - 1)))
                     highest_progress = 0
                     window_time = 0
             # The reference stores the chunk_start *tensor object* in `alignments` and then advances it in
             # place (system.py:400,441,468), so the recorded value is the post-advance, pre-clamp one.
-            record[0] = chunk_start
+            if record_kept:
+                rec_cs[-1] = chunk_start
             chunk_start = min(chunk_start, encoder_len - chunk_size)
-            history_start = max(history_start, max(len(gen) - max_positions, 0))
-            assert history_start < len(gen), ("Invalid history start index", history_start, len(gen))
-            assert len(gen) - history_start <= max_positions, ("Exceed max positions", history_start, len(gen))
+            history_start = max(history_start, max(n - max_positions, 0))
+            assert history_start < n, ("Invalid history start index", history_start, n)
+            assert n - history_start <= max_positions, ("Exceed max positions", history_start, n)
             window_time += 1
             if reset_window and is_last_chunk:
                 break
-        out = torch.tensor([gen], dtype=torch.int64, device=dev)
-        return out, [(torch.tensor([c], dtype=torch.int64), a) for c, a in alignments]
+        out = torch.from_numpy(gen[:n].copy()).view(1, -1).to(dev)
+        rows = torch.from_numpy(np.stack(rec_attn)) if len({a.shape[0] for a in rec_attn}) == 1 else None
+        cs_t = torch.tensor(rec_cs, dtype=torch.int64)
+        return out, [(cs_t[i:i + 1], rows[i:i + 1] if rows is not None else torch.from_numpy(rec_attn[i]).unsqueeze(0))
+                     for i in range(len(rec_cs))]

@@ -17,7 +17,7 @@ import torch
 from tests.conftest import GOLDEN, golden, has_gpu
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
-EP = "ep-synth-2468"
+EP = None  # read from the fixture
 
 
 def _load(model, weights, device):
@@ -47,6 +47,8 @@ def episode(asr_weights, sd_weights):
     del asr
     sdm = _load(SDModel(), sd_weights, dev)
     feat, ids = sdm.speaker_ids(audio)
+    global EP
+    EP = text["episode"]
     return dict(g=g, text=text, utts=utts, generated=generated, alignments=alignments, feat=feat[0], ids=ids[0],
                 tok=system.tokenizer)
 

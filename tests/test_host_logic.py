@@ -24,3 +24,17 @@ def test_split_speaker_turns():
     turns, splits = split_speaker_turns(toks, V, add_last=False)
     assert splits == [3, 8]
     assert split_speaker_turns([], V) == ([], [])
+
+
+def test_native_ngram_repeat_count_matches_mask_sum():
+    """The decode loop's C helper (tal_ngram_repeat_count, host code) against ngram_repeat_mask(...).sum()."""
+    import numpy as np
+    from tal_asrd_amd import _native as N
+    from tal_asrd_amd.util import ngram_repeat_mask
+    lib = N.lib()
+    rng = np.random.RandomState(0)
+    for _ in range(400):
+        L, n = int(rng.randint(0, 60)), int(rng.randint(1, 7))
+        row = rng.randint(0, 3, size=L).astype(np.int64)
+        want = int(ngram_repeat_mask([row.tolist()], n).sum()) if L else 0
+        assert lib.tal_ngram_repeat_count(row.ctypes.data, L, n) == want

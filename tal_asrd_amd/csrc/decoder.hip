@@ -27,7 +27,19 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
     __syncthreads();
     for (int d = threadIdx.x; d < D; d += 256) {
         float acc;
-        if (proj) {
+        if (proj && E0 == 64 && (reinterpret_cast<uintptr_t>(proj) & 15) == 0) {
+            // all 16 loads of the projection row in flight at once (a run-time-bounded scalar loop is 64 serial round trips)
+            const float* pr = proj + (int64_t)d * 64;
+            f32x4 pv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) pv[k] = *reinterpret_cast<const f32x4*>(pr + 4 * k);
+            acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {                    // same fmaf chain order as the scalar loop
+                acc = fmaf(e[4 * k], pv[k].x, acc); acc = fmaf(e[4 * k + 1], pv[k].y, acc);
+                acc = fmaf(e[4 * k + 2], pv[k].z, acc); acc = fmaf(e[4 * k + 3], pv[k].w, acc);
+            }
+        } else if (proj) {
             acc = 0.f;
             const float* pr = proj + (int64_t)d * E0;
             for (int k = 0; k < E0; ++k) acc = fmaf(e[k], pr[k], acc);
@@ -402,27 +414,25 @@ __global__ __launch_bounds__(256) void lm_pick_kernel(const float* __restrict__ 
     // attention row of the new token: mean over layers of (mean over heads), summed in layer / head order.
     // (fixed-trip loops with every load issued first: a run-time-bounded loop of loads is a serial chain of round trips)
     const float inv_h = 1.0f / (float)H;
-    constexpr int RMAX = 32;                              // n_layers * H rows held in registers per position
-    const int nrow = n_layers * H;
-    for (int i = tid; i < S; i += 256) {
+    constexpr int LM = 8, HM = 8;                         // layers x heads held in registers per position (no run-time
+    for (int i = tid; i < S; i += 256) {                  // division in the index arithmetic: 64 of them cost microseconds)
         float a = 0.f;
-        if (nrow <= RMAX) {
-            float rv[RMAX];
+        if (n_layers <= LM && H <= HM) {
+            float rv[LM][HM];
 #pragma unroll
-            for (int k = 0; k < RMAX; ++k) {
-                const int l = k / H, hh = k - l * H;
-                rv[k] = k < nrow ? attn[l * layer_stride + hh * head_stride + i] : 0.f;
-            }
-            float al = 0.f;
+            for (int l = 0; l < LM; ++l)
 #pragma unroll
-            for (int k = 0; k < RMAX; ++k)
-                if (k < nrow) {
-                    const int l = k / H, hh = k - l * H;
-                    al = hh == 0 ? rv[k] : al + rv[k];
-                    if (hh == H - 1) {
-                        if (H > 1) al *= inv_h;
-                        a = l == 0 ? al : a + al;
-                    }
+                for (int hh = 0; hh < HM; ++hh)
+                    rv[l][hh] = (l < n_layers && hh < H) ? attn[l * layer_stride + hh * head_stride + i] : 0.f;
+#pragma unroll
+            for (int l = 0; l < LM; ++l)
+                if (l < n_layers) {
+                    float al = rv[l][0];
+#pragma unroll
+                    for (int hh = 1; hh < HM; ++hh)
+                        if (hh < H) al += rv[l][hh];
+                    if (H > 1) al *= inv_h;
+                    a = l == 0 ? al : a + al;
                 }
         } else {
             for (int l = 0; l < n_layers; ++l) {

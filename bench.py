@@ -2,40 +2,47 @@
 """Headline benchmark: audio frames/s, waveform-on-device -> log-mel -> TDS encoder ->
 diarization head (128-d features + argmax speaker ids), BASELINE.json's metric.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload clip|segments|decode]
 
-One process per GPU (launched by torch.distributed.run for N > 1, rank/addr from the
-env).  A step = one pass of the hot path over this rank's clip(s) already resident in
-HBM.  Default workload (config[2] of BASELINE.json): ONE 1-hour 16 kHz synthetic clip per
-GPU processed as a single B=1 call, exactly how the reference's whole-episode
-diarization path consumes audio (tal/baseline/reconcile.py:76-85).  Weak scaling: every
-rank processes its own clip (independent episodes; no data-path collective except the
-result gather of ids + features to rank 0, which is inside the timed region).
+One process per GPU.  Typed as above with N > 1 and no WORLD_SIZE in the environment, the script starts its own N
+rank processes (127.0.0.1 rendezvous) before anything touches the GPU and prints rank 0's line; under
+`python -m torch.distributed.run ... bench.py --gpus N` (how the driver launches it) it reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment.
+
+Workloads (a step = one pass of the hot path over synthetic input already resident in HBM):
+  clip      (default at N = 1)  BASELINE.json configs[2]: ONE 1-hour 16 kHz clip per GPU as a single B = 1 call, how the
+            reference's whole-episode diarization path consumes audio (tal/baseline/reconcile.py:76-85).  Weak scaling.
+  segments  (default at N > 1)  configs[3]: 64 x 5-minute segments = ONE reference call over a [64, L] batch
+            (tal/asr/models.py:52: one log-mel mean couples the batch), sharded over the ranks by
+            distributed.shard_indices, every rank's share one batched call, the call's global mean restored with one
+            (sum, count) scalar all-reduce, ids + features returned to rank 0 through distributed.gather_segments
+            inside the timed region.  Strong scaling (the 64 segments are fixed).
+  decode    configs[4]: the joint decode of a 1-hour episode end to end -- ASR encode + sliding-window greedy decode
+            (System.generate_unaligned) + SDModel pass + word-level WDER-format pooling / voting; one episode per GPU.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     -- dominant kernel (the dense layers): algorithmic fp32 flops / HIP-event time of its launches
-                  inside the timed region vs the matrix peak of the MFMA it issues (fp16: 2500 TFLOP/s; the TDS
-                  pointwise layers run as 3 f16 MFMAs per fp32 product; TAL_TDS_F32=1: pure fp32, 157.3)
-  cpu_baseline -- the CPU oracle (a port of the reference's PyTorch-CPU path) timed on
-                  this box's host cores on a bounded 5-minute sample.
+  roofline     -- dominant kernel: algorithmic work / HIP-event time of its launches inside the timed region vs the
+                  peak it is bounded by
+  cpu_baseline -- the CPU oracle (a port of the reference's PyTorch-CPU path) timed on this box's host cores on a
+                  bounded sample (N = 1 only).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 F16_MATRIX_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/FP16 MFMA dense (v_mfma_f32_32x32x16_f16)
+HBM_PEAK_GBS = 8000.0
 POINTWISE_MAC_PER_FRAME = 6_272_000   # the 22 pointwise layers of the TDS blocks (SURVEY.md 8d): fp16x3 form
-MAC_PER_FRAME_GEMM = 6_272_000 + 119_168 / 1.0  # pointwise pairs + SD head (per mel frame; SURVEY.md 8d)
+METRIC = "audio frames/sec (16 kHz, 10 ms hop) end-to-end log-mel -> TDS encoder -> diarization head"
 
 
 def parse():
@@ -43,17 +50,47 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--seconds", type=float, default=3600.0, help="clip length per segment")
-    ap.add_argument("--segments", type=int, default=1, help="segments (independent B=1 calls) per GPU per step")
-    ap.add_argument("--batched", action="store_true", help="process the segments of a step as ONE [segments, L] call "
-                    "(one reference call: the log-mel mean then couples the batch, tal/asr/models.py:52)")
+    ap.add_argument("--workload", choices=["clip", "segments", "decode"], default=None,
+                    help="default: clip at --gpus 1, segments (configs[3]) at --gpus > 1")
+    ap.add_argument("--seconds", type=float, default=None, help="clip / segment length (clip, decode: 3600; segments: 300)")
+    ap.add_argument("--segments", type=int, default=None, help="clip: clips per GPU per step (1); segments: total segments (64)")
+    ap.add_argument("--batched", action="store_true", help="clip workload: process a rank's clips as ONE [n, L] call")
     ap.add_argument("--cpu-seconds", type=float, default=300.0, help="clip length of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event timing")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.workload is None:
+        a.workload = "clip" if a.gpus == 1 else "segments"
+    if a.seconds is None:
+        a.seconds = 300.0 if a.workload == "segments" else 3600.0
+    if a.segments is None:
+        a.segments = 64 if a.workload == "segments" else 1
+    return a
 
 
-def build_model(dev):
+def self_launch(args):
+    """`python bench.py --gpus N` typed by hand: start the N rank processes (nothing in THIS process has touched the GPU;
+    the library is built once here so that the ranks do not race hipcc)."""
+    import __graft_entry__ as g
+    g.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def build_sd_model(dev):
+    import torch
     from tal_asrd_amd import SDModel, synth
     model = SDModel()
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -65,9 +102,21 @@ def build_model(dev):
     return model.to(dev), sd
 
 
-def dense_layer_algorithmic_bytes(frames):
-    """Algorithmic HBM bytes of the dense-layer launches of one SD-path step over `frames` mel frames, summed
-    and per launch: every launch reads its activations (+ the residual for the second pointwise layer of a
+def build_asr_model(dev):
+    import torch
+    from tal_asrd_amd import ASRModel, synth
+    model = ASRModel("2x", num_speakers=6008, vocab_size=10000, use_speaker_head=True)
+    sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    own = model.state_dict()
+    for k, v in sd.items():
+        own[k] = torch.from_numpy(v.copy())
+    model.load_state_dict(own)
+    return model.to(dev)
+
+
+def dense_layer_algorithmic_bytes(frames, batch=1):
+    """Algorithmic HBM bytes of the dense-layer launches of one SD-path step over `batch` clips of `frames` mel frames,
+    summed and per launch: every launch reads its activations (+ the residual for the second pointwise layer of a
     TDSBlock) and its weights once and writes its output once.  (For comparison with roofline.traffic.)"""
     def f(t):
         return (t - 21) // 2 + 1
@@ -75,18 +124,19 @@ def dense_layer_algorithmic_bytes(frames):
     total = 0.0
     launches = 0
     for t, c, depth in ((t1, 800, 2), (t2, 1120, 3), (t3, 1440, 6)):
-        act = 4.0 * t * c
+        act = 4.0 * batch * t * c
         w = 4.0 * c * c
         total += depth * ((act + w + act) + (act + w + act + act))      # relu layer; residual layer
         launches += 2 * depth
-    total += 4.0 * (t3 * 1440 + 128 * 1440 + t3 * 128)                   # 1440 -> 128 features
-    total += 4.0 * (t3 * 128 + 6008 * 128) + 8.0 * t3 * 38                # 128 -> 6008 logits, arg-max partials only
+    total += 4.0 * (batch * t3 * 1440 + 128 * 1440 + batch * t3 * 128)   # 1440 -> 128 features
+    total += 4.0 * (batch * t3 * 128 + 6008 * 128) + 8.0 * batch * t3 * 38   # 128 -> 6008 logits, arg-max partials only
     launches += 2
     return total, launches
 
 
 def cpu_baseline(sd, seconds):
     """The oracle (CPU restatement of the reference's PyTorch-CPU path) on a bounded sample."""
+    import torch
     from oracle import tal_oracle as O
     from tal_asrd_amd import synth
     L = int(seconds * 16000)
@@ -101,28 +151,51 @@ def cpu_baseline(sd, seconds):
         times.append(time.perf_counter() - t0)
     med = sorted(times)[1]
     return {"value": frames / med, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%.0f s synthetic clip (%d frames), torch-CPU fp32, %d threads, median of 3 after 1 warm-up"
-                      % (seconds, frames, cores)}
+            "sample": "%.0f s synthetic clip (%d frames), torch-CPU fp32, %d threads, median of 3 after 1 warm-up "
+                      "(a 5-minute sample, not the 1-hour clip `value` is measured on)" % (seconds, frames, cores)}
+
+
+class FakeSD:
+    """TAL_BENCH_FAKE=1 (CPU plumbing self-test of the launch / shard / gather / timing code, tests/test_distributed_cpu.py):
+    stands in for the GPU work with deterministic tensors of the right shapes.  Never used for a reported number."""
+
+    def speaker_ids_batch(self, idx, frames):
+        import torch
+        tp = ((((frames - 21) // 2 + 1) - 21) // 2 + 1 - 21) // 2 + 1
+        out = {}
+        for i in idx:
+            g = torch.Generator().manual_seed(100 + i)
+            out[i] = (torch.randn(tp, 128, generator=g), torch.randint(0, 6008, (tp,), generator=g, dtype=torch.int32))
+        return out
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+
+    import torch
     import __graft_entry__ as g
     g.build()
     from tal_asrd_amd import _native, synth
+    from tal_asrd_amd import distributed as D
 
+    fake = bool(os.environ.get("TAL_BENCH_FAKE"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not fake and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # TAL_BENCH_BACKEND=gloo is a plumbing self-test only (N ranks sharing the visible GPUs, results
     # staged through host memory); real runs use RCCL ("nccl") with one GPU per rank.
-    backend = os.environ.get("TAL_BENCH_BACKEND", "nccl")
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank)
-    torch.cuda.set_device(dev)
+    backend = "gloo" if fake else os.environ.get("TAL_BENCH_BACKEND", "nccl")
+    if fake:
+        dev = torch.device("cpu")
+    else:
+        dev = torch.device("cuda", local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank)
+        torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -132,77 +205,161 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    model, sd = build_model(dev)
-    if dist is not None:
-        # weights come from rank 0 over RCCL/xGMI (one flat broadcast per tensor, start-up only)
-        for t in list(model.parameters()) + list(model.buffers()):
-            if backend == "nccl":
-                dist.broadcast(t.data, src=0)
-            else:
-                h = t.data.cpu()
-                dist.broadcast(h, src=0)
-                t.data.copy_(h)
+    def sync():
+        if not fake:
+            torch.cuda.synchronize()
 
     L = int(args.seconds * 16000)
     frames = 1 + L // 160
-    clips = [torch.from_numpy(synth.synth_audio_batch(1, L, 1234 + rank * args.segments + i)).to(dev)
-             for i in range(args.segments)]
-    if args.batched:
-        clips = [torch.cat(clips, dim=0)]
-    torch.cuda.synchronize()
-    # PCIe-inclusive figure (reported beside `value`, never as `value`): one pinned-host -> device copy
-    h2d_ms = None
-    if rank == 0:
-        host = clips[0].cpu().pin_memory()
-        torch.cuda.synchronize()
-        t_h = time.perf_counter()
-        _tmp = host.to(dev, non_blocking=True)
-        torch.cuda.synchronize()
-        h2d_ms = 1e3 * (time.perf_counter() - t_h)
-        del _tmp, host
+    lib = None if fake else _native.lib()
+    prof = not args.no_prof and not fake
+    extra = {}
 
-    gather_feat = gather_ids = None
-    pending = []
-
-    def step():
-        outs = []
-        for clip in clips:
-            feat, ids = model.speaker_ids(clip)
-            outs.append((feat, ids))
+    # ------------------------------------------------------------------ workload set-up
+    if args.workload == "decode":
+        from tal_asrd_amd.system import System
+        from tal_asrd_amd.tokenizer import SynthTokenizer
+        from tal_asrd_amd.wder_format import unaligned_to_wder
+        asr = build_asr_model(dev)
+        sdm, sd = build_sd_model(dev)
         if dist is not None:
-            feat = torch.cat([o[0].reshape(-1, o[0].shape[-1]) for o in outs])
-            ids = torch.cat([o[1].reshape(-1) for o in outs])
-            if backend != "nccl":
-                feat, ids = feat.cpu(), ids.cpu()
-            # Result gather to rank 0 is asynchronous (RCCL's own stream): it overlaps the next step's
-            # compute instead of serialising 23 MB x (N-1) of xGMI traffic behind every step; all
-            # pending gathers are waited for inside the timed region.  `keep` pins the source tensors.
-            pending.append((dist.gather(feat, gather_feat if rank == 0 else None, dst=0, async_op=True),
-                            dist.gather(ids, gather_ids if rank == 0 else None, dst=0, async_op=True), feat, ids))
-        return outs
+            D.broadcast_module(asr)
+            D.broadcast_module(sdm)
+        system = System(asr, tokenizer=SynthTokenizer(10000))
+        import numpy as np
+        audio = torch.from_numpy(synth.synth_audio_batch(1, L, 2469 + rank).astype(np.float16).astype(np.float32)).to(dev)
+        lens = torch.tensor([L])
+        stats = {}
 
-    def drain():
-        while pending:
-            w1, w2, _, _ = pending.pop(0)
-            w1.wait()
-            w2.wait()
+        def step():
+            t0 = time.perf_counter()
+            utts, gen, _ = system.transcribe_unaligned(audio, lens)
+            sync(); t1 = time.perf_counter()
+            feat, ids = sdm.speaker_ids(audio)
+            sync(); t2 = time.perf_counter()
+            tp = feat.shape[1]
+            kept = [u for u in utts if int(u["chunkStart"].max()) <= tp - 357]
+            ref = [{"episode": "e", "utterance": "x", "speaker": 0, "role": "host"}]
+            out = unaligned_to_wder([(ref, kept)], {"e": feat[0]}, {"e": ids[0]}, {}, system.tokenizer, word_level=True,
+                                    num_ids=6008)
+            sync(); t3 = time.perf_counter()
+            stats.update(tokens=int(gen.shape[1]) - 1, utterances=len(utts), words=len(out[0][1]),
+                         decode_ms=1e3 * (t1 - t0), sd_ms=1e3 * (t2 - t1), wder_format_ms=1e3 * (t3 - t2))
+        units_per_step = world * frames
+        scaling = "weak"
+        workload = ("1 x %.0f s 16 kHz episode per GPU: ASRModel encode + sliding-window greedy decode "
+                    "(System.generate_unaligned, tal/asr/system.py:254-524) + SDModel pass + word-level WDER-format pooling "
+                    "and voting (BASELINE.json configs[4])" % args.seconds)
+    elif args.workload == "segments":
+        n_seg = args.segments
+        lengths = [L] * n_seg
+        mine = D.shard_indices(n_seg, rank, world, weights=lengths)
+        if fake:
+            model, sd = FakeSD(), None
+        else:
+            model, sd = build_sd_model(dev)
+            if dist is not None:
+                D.broadcast_module(model)     # weights come from rank 0 over RCCL / xGMI (start-up only)
+            from tal_asrd_amd import ops
+            batch = torch.cat([torch.from_numpy(synth.synth_audio_batch(1, L, 1234 + i)) for i in mine]).to(dev) if mine else None
+        gathered = {}
 
-    with torch.no_grad():
+        def step():
+            if fake:
+                res = model.speaker_ids_batch(mine, frames)
+                feat_l = {i: res[i][0] for i in mine}
+                ids_l = {i: res[i][1] for i in mine}
+            else:
+                feat_l, ids_l = {}, {}
+                # this rank's share of ONE reference call over the [n_seg, L] batch: log-mel without the mean, the call's
+                # global (sum, count) over all ranks, subtract, encoder + head
+                if batch is not None:
+                    mel, _, st = ops.logmel(model.logmelspec.plan(), batch, eps=model.logmelspec.eps, subtract_mean=False,
+                                            return_stats=True)
+                else:
+                    st = torch.zeros(2, dtype=torch.float64, device=dev)
+                mean = D.allreduce_logmel_stats(st)
+                if batch is not None:
+                    ops.subtract_scalar_(mel, mean)
+                    enc = model.encode_features(mel, None)
+                    feat, _, ids = ops.sd_head(enc["encoder_out"], model.spk_embed_proj.weight, model.spk_embed_proj.bias,
+                                               model.spk_logit_proj.weight, model.spk_logit_proj.bias, want_logits=False,
+                                               want_ids=True)
+                    for k, i in enumerate(mine):
+                        feat_l[i], ids_l[i] = feat[k], ids[k]
+            gathered["feat"] = D.gather_segments(feat_l, n_seg, dst=0)
+            gathered["ids"] = D.gather_segments(ids_l, n_seg, dst=0)
+        units_per_step = n_seg * frames
+        scaling = "strong"
+        workload = ("%d x %.0f s 16 kHz segments = one reference call over a [%d, L] batch, sharded over %d GPU(s) by "
+                    "distributed.shard_indices, each rank's share one batched call, one scalar (sum, count) all-reduce for "
+                    "the call's log-mel mean, ids + features gathered to rank 0 (BASELINE.json configs[3]; SDModel path: "
+                    "log-mel -> TDS 80-800-1120-1440 -> 128-d feat + argmax over 6008 speakers)"
+                    % (n_seg, args.seconds, n_seg, world))
+    else:
+        model, sd = build_sd_model(dev)
+        if dist is not None:
+            D.broadcast_module(model)
+        clips = [torch.from_numpy(synth.synth_audio_batch(1, L, 1234 + rank * args.segments + i)).to(dev)
+                 for i in range(args.segments)]
+        if args.batched:
+            clips = [torch.cat(clips, dim=0)]
+        pending = []
+        gather_feat = gather_ids = None
         if dist is not None and rank == 0:
-            f0, i0 = model.speaker_ids(clips[0])
+            with torch.no_grad():
+                f0, _ = model.speaker_ids(clips[0])
             n_rows = f0.shape[-2] * args.segments
             gdev = dev if backend == "nccl" else torch.device("cpu")
             gather_feat = [torch.empty(n_rows, f0.shape[-1], device=gdev) for _ in range(world)]
             gather_ids = [torch.empty(n_rows, dtype=torch.int32, device=gdev) for _ in range(world)]
+
+        def step():
+            outs = [model.speaker_ids(clip) for clip in clips]
+            if dist is not None:
+                feat = torch.cat([o[0].reshape(-1, o[0].shape[-1]) for o in outs])
+                ids = torch.cat([o[1].reshape(-1) for o in outs])
+                if backend != "nccl":
+                    feat, ids = feat.cpu(), ids.cpu()
+                # Result gather to rank 0 is asynchronous (RCCL's own stream): it overlaps the next step's
+                # compute instead of serialising 23 MB x (N-1) of xGMI traffic behind every step; all
+                # pending gathers are waited for inside the timed region.
+                pending.append((dist.gather(feat, gather_feat if rank == 0 else None, dst=0, async_op=True),
+                                dist.gather(ids, gather_ids if rank == 0 else None, dst=0, async_op=True), feat, ids))
+        units_per_step = world * args.segments * frames
+        scaling = "weak"
+        workload = ((("%d x %.0f s 16 kHz clips per GPU as one batched call " if args.batched else
+                      "%d x %.0f s 16 kHz clip per GPU, each a whole-episode B=1 call ") % (args.segments, args.seconds)) +
+                    "(BASELINE.json configs[2]; SDModel path of tal/baseline/reconcile.py:76-85: "
+                    "log-mel -> TDS 80-800-1120-1440 -> 128-d feat + argmax over 6008 speakers)")
+
+    def drain():
+        if args.workload == "clip":
+            while pending:
+                w1, w2, _, _ = pending.pop(0)
+                w1.wait()
+                w2.wait()
+
+    # PCIe-inclusive figure (reported beside `value`, never as `value`): one pinned-host -> device copy
+    h2d_ms = None
+    if rank == 0 and args.workload == "clip":
+        host = clips[0].cpu().pin_memory()
+        sync()
+        t_h = time.perf_counter()
+        _tmp = host.to(dev, non_blocking=True)
+        sync()
+        h2d_ms = 1e3 * (time.perf_counter() - t_h)
+        del _tmp, host
+
+    # ------------------------------------------------------------------ timed region
+    with torch.no_grad():
         for _ in range(args.warmup):
             step()
         drain()
-        lib = _native.lib()
-        prof = not args.no_prof
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         if prof:
             lib.tal_prof_reset()
             lib.tal_prof_enable(1)
@@ -210,10 +367,10 @@ def main():
         for _ in range(args.steps):
             step()
         drain()
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         elapsed = time.perf_counter() - t0
         if prof:
             lib.tal_prof_enable(0)
@@ -224,22 +381,35 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        total_frames = world * args.segments * frames * args.steps
+        total_frames = units_per_step * args.steps
         line = {
-            "metric": "audio frames/sec (16 kHz, 10 ms hop) end-to-end log-mel -> TDS encoder -> diarization head",
-            "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC, "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if os.environ.get("TAL_TDS_F32") else "f32 (dense layers: 3 x f16 MFMA hi/lo split, f32 accumulate)",
+            "scaling": scaling, "vs_baseline": None,
+            "dtype": "f32" if os.environ.get("TAL_TDS_F32") or args.workload == "decode"
+                     else "f32 (dense layers: 3 x f16 MFMA hi/lo split, f32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": (("%d x %.0f s 16 kHz clips per GPU as one batched call " if args.batched else
-                                     "%d x %.0f s 16 kHz clip per GPU, each a whole-episode B=1 call ") % (args.segments, args.seconds)) +
-                                   "(BASELINE.json configs[2]; SDModel path of tal/baseline/reconcile.py:76-85: "
-                                   "log-mel -> TDS 80-800-1120-1440 -> 128-d feat + argmax over 6008 speakers)",
-                       "frames_per_gpu_per_step": args.segments * frames, "weights": "synthetic deterministic",
+            "config": {"workload": workload, "frames_per_step": units_per_step, "weights": "synthetic deterministic",
                        "audio_resident_in_hbm": True},
         }
-        if prof:
+        if fake:
+            line["data"] = "FAKE (TAL_BENCH_FAKE plumbing self-test: no GPU work, not a measurement)"
+        if args.workload == "segments":
+            got = gathered.get("ids")
+            line["gathered_segments"] = len(got) if got is not None else 0
+        if args.workload == "decode":
+            line["episode"] = stats
+            steps_n = max(stats.get("tokens", 1), 1)
+            # dominant cost: the decode step, a chain of ~35 dependent launches that stream the decoder weights
+            # (67 MB) and the window's K / V^T (5.8 MB) once: latency-bound, priced against HBM for honesty
+            wbytes = 4.0 * (4 * (4 * 512 * 512 + 4 * 512 * 512 + 2 * 512 * 2048) + 10000 * 64 + 64 * 512) + 4.0 * 4 * 2 * 357 * 512
+            step_ms = stats["decode_ms"] / steps_n
+            line["roofline"] = {"bound": "hbm", "kernel": "decode step (tal_greedy_step_fwd: ~35 dependent launches per generated token)",
+                                "achieved": wbytes / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": wbytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                "ms_per_decode_step": step_ms, "algorithmic_bytes_per_step": wbytes,
+                                "note": "launch-latency-bound, not bandwidth-bound: ~6 us per dependent launch"}
+        if prof and args.workload != "decode":
             ms, n, work = C.c_double(), C.c_int64(), C.c_double()
             kern = {}
             for cls, name in ((0, "gemm_nt_f32"), (1, "gconv_res"), (2, "gconv_s2"), (3, "logmel"), (4, "other")):
@@ -249,36 +419,42 @@ def main():
             achieved = gm["work"] / (gm["ms_total"] * 1e-3) / 1e12 if gm["ms_total"] > 0 else 0.0
             traffic = None
             try:   # HBM-side bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-                with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-                    traffic = json.load(f)["hbm_bytes_per_launch"]
+                for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+                    path = os.path.join(ROOT, "profiles", name)
+                    if os.path.exists(path):
+                        with open(path) as f:
+                            traffic = json.load(f)["hbm_bytes_per_launch"]
+                        break
             except Exception:
                 pass
             f32_only = bool(os.environ.get("TAL_TDS_F32"))
             peak = FP32_MATRIX_PEAK_TFLOPS if f32_only else F16_MATRIX_PEAK_TFLOPS
             # MFMA flops actually issued: the pointwise layers run as 3 fp16 MFMAs per fp32 product (hi*hi, hi*lo, lo*hi)
-            pw = 2.0 * POINTWISE_MAC_PER_FRAME * frames * args.segments * args.steps
+            per_rank_frames = (len(mine) if args.workload == "segments" else args.segments) * frames
+            pw = 2.0 * POINTWISE_MAC_PER_FRAME * per_rank_frames * args.steps
             issued = gm["work"] + (0.0 if f32_only else 2.0 * pw)
+            nb = len(mine) if args.workload == "segments" else (args.segments if args.batched else 1)
             line["roofline"] = {"bound": "mfma",
                                 "kernel": "tal::gemm_glds_kernel (dense layers; TDS pointwise layers in the fp16x3 form: fp32 "
                                           "products as 3 f16 MFMAs, fp32 accumulate)" if not f32_only else
                                           "tal::gemm_glds_kernel (fp32 MFMA dense layer, all epilogues)",
                                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                                 "frac": achieved / peak, "traffic": traffic,
-                                "achieved_is": "algorithmic fp32 flops (2 M N K per dense layer) / HIP-event time",
+                                "achieved_is": "algorithmic fp32 flops (2 M N K per dense layer) / HIP-event time (rank 0)",
                                 "issued_mfma_tflops": issued / (gm["ms_total"] * 1e-3) / 1e12 if gm["ms_total"] > 0 else 0.0,
                                 "issued_frac": (issued / (gm["ms_total"] * 1e-3) / 1e12 / peak) if gm["ms_total"] > 0 else 0.0,
                                 "fp32_matrix_peak": FP32_MATRIX_PEAK_TFLOPS,
                                 "avg_launch_ms": gm["ms_total"] / max(gm["launches"], 1),
                                 "launches": gm["launches"],
                                 "algorithmic_flops_per_launch": gm["work"] / max(gm["launches"], 1),
-                                "algorithmic_bytes_per_launch": (lambda tb: tb[0] / tb[1])(dense_layer_algorithmic_bytes(frames))}
+                                "algorithmic_bytes_per_launch": (lambda tb: tb[0] / tb[1])(dense_layer_algorithmic_bytes(frames, max(nb, 1)))}
             tot = sum(k["ms_total"] for k in kern.values())
             line["kernel_time_share"] = {k: (v["ms_total"] / tot if tot else 0.0) for k, v in kern.items()}
             line["kernel_ms_per_step"] = {k: v["ms_total"] / args.steps for k, v in kern.items()}
         if h2d_ms is not None:
             line["h2d_ms_per_clip"] = h2d_ms
             line["value_including_h2d"] = total_frames / (elapsed + 1e-3 * h2d_ms * args.segments * args.steps)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1 and not fake:
             line["cpu_baseline"] = cpu_baseline(sd, args.cpu_seconds)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)

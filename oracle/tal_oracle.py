@@ -104,6 +104,27 @@ def logmel(audio, eps=1e-6, subtract_mean=True, fb=None):
     return mel
 
 
+def logmel_f64_frames(audio_1d, f0, f1, eps=1e-6):
+    """Frames [f0, f1) of log(mel + eps) (NO mean subtraction) of ONE clip in float64, without materialising the whole
+    clip's frames: frame t covers padded samples [160 t, 160 t + 400) of the reflect-padded (200 each side) signal.
+    Same arithmetic as logmel_f64; used to check hour-long clips piecewise.  -> [f1 - f0, 80] float64."""
+    a = np.asarray(audio_1d, dtype=np.float64)
+    L = a.shape[0]
+    pad = N_FFT // 2
+    lo, hi = f0 * HOP - pad, (f1 - 1) * HOP + N_FFT - pad        # sample range in unpadded coordinates, [lo, hi)
+    idx = np.arange(lo, hi)
+    idx = np.where(idx < 0, -idx, idx)                          # reflect (no edge repeat), as np.pad mode="reflect"
+    idx = np.where(idx >= L, 2 * (L - 1) - idx, idx)
+    seg = a[idx]
+    k = np.arange(N_FFT, dtype=np.float64)
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * k / N_FFT)
+    fi = np.arange(f1 - f0)[:, None] * HOP + np.arange(N_FFT)[None, :]
+    spec = np.fft.rfft(seg[fi] * win, axis=-1)
+    power = spec.real ** 2 + spec.imag ** 2
+    fb = mel_filterbank().double().numpy()
+    return np.log(power @ fb + eps)
+
+
 def logmel_f64(audio, eps=1e-6, subtract_mean=True):
     """Independent float64 numpy restatement (explicit reflect pad + rfft)."""
     a = np.asarray(audio, dtype=np.float64)

@@ -55,25 +55,44 @@ def allreduce_logmel_stats(stats: torch.Tensor) -> torch.Tensor:
     return (stats[0] / stats[1]).to(torch.float32).reshape(1)
 
 
-def gather_segments(local: dict, n_items: int, dst: int = 0):
+def gather_segments(local: dict, n_items: int, dst: int = 0, like=None):
     """Gather variable-length per-segment results to rank `dst`.
 
     local: {item_index: tensor [T_i, ...]} for the items this rank processed (same trailing
     shape and dtype everywhere).  Returns the list of n_items tensors (in item order) on
     `dst`, None elsewhere.  Protocol: all_gather of (index, length) pairs, then one padded
-    all_gather-free exchange per rank pair via dist.gather of a flat buffer."""
+    all_gather-free exchange per rank pair via dist.gather of a flat buffer.
+    A rank that processed nothing (more ranks than items) passes `like`, any tensor with the results' trailing
+    shape, dtype and device; without it the description is fetched from a rank that holds data (one small
+    all_gather_object)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world == 1:
         return [local[i] for i in range(n_items)]
     items = sorted(local)
-    sample = local[items[0]] if items else None
+    sample = local[items[0]] if items else like
+    if like is None:
+        # every rank must agree on whether the description exchange happens: it does whenever n_items < world
+        # (some rank is necessarily empty) -- a pure function of arguments all ranks share
+        if n_items < world:
+            desc = [None] * world
+            mine = None if sample is None else (tuple(sample.shape[1:]), str(sample.dtype).replace("torch.", ""), str(sample.device.type))
+            dist.all_gather_object(desc, mine)
+            if sample is None:
+                got = next((d for d in desc if d is not None), None)
+                if got is None:
+                    raise RuntimeError("gather_segments: no rank holds any item")
+                dev_type = got[2]
+                device = torch.device("cuda", torch.cuda.current_device()) if dev_type == "cuda" else torch.device("cpu")
+                sample = torch.empty((0,) + got[0], dtype=getattr(torch, got[1]), device=device)
+    if sample is None:
+        raise RuntimeError("gather_segments: this rank holds no item; pass `like`")
     # 1) who holds what, and how long
     meta = torch.full((n_items, 2), -1, dtype=torch.int64)
     for i in items:
         meta[i, 0] = rank
         meta[i, 1] = local[i].shape[0]
-    dev = sample.device if sample is not None else torch.device("cpu")
+    dev = sample.device
     meta = meta.to(dev)
     dist.all_reduce(meta, op=dist.ReduceOp.MAX)
     meta = meta.cpu()

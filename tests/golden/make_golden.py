@@ -371,7 +371,65 @@ def sec_uisrnn(ns):
         json.dump(out, f, indent=1)
 
 
-SECTIONS = {"keys": sec_keys, "unit": sec_unit, "sd": sec_sd, "asr": sec_asr,
+def sec_variants(ns):
+    """The other model variants of tal/asr/models.py:79-84,103: '1x' (d = 256, head dim 64) with the speaker head, and '2x'
+    with speaker ids as extra vocabulary tokens (use_speaker_head=False, V = 10000 + 6008): encoder projections, decode
+    / decode_spk last rows, attention rows, and a short generate_unaligned trajectory each."""
+    import types
+    System = ns.system.System
+    tok = types.SimpleNamespace(eos_token_id=1, bos_token_id=0, pad_token_id=2)
+    keys = json.load(open(os.path.join(HERE, "state_dict_keys.json")))
+    for tag, kw in (("1x_spk", dict(model_type="1x", num_speakers=6008, vocab_size=10000, use_speaker_head=True)),
+                    ("2x_tok", dict(model_type="2x", num_speakers=6008, vocab_size=10000, use_speaker_head=False))):
+        model = fill(ns.models.ASRModel(**kw))
+        keys["ASRModel_" + tag] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        V = model.embedding.weight.shape[0]
+        audio = synth.synth_audio_batch(1, 480000, 1234)
+        enc = model.encode(torch.from_numpy(audio), torch.tensor([480000]))
+        S = 357
+        mem = {"encoder_out": enc["encoder_out"][:, :S].contiguous(),
+               "speaker_out": None if enc["speaker_out"] is None else enc["speaker_out"][:, :S].contiguous(),
+               "encoder_padding_mask": enc["encoder_padding_mask"][:, :S].contiguous()}
+        r = rows(enc["encoder_out"].shape[1], 8)
+        out = {"S": S, "V": V, "enc_rows": r, "encoder_out": enc["encoder_out"][:, r].numpy()}
+        for U in (1, 7, 64):
+            y = _tokens("variants/%s/y%d" % (tag, U), 1, U, vocab=V)
+            out["y_%d" % U] = y
+            for causal in (True, False):
+                t = "U%d_%s" % (U, "causal" if causal else "full")
+                logits = model.decode(torch.from_numpy(y), mem, causal_mask=causal)
+                out["logits_last_" + t] = logits[:, -1].numpy()
+                out["attn_last_" + t] = torch.stack([l.src_attn_weights[:, -1] for l in model.decoder.layers], 0).numpy()
+                if kw["use_speaker_head"]:
+                    out["spk_last_" + t] = model.decode_spk(torch.from_numpy(y), mem, causal_mask=causal)[:, -1].numpy()
+        # short sliding-window greedy decode (90 s clip, 150 steps)
+        L = 1440000
+        a90 = synth.synth_audio_batch(1, L, 97).astype(np.float16).astype(np.float32)
+        me = types.SimpleNamespace(model=model, lm=None, tokenizer=tok,
+                                   args=types.SimpleNamespace(spk_weight=0.0, lm_weight=0.0))
+        margins = []
+        dec = model.decode
+
+        def spy(y_prev, e, **k):
+            lg = dec(y_prev, e, **k)
+            t2 = torch.topk(lg[0, -1], 2).values
+            margins.append(float(t2[0] - t2[1]))
+            return lg
+        model.decode = spy
+        gen, align = System.generate_unaligned(me, torch.from_numpy(a90), torch.full((1, 1), 1, dtype=torch.long),
+                                               torch.tensor([L]), max_iters=150, stall_patience=25)
+        model.decode = dec
+        print(tag, "closest greedy decisions:", np.sort(np.asarray(margins))[:4])
+        out.update(flow_seed=97, flow_len=L, flow_iters=150, flow_generated=gen.numpy(),
+                   flow_chunk_start=np.asarray([int(c[0]) for c, _ in align]),
+                   flow_attn=np.stack([a.numpy()[0] for _, a in align]).astype(np.float32)[::5],
+                   flow_min_margin=float(min(margins)))
+        save("asr_variant_" + tag, **out)
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)
+
+
+SECTIONS = {"variants": sec_variants, "keys": sec_keys, "unit": sec_unit, "sd": sec_sd, "asr": sec_asr,
             "decode": sec_decode, "gru": sec_gru, "flow": sec_flow,
             "transcribe": sec_transcribe, "uisrnn": sec_uisrnn}
 

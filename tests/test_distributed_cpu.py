@@ -15,3 +15,36 @@ def test_two_rank_sharding_broadcast_gather():
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "rank 0 ok" in p.stdout and "rank 1 ok" in p.stdout
+
+
+def test_bench_entry_self_launches_two_ranks_and_gathers_segments():
+    """`python bench.py --gpus 2` typed as is: the script starts its own two rank processes, shards the segments of the
+    configs[3] workload with distributed.shard_indices and returns them through distributed.gather_segments.  CPU
+    plumbing run (TAL_BENCH_FAKE: the per-segment GPU work is replaced by deterministic tensors; the JSON line says so)."""
+    import json
+    env = dict(os.environ, TAL_BENCH_FAKE="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--segments", "5",
+           "--seconds", "30"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "strong"
+    assert line["gathered_segments"] == 5 and "FAKE" in line["data"]
+    assert "configs[3]" in line["config"]["workload"]
+    assert line["value"] > 0 and abs(line["config"]["frames_per_step"] - 5 * 3001) < 1
+
+
+def test_bench_entry_more_ranks_than_segments():
+    """An empty rank (3 ranks, 2 segments) goes through gather_segments without a sample tensor."""
+    import json
+    env = dict(os.environ, TAL_BENCH_FAKE="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0", "--segments", "2",
+           "--seconds", "30"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["gathered_segments"] == 2

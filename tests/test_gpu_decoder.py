@@ -178,3 +178,56 @@ def test_core_rnn_golden():
     m, h = rnn2(torch.from_numpy(g2["x3"]).to(dev()), None)
     np.testing.assert_allclose(m.cpu().numpy(), g2["m3"], atol=2e-5, rtol=0)
     np.testing.assert_allclose(h.cpu().numpy(), g2["h3"], atol=2e-5, rtol=0)
+
+
+VARIANTS = {"1x_spk": dict(model_type="1x", num_speakers=6008, vocab_size=10000, use_speaker_head=True),
+            "2x_tok": dict(model_type="2x", num_speakers=6008, vocab_size=10000, use_speaker_head=False)}
+
+
+@pytest.mark.parametrize("tag", sorted(VARIANTS))
+def test_model_variants_decode_and_greedy_flow(tag):
+    """The other model variants of tal/asr/models.py:79-84,103 -- '1x' (d = 256, head dim 64) with the speaker head and '2x'
+    with speaker ids as 6008 extra vocabulary tokens -- against fixtures recorded from the reference
+    (tests/golden/make_golden.py, section `variants`): state_dict keys, encoder projection, decode / decode_spk last rows,
+    attention rows, and a 150-step System.generate_unaligned trajectory (identical tokens and window starts)."""
+    import json
+    import os
+    from tal_asrd_amd import ASRModel, synth
+    from tal_asrd_amd.system import System
+    from tests.conftest import GOLDEN
+    g = golden("asr_variant_" + tag)
+    keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))["ASRModel_" + tag]
+    m = ASRModel(**VARIANTS[tag])
+    own = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert own == {k: tuple(s) for k, s in keys}
+    m = _load(m, synth.fill_state_dict(own))
+    V = int(g["V"])
+    assert m.embedding.weight.shape[0] == V
+    audio = torch.from_numpy(synth.synth_audio_batch(1, 480000, 1234)).to(dev())
+    enc = m.encode(audio, torch.tensor([480000]))
+    np.testing.assert_allclose(enc["encoder_out"][:, torch.from_numpy(g["enc_rows"])].cpu().numpy(), g["encoder_out"],
+                               atol=LOGIT_TOL, rtol=0)
+    S = int(g["S"])
+    mem = {"encoder_out": enc["encoder_out"][:, :S].contiguous(),
+           "speaker_out": None if enc["speaker_out"] is None else enc["speaker_out"][:, :S].contiguous(),
+           "encoder_padding_mask": enc["encoder_padding_mask"][:, :S].contiguous()}
+    for U in (1, 7, 64):
+        y = torch.from_numpy(g["y_%d" % U]).to(dev())
+        for causal in (True, False):
+            t = "U%d_%s" % (U, "causal" if causal else "full")
+            logits = m.decode(y, mem, causal_mask=causal)
+            assert tuple(logits.shape) == (1, U, V)
+            np.testing.assert_allclose(logits[:, -1].cpu().numpy(), g["logits_last_" + t], atol=LOGIT_TOL, rtol=0)
+            assert int(logits[0, -1].argmax()) == int(g["logits_last_" + t][0].argmax())
+            attn = torch.stack([l.src_attn_weights[:, -1] for l in m.decoder.layers], 0)
+            np.testing.assert_allclose(attn.cpu().numpy(), g["attn_last_" + t], atol=ATTN_TOL, rtol=0)
+            if VARIANTS[tag]["use_speaker_head"]:
+                spk = m.decode_spk(y, mem, causal_mask=causal)
+                np.testing.assert_allclose(spk[:, -1].cpu().numpy(), g["spk_last_" + t], atol=LOGIT_TOL, rtol=0)
+    L = int(g["flow_len"])
+    a = synth.synth_audio_batch(1, L, int(g["flow_seed"])).astype(np.float16).astype(np.float32)
+    gen, align = System(m).generate_unaligned(torch.from_numpy(a).to(dev()), torch.ones(1, 1, dtype=torch.long, device=dev()),
+                                              torch.tensor([L]), max_iters=int(g["flow_iters"]), stall_patience=25)
+    np.testing.assert_array_equal(gen.cpu().numpy(), g["flow_generated"])
+    np.testing.assert_array_equal(np.array([int(c[0]) for c, _ in align]), g["flow_chunk_start"])
+    np.testing.assert_allclose(np.stack([x.numpy()[0] for _, x in align])[::5], g["flow_attn"], atol=ATTN_TOL, rtol=0)

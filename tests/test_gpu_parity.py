@@ -360,9 +360,9 @@ def _check_sd_golden(model, name, with_lens):
         from tal_asrd_amd import ops
         ids = ops.argmax_rows(logits).cpu().numpy()
         np.testing.assert_array_equal(ids, logits.argmax(-1).cpu().numpy())   # argmax kernel == torch.argmax
-        bad = ids != g["ids"]
-        assert not (bad & (g["margin"] > LOGIT_TOL)).any(), "speaker id differs away from a near-tie"
-        assert bad.sum() <= 2
+        # committed fixtures: IDENTICAL speaker ids (their closest top-2 margin is far above fp32 noise; the
+        # near-tie escape hatch lives only in the random-data tests)
+        np.testing.assert_array_equal(ids, g["ids"])
         if with_lens:
             np.testing.assert_array_equal(enc["encoder_padding_mask"].cpu().numpy(), g["mask"])
     return float(np.abs(logits[:, g["logit_rows"]].cpu().numpy() - g["logit_sample"]).max())
@@ -460,6 +460,34 @@ def test_batch_items_independent(sd_model):
 
 
 # ------------------------------------------------------------------ full-size (1 hour) properties
+def test_one_hour_logmel_against_float64_oracle(sd_model):
+    """configs[2] front-end at full size: LogMelSpec.forward on the 57.6 M-sample clip, 256 sampled rows and the global
+    mean against the float64 restatement of torchaudio 0.4.0 (oracle.logmel_f64 on +-600-sample neighbourhoods of
+    the sampled frames; the mean from float64 partial sums over the whole clip in 30-second pieces)."""
+    from oracle import tal_oracle as O
+    from tal_asrd_amd import ops, synth
+    L = 57_600_000
+    audio = synth.synth_audio_batch(1, L, 1234)
+    x = torch.from_numpy(audio).to(dev())
+    mel, mean, stats = ops.logmel(sd_model.logmelspec.plan(), x, eps=sd_model.logmelspec.eps, subtract_mean=True,
+                                  return_stats=True)
+    T = 1 + L // 160
+    assert tuple(mel.shape) == (1, T, 80)
+    # global mean: float64 reference, piecewise (each piece extended by the 200-sample reflect / overlap context)
+    total = 0.0
+    piece = 3000                                    # frames per piece
+    for f0 in range(0, T, piece):
+        f1 = min(T, f0 + piece)
+        total += float(O.logmel_f64_frames(audio[0], f0, f1).sum())
+    want_mean = total / (T * 80)
+    assert abs(float(mean) - want_mean) < 2e-5, (float(mean), want_mean)
+    assert abs(float(stats[0]) / float(stats[1]) - want_mean) < 2e-6
+    rows = np.unique(np.concatenate([np.arange(0, 8), np.arange(T - 8, T), np.linspace(0, T - 1, 240).astype(np.int64)]))
+    got = mel[0, torch.from_numpy(rows).to(dev())].cpu().numpy()
+    want = np.stack([O.logmel_f64_frames(audio[0], int(r), int(r) + 1)[0] for r in rows]) - want_mean
+    np.testing.assert_allclose(got, want, atol=MEL_TOL, rtol=0)
+
+
 def test_one_hour_prefix_consistency_and_determinism(sd_model):
     """BASELINE.json's full size (360,001 mel frames): encoder frames whose receptive field
     (mel frames [8c-640, 8c+780]) lies inside a 5-minute prefix must equal the 5-minute run, and

@@ -158,11 +158,21 @@ typedef struct tal_tds_desc {
     const float* down_b[TAL_MAX_STAGES];  /* (blocks.i.0.bias) */
     tal_tds_block_w blocks[TAL_MAX_STAGES][TAL_MAX_DEPTH];
     const void* down_w_frag[TAL_MAX_STAGES]; /* stride-2 conv weights as fp16x3 MFMA fragments, or NULL (VALU kernel) */
+    int32_t flags;                    /* TAL_TDS_EXACT_F32: every layer on the exact fp32-input kernels (no fp16x3 form) */
+    int32_t _pad2;
 } tal_tds_desc;
+#define TAL_TDS_EXACT_F32 1
 
 /* output length after all stride-2 stages: T' = f(f(f(T))), f(t) = (t-21)/2+1 */
 int64_t tal_tds_out_len(const tal_tds_desc* d, int64_t T);
 size_t tal_tds_workspace_bytes(const tal_tds_desc* d, int B, int64_t T);
+/* fp16-range guard.  The fp16x3 form carries fp32 values as two fp16 halves, so it needs |x| <= 65504 for every
+ * activation it converts (and for the weights, which the caller checks when it builds the splits).  Every converting
+ * kernel tracks max |x|; tal_tds_fwd clears a status word in its workspace at tal_tds_status_offset() bytes and the
+ * kernels raise it (non-zero int32) when a value was out of range -- the output of that call is then NOT valid and the
+ * caller re-runs it with desc->flags |= TAL_TDS_EXACT_F32 (fp32-input MFMA kernels, no range limit).  Values below
+ * 2^-24 in magnitude lose their low half (absolute error <= 2^-35 per product, far below fp32 resolution of the sums). */
+size_t tal_tds_status_offset(const tal_tds_desc* d, int B, int64_t T);
 /* x [B, T, channels[0]] -> y [B, T', channels[n_stages]] */
 int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t T, float* y,
                 void* workspace, size_t workspace_bytes, void* stream);

@@ -1,0 +1,24 @@
+"""Short-clip latency: SDModel.speaker_ids on one clip of the given length, repeated.  python scripts/bench_short.py [seconds ...]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as g
+g.build()
+from tal_asrd_amd import SDModel, synth
+dev = torch.device("cuda:0")
+m = SDModel()
+sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+own = m.state_dict()
+for k, v in sd.items():
+    own[k] = torch.from_numpy(v.copy())
+m.load_state_dict(own); m.to(dev)
+n = int(os.environ.get("REPS", "50"))
+for sec in [float(a) for a in sys.argv[1:]] or [30.0, 300.0]:
+    L = int(sec * 16000)
+    x = torch.from_numpy(synth.synth_audio_batch(1, L, 1234)).to(dev)
+    with torch.no_grad():
+        for _ in range(5): m.speaker_ids(x)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): m.speaker_ids(x)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    print("%.0f s clip: %.3f ms per call = %.2f M frames/s" % (sec, dt * 1e3, (1 + L // 160) / dt / 1e6), flush=True)

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("TAL_ASRD_LIB", os.path.join(_HERE, "libtal_asrd_hip.s
 
 TAL_MAX_STAGES = 4
 TAL_MAX_DEPTH = 8
+TAL_TDS_EXACT_F32 = 1
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -27,7 +28,7 @@ class TdsDesc(C.Structure):
                 ("channels", C.c_int32 * (TAL_MAX_STAGES + 1)), ("depths", C.c_int32 * TAL_MAX_STAGES),
                 ("down_w", C.c_void_p * TAL_MAX_STAGES), ("down_b", C.c_void_p * TAL_MAX_STAGES),
                 ("blocks", (TdsBlockW * TAL_MAX_DEPTH) * TAL_MAX_STAGES),
-                ("down_w_frag", C.c_void_p * TAL_MAX_STAGES)]
+                ("down_w_frag", C.c_void_p * TAL_MAX_STAGES), ("flags", C.c_int32), ("_pad2", C.c_int32)]
 
 
 class DecoderLayerW(C.Structure):
@@ -71,6 +72,7 @@ SIGNATURES = {
     "tal_gconv_res_f16x3_fwd": (_i, [_p, _p, _p, _f, _i, _i64, _i, _i, _p, _p, _p]),
     "tal_tds_out_len": (_i64, [C.POINTER(TdsDesc), _i64]),
     "tal_tds_workspace_bytes": (_sz, [C.POINTER(TdsDesc), _i, _i64]),
+    "tal_tds_status_offset": (_sz, [C.POINTER(TdsDesc), _i, _i64]),
     "tal_tds_fwd": (_i, [C.POINTER(TdsDesc), _p, _i, _i64, _p, _p, _sz, _p]),
     "tal_sd_head_workspace_bytes": (_sz, [_i64, _i]),
     "tal_sd_head_fwd": (_i, [_p, _i64, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _sz, _p]),

@@ -72,21 +72,34 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 }
 
 // final reduction of the fused arg-max partials (ascending column slices; strict '>' keeps the lowest index)
+// One wave per row: lanes take partials p = lane, lane + 64, ... (a thread per row walking P partials is a chain of P
+// dependent loads: 46 us for 188 partials); the partials are in ascending column order, so the lowest column wins ties.
 __global__ __launch_bounds__(256) void argmax_partials_kernel(const float* __restrict__ pv,
                                                              const int32_t* __restrict__ pi, int64_t M, int P, int ld,
                                                              int32_t* __restrict__ ids) {
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     float best = -INFINITY;
-    int bi = 0;
-    for (int p = 0; p < P; ++p) {
+    int bi = 0x7fffffff;
+    for (int p = lane; p < P; p += 64) {
         const float v = pv[row * ld + p];
-        if (v > best) {
+        const int idx = pi[row * ld + p];
+        if (v > best || (v == best && idx < bi)) {
             best = v;
-            bi = pi[row * ld + p];
+            bi = idx;
         }
     }
-    ids[row] = bi;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) ids[row] = bi == 0x7fffffff ? 0 : bi;
 }
 
 // one workgroup per row (few long rows: the arg-max of a decode step's [1, V] logits)
@@ -291,9 +304,15 @@ static size_t tds_buf_floats(const tal_tds_desc* d, int B, int64_t T) {
     return (mx + 63) & ~(size_t)63;
 }
 
-extern "C" size_t tal_tds_workspace_bytes(const tal_tds_desc* d, int B, int64_t T) {
+// workspace = 4 rotating activation buffers | split-K scratch | 64-byte status block (word 0: fp16-range flag)
+extern "C" size_t tal_tds_status_offset(const tal_tds_desc* d, int B, int64_t T) {
     if (!d || B <= 0 || T <= 0) return 0;
     return 4 * tds_buf_floats(d, B, T) * sizeof(float) + gemm_splitk_ws_bytes();
+}
+
+extern "C" size_t tal_tds_workspace_bytes(const tal_tds_desc* d, int B, int64_t T) {
+    if (!d || B <= 0 || T <= 0) return 0;
+    return tal_tds_status_offset(d, B, T) + 64;
 }
 
 extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t T, float* y, void* workspace,
@@ -311,7 +330,14 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
     float* buf[4];
     for (int q = 0; q < 4; ++q) buf[q] = reinterpret_cast<float*>(workspace) + q * nf;
     float* skws = reinterpret_cast<float*>(workspace) + 4 * nf;   // split-K scratch of the dense layers
-    static const bool force_f32 = getenv("TAL_TDS_F32") != nullptr;
+    static const bool env_f32 = getenv("TAL_TDS_F32") != nullptr;
+    const bool force_f32 = env_f32 || (d->flags & TAL_TDS_EXACT_F32) != 0;
+    // status word: raised by any kernel that turns an fp32 value outside the finite fp16 range into hi / lo halves
+    int* range_flag = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + tal_tds_status_offset(d, B, T));
+    if (hipMemsetAsync(range_flag, 0, 64, s) != hipSuccess) {
+        set_error("tal_tds_fwd: cannot clear the status word");
+        return TAL_EHIP;
+    }
     // four rotating buffers; `ia` = index of the buffer holding the live activations (-1: caller's x).
     // No launch ever reads and writes the same buffer (workgroups read halos of their neighbours).
     const float* cur = x;
@@ -325,8 +351,9 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
         const int io = (ia + 1) % 4;
         float* a = (last_stage && d->depths[i] == 0) ? y : buf[io];
         // stride-2 resize conv: on the matrix cores for long inputs when the fragments are there (10 -> 14, 14 -> 18 per group)
-        if (!force_f32 && d->down_w_frag[i] && (int64_t)B * To > 512 && gconv_f16x3_weight_bytes(cin, c, d->groups, 2) > 0 && gconv_f16x3_fits(Tc, cin))
-            rc = launch_gconv_s2_f16x3(cur, d->down_w_frag[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s);
+        // (the matrix-core conv pays from ~a hundred output steps on: 358 steps of 18 channels per group take 13 us against 57)
+        if (!force_f32 && d->down_w_frag[i] && (int64_t)B * To > 64 && gconv_f16x3_weight_bytes(cin, c, d->groups, 2) > 0 && gconv_f16x3_fits(Tc, cin))
+            rc = launch_gconv_s2_f16x3(cur, d->down_w_frag[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s, range_flag);
         else
             rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s);
         if (rc) return rc;
@@ -340,22 +367,23 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
             float* x1s = buf[(ia + 3) % 4];
             float* outp = (last_stage && j == d->depths[i] - 1) ? y : buf[ia];
             const bool f16x3 = !force_f32 && bw.fc0_w_split && bw.fc3_w_split && M > 512 && c % 160 == 0;
-            const bool conv_mfma = f16x3 && bw.conv_w_frag && gconv_f16x3_weight_bytes(c, c, d->groups, 1) > 0 && gconv_f16x3_fits(To, c);
+            const bool conv_mfma = !force_f32 && M > 64 && bw.conv_w_frag && gconv_f16x3_weight_bytes(c, c, d->groups, 1) > 0 && gconv_f16x3_fits(To, c);
             // x1 = x + rw * relu(gconv(x))            : a -> x1
             // (The matrix-core kernel can also emit x1 as the hi / lo split; measured on the 1-hour shapes that fused store
             //  costs +0.35 / +0.21 / +0.14 ms per launch -- 8-byte pieces that fill 32-byte sectors only partially -- against
             //  0.20 / 0.12 / 0.09 ms for the separate, fully coalesced split pass, so the driver keeps the pass.)
             static const bool fuse_split = getenv("TAL_GCONV_FUSE_SPLIT") != nullptr;
             if (conv_mfma)
-                rc = launch_gconv_res_f16x3(a, bw.conv_w_frag, bw.conv_b, bw.resweight, B, To, c, d->groups, x1, fuse_split ? x1s : nullptr, s);
+                rc = launch_gconv_res_f16x3(a, bw.conv_w_frag, bw.conv_b, bw.resweight, B, To, c, d->groups, x1, (fuse_split && f16x3) ? x1s : nullptr, s,
+                                            range_flag);
             else
                 rc = launch_gconv_res(a, bw.conv_w, bw.conv_b, bw.resweight, B, To, c, d->groups, x1, s);
             if (rc) return rc;
             if (f16x3) {
                 // the two dense layers in the fp16x3 form: x1 is split once, fc0 writes its output already split
-                if (!(conv_mfma && fuse_split)) rc = launch_split_f16x3(x1, x1s, M, c, s);
+                if (!(conv_mfma && fuse_split)) rc = launch_split_f16x3(x1, x1s, M, c, s, range_flag);
                 if (rc) return rc;
-                rc = launch_linear_f16x3(x1s, bw.fc0_w_split, bw.fc0_b, nullptr, 0.f, 1, M, c, c, h, 1, skws, gemm_splitk_ws_bytes(), s);
+                rc = launch_linear_f16x3(x1s, bw.fc0_w_split, bw.fc0_b, nullptr, 0.f, 1, M, c, c, h, 1, skws, gemm_splitk_ws_bytes(), s, range_flag);
                 if (rc) return rc;
                 rc = launch_linear_f16x3(h, bw.fc3_w_split, bw.fc3_b, x1, bw.resweight, 2, M, c, c, outp, 0, skws,
                                          gemm_splitk_ws_bytes(), s);
@@ -442,7 +470,7 @@ extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_
         rc = launch_head_argmax(feat, w_logit, wsplit, b_logit, M, S, pv, pi, s);
         if (rc) return rc;
         ProfScope prof(PROF_OTHER, (double)M * P * 8.0, s);
-        hipLaunchKernelGGL(argmax_partials_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, pv, pi, M, P, P, ids);
+        hipLaunchKernelGGL(argmax_partials_kernel, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, pv, pi, M, P, P, ids);
         TAL_CHECK_LAUNCH("tal_sd_head_fwd(argmax)");
         return TAL_OK;
     }
@@ -460,7 +488,7 @@ extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_
     if (rc) return rc;
     {
         ProfScope prof(PROF_OTHER, (double)M * ld * 8.0, s);
-        hipLaunchKernelGGL(argmax_partials_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, g.part_val, g.part_idx, M,
+        hipLaunchKernelGGL(argmax_partials_kernel, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, g.part_val, g.part_idx, M,
                            gemm_mode4_partials(M, S), ld, ids);
     }
     TAL_CHECK_LAUNCH("tal_sd_head_fwd(argmax)");

@@ -71,6 +71,16 @@ __device__ __forceinline__ void reset_ticket(unsigned* word) {
     __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// fp16-range guard of the fp16x3 form: every place that turns fp32 data into hi / lo halves tracks max |x| and raises a
+// status word when a value lies outside the finite fp16 range (the halves are clamped, so the results of that launch
+// are wrong, not inf).  tal_tds_fwd exposes the word; the host re-runs the affected call on the exact fp32 kernels.
+__device__ __forceinline__ float amax4(float a, const f32x4& v) {
+    return fmaxf(fmaxf(a, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+__device__ __forceinline__ void note_range(float amax, int* flag) {
+    if (flag && amax > 65504.f) atomicOr(flag, 1);
+}
+
 // wave-uniform wave index inside the workgroup, provably uniform to the compiler
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
@@ -114,6 +124,7 @@ struct GemmArgs {
     // fp32 rows (per row and 32-wide K block: 32 hi halves, then 32 lo halves scaled by 2^11); out_split: write Y in
     // the same split form (it is the next layer's A) instead of fp32.  Needs K % 32 == 0 (and N % 32 == 0 for out_split).
     int f16x3, out_split;
+    int* range_flag;   // out_split: raised when an output value lies outside the fp16 range (may be NULL)
 };
 // mode 0: acc+b | 1: relu(acc+b) | 2: res + alpha*(acc+b) | 3: alpha*(acc+b) | 4: row arg-max partials of acc+b
 int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s);
@@ -127,10 +138,10 @@ int launch_linear_ws(const float* x, const float* w, const float* b, const float
                      int64_t M, int N, int K, float* y, float* ws, size_t ws_bytes, hipStream_t s);
 size_t gemm_splitk_ws_bytes();
 // fp32 [rows, K] -> hi/lo fp16 split in fp32-row geometry (K % 32 == 0)
-int launch_split_f16x3(const float* x, void* out, int64_t rows, int K, hipStream_t s);
+int launch_split_f16x3(const float* x, void* out, int64_t rows, int K, hipStream_t s, int* range_flag = nullptr);
 // dense layer on pre-split operands (see GemmArgs::f16x3); ws as launch_linear_ws
 int launch_linear_f16x3(const void* xs, const void* wsplit, const float* b, const float* res, float alpha, int mode, int64_t M,
-                        int N, int K, void* y, int out_split, float* ws, size_t ws_bytes, hipStream_t s);
+                        int N, int K, void* y, int out_split, float* ws, size_t ws_bytes, hipStream_t s, int* range_flag = nullptr);
 int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, int64_t T_in, int C_in, int C_out,
                     int groups, float* y, hipStream_t s);
 int launch_gconv_res(const float* x, const float* wp, const float* bias, float alpha, int B, int64_t T, int C,
@@ -139,9 +150,9 @@ size_t gconv_f16x3_weight_bytes(int C_in, int C_out, int groups, int stride);
 bool gconv_f16x3_fits(int64_t T, int C);
 int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C_in, int C_out, int groups, int stride, hipStream_t s);
 int launch_gconv_s2_f16x3(const float* x, const void* w_frag, const float* bias, int B, int64_t T_in, int C_in, int C_out, int groups,
-                          float* y, hipStream_t s);
+                          float* y, hipStream_t s, int* range_flag = nullptr);
 int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias, float alpha, int B, int64_t T, int C, int groups,
-                           float* y, void* y_split, hipStream_t s);
+                           float* y, void* y_split, hipStream_t s, int* range_flag = nullptr);
 int launch_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, hipStream_t s);
 // A-stationary speaker-logit arg-max (csrc/head.hip): partials [M, head_argmax_partials()] for argmax_partials_kernel
 bool head_argmax_applicable(int64_t M, int S, int E);

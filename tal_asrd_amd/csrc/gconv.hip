@@ -372,7 +372,7 @@ template <int CIG, int COG, int STRIDE, bool RESID, int GB, int TT, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restrict__ x, const _Float16* __restrict__ wfrag,
                                                            const float* __restrict__ bias, float alpha, float* __restrict__ y,
                                                            _Float16* __restrict__ ysplit, int64_t T_in, int64_t T_out, int C_in,
-                                                           int C_out) {
+                                                           int C_out, int* __restrict__ range_flag) {
     using LY = GcLayout<CIG, STRIDE>;
     constexpr int NKS = LY::NKS, NK0 = LY::nk(0), MT = (COG + 15) / 16;
     constexpr int P0 = LY::pitch(0), P1 = LY::pitch(1);
@@ -414,11 +414,14 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
         // (32-bit byte offset: launch_* checks that a batch item stays below 2 GiB; a negative row wraps to an offset past the range)
         const int voff = (int)((row0 * C_in + g0 * CIG + (active ? c4 * 4 : 0)) * 4);
         constexpr int NPASS = (TIN + RPP - 1) / RPP, UNR = NPASS > 20 ? (NPASS + 1) / 2 : NPASS;
+        float amax = 0.f;      // fp16-range guard: the largest |x| this thread turns into halves
         for (int p0 = 0; p0 < NPASS; p0 += UNR) {
             f32x4 v[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
                 v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff + (p0 + u) * RPP * C_in * 4, 0, 0));
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) amax = amax4(amax, v[u]);
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int ti = r0 + (p0 + u) * RPP;
@@ -442,6 +445,7 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
                 }
             }
         }
+        note_range(amax, range_flag);
         // zeros in the pad channels of every row and behind the last row of each segment (finite bytes under zero weights)
         const f16x2 z2 = {(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
@@ -562,6 +566,7 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
                         // the same values as hi / lo halves in the dense layers' operand geometry: per row and 32-channel
                         // block 32 hi halves, then 32 lo halves (channels cbase .. cbase + 3; cbase is even)
                         _Float16 h[4], l[4];
+                        note_range(amax4(0.f, o), range_flag);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) split_f16x3(o[i], h[i], l[i]);
                         _Float16* sp = ysplit + (((int64_t)b * T_out + t) * (C_out >> 5) + (cbase >> 5)) * 64 + (cbase & 31);
@@ -613,7 +618,7 @@ __global__ void pack_gconv_mfma_kernel(const float* __restrict__ src, _Float16* 
 
 template <int CIG, int COG, int STRIDE, bool RESID, int GB, int TT>
 static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias, float alpha, float* y, void* ysplit, int B,
-                            int64_t T_in, int64_t T_out, int C_in, int C_out, int groups, hipStream_t s) {
+                            int64_t T_in, int64_t T_out, int C_in, int C_out, int groups, hipStream_t s, int* range_flag) {
     using LY = GcLayout<CIG, STRIDE>;
     constexpr size_t lds = (size_t)2 * GB * (LY::slab(0, TT) + LY::slab(1, TT)) * sizeof(_Float16);
     auto k0 = gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, false>;
@@ -630,7 +635,7 @@ static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias
     dim3 grid((unsigned)cdiv(T_out, TT), (unsigned)(groups / GB), (unsigned)B);
     ProfScope prof(RESID ? PROF_GCONV_RES : PROF_GCONV_S2, 2.0 * (double)B * (double)T_out * C_out * CIG * KS, s);
     hipLaunchKernelGGL((ysplit && RESID) ? k1 : k0, grid, dim3(256), lds, s, x, reinterpret_cast<const _Float16*>(wfrag), bias, alpha, y,
-                       reinterpret_cast<_Float16*>(ysplit), T_in, T_out, C_in, C_out);
+                       reinterpret_cast<_Float16*>(ysplit), T_in, T_out, C_in, C_out, range_flag);
     TAL_CHECK_LAUNCH("gconv (fp16x3)");
     return TAL_OK;
 }
@@ -657,7 +662,7 @@ int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C_in, int C_ou
 }
 
 int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias, float alpha, int B, int64_t T, int C, int groups,
-                           float* y, void* y_split, hipStream_t s) {
+                           float* y, void* y_split, hipStream_t s, int* range_flag) {
     TAL_CHECK_ARG(x && w_frag && bias && y, "tal_gconv_res_f16x3_fwd: null pointer");
     TAL_CHECK_ARG(x != y, "tal_gconv_res_f16x3_fwd: in-place not supported (halo reads)");
     TAL_CHECK_ARG(gconv_f16x3_weight_bytes(C, C, groups, 1) > 0, "tal_gconv_res_f16x3_fwd: no fp16x3 kernel for C=%d groups=%d", C, groups);
@@ -666,13 +671,13 @@ int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias
     TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && C % 4 == 0, "tal_gconv_res_f16x3_fwd: x must be 16-byte aligned");
     TAL_CHECK_ARG(gconv_f16x3_fits(T, C), "tal_gconv_res_f16x3_fwd: one batch item must stay below 2 GiB (T=%lld, C=%d)", (long long)T, C);
     const int cg = C / groups;
-    if (cg == 10) return launch_mfma_spec<10, 10, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s);
-    if (cg == 14) return launch_mfma_spec<14, 14, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s);
-    return launch_mfma_spec<18, 18, 1, true, 2, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s);
+    if (cg == 10) return launch_mfma_spec<10, 10, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag);
+    if (cg == 14) return launch_mfma_spec<14, 14, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag);
+    return launch_mfma_spec<18, 18, 1, true, 2, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag);
 }
 
 int launch_gconv_s2_f16x3(const float* x, const void* w_frag, const float* bias, int B, int64_t T_in, int C_in, int C_out, int groups,
-                          float* y, hipStream_t s) {
+                          float* y, hipStream_t s, int* range_flag) {
     TAL_CHECK_ARG(x && w_frag && bias && y, "tal_gconv_s2_f16x3_fwd: null pointer");
     TAL_CHECK_ARG(gconv_f16x3_weight_bytes(C_in, C_out, groups, 2) > 0, "tal_gconv_s2_f16x3_fwd: no fp16x3 kernel for %d -> %d channels, groups=%d",
                   C_in, C_out, groups);
@@ -680,8 +685,8 @@ int launch_gconv_s2_f16x3(const float* x, const void* w_frag, const float* bias,
     TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && C_in % 4 == 0, "tal_gconv_s2_f16x3_fwd: x must be 16-byte aligned");
     TAL_CHECK_ARG(gconv_f16x3_fits(T_in, C_in), "tal_gconv_s2_f16x3_fwd: one batch item must stay below 2 GiB (T=%lld, C=%d)", (long long)T_in, C_in);
     const int64_t T_out = (T_in - KS) / 2 + 1;
-    if (C_in / groups == 10) return launch_mfma_spec<10, 14, 2, false, 4, 128>(x, w_frag, bias, 0.f, y, nullptr, B, T_in, T_out, C_in, C_out, groups, s);
-    return launch_mfma_spec<14, 18, 2, false, 2, 128>(x, w_frag, bias, 0.f, y, nullptr, B, T_in, T_out, C_in, C_out, groups, s);
+    if (C_in / groups == 10) return launch_mfma_spec<10, 14, 2, false, 4, 128>(x, w_frag, bias, 0.f, y, nullptr, B, T_in, T_out, C_in, C_out, groups, s, range_flag);
+    return launch_mfma_spec<14, 18, 2, false, 2, 128>(x, w_frag, bias, 0.f, y, nullptr, B, T_in, T_out, C_in, C_out, groups, s, range_flag);
 }
 
 // reference Conv1d weight [C_out, CIG, K] -> packed [G][CIG][K][COG]

@@ -50,6 +50,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
     const int rowb = 4 * (lane >> 5);
     const float alpha = g.alpha;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    float amax = 0.f;              // out_split: largest |value| this lane turned into halves
     constexpr int CW = 32 * NSUB;  // columns owned by one wave
     if (MODE == 4) {
         // Fused arg-max over this wave's CW columns (the [M, 6008] speaker logits are never written,
@@ -172,6 +173,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                         // K blocks [32 hi | 32 lo]  (column c of the wave's window -> block c / 32, slot c % 32)
                         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                         f16x4 hi, lo;
+                        amax = amax4(amax, v);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             _Float16 h, l;
@@ -187,6 +189,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y[half], offy[t], 0, 0);
                 }
+                if (g.out_split && half == 1) note_range(amax, g.range_flag);
                 continue;
             }
 #pragma unroll
@@ -746,6 +749,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(const GemmArgs g
             if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) v = g.alpha * v;
             if (g.out_split) {
                 f16x4 hi, lo;
+                note_range(amax4(0.f, v), g.range_flag);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     _Float16 h, l;
@@ -930,10 +934,12 @@ int launch_linear_ws(const float* x, const float* w, const float* b, const float
 
 // fp32 -> hi / lo fp16 split in fp32-row geometry: per row and 32-wide K block, 32 hi halves then 32 lo halves
 // (lo = (x - hi) * 2^11): one thread per 4 consecutive floats
-__global__ __launch_bounds__(256) void split_f16x3_kernel(const float* __restrict__ x, _Float16* __restrict__ out, int64_t n4) {
+__global__ __launch_bounds__(256) void split_f16x3_kernel(const float* __restrict__ x, _Float16* __restrict__ out, int64_t n4,
+                                                         int* __restrict__ range_flag) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    note_range(amax4(0.f, v), range_flag);
     f16x4 hi, lo;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -949,19 +955,19 @@ __global__ __launch_bounds__(256) void split_f16x3_kernel(const float* __restric
     *reinterpret_cast<f16x4*>(o + 32) = lo;
 }
 
-int launch_split_f16x3(const float* x, void* out, int64_t rows, int K, hipStream_t s) {
+int launch_split_f16x3(const float* x, void* out, int64_t rows, int K, hipStream_t s, int* range_flag) {
     TAL_CHECK_ARG(x && out && rows >= 0 && K > 0 && K % 32 == 0, "split_f16x3: bad argument (K %% 32 == 0 required)");
     TAL_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "split_f16x3: 16-byte alignment required");
     const int64_t n4 = rows * K / 4;
     if (n4 == 0) return TAL_OK;
     ProfScope prof(PROF_OTHER, (double)rows * K * 8.0, s);
-    hipLaunchKernelGGL(split_f16x3_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, s, x, reinterpret_cast<_Float16*>(out), n4);
+    hipLaunchKernelGGL(split_f16x3_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, s, x, reinterpret_cast<_Float16*>(out), n4, range_flag);
     TAL_CHECK_LAUNCH("split_f16x3");
     return TAL_OK;
 }
 
 int launch_linear_f16x3(const void* xs, const void* wsplit, const float* b, const float* res, float alpha, int mode, int64_t M,
-                        int N, int K, void* y, int out_split, float* ws, size_t ws_bytes, hipStream_t s) {
+                        int N, int K, void* y, int out_split, float* ws, size_t ws_bytes, hipStream_t s, int* range_flag) {
     TAL_CHECK_ARG(xs && wsplit && y, "linear_f16x3: null pointer");
     GemmArgs g = {};
     g.A = reinterpret_cast<const float*>(xs); g.W = reinterpret_cast<const float*>(wsplit); g.bias = b; g.res = res;
@@ -974,6 +980,7 @@ int launch_linear_f16x3(const void* xs, const void* wsplit, const float* b, cons
     g.splitk_ws_bytes = ws_bytes;
     g.f16x3 = 1;
     g.out_split = out_split;
+    g.range_flag = range_flag;
     return launch_gemm(g, mode, 1, s);
 }
 

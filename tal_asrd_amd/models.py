@@ -210,17 +210,23 @@ class TDS(nn.Module):
             return self._packs[s]
         down, chain = self.blocks[s][0], self.blocks[s][1]
         c = self.sizes[s + 1]
-        pack = {"down_w": down.packed(), "down_frag": ops.pack_gconv_f16x3_weight(down.weight.detach(), down.groups, stride=2),
+        # fp16-range guard, weight side: a weight beyond the finite fp16 range (or non-finite) cannot be carried as hi / lo
+        # halves; such a layer keeps the exact fp32 kernels (no split / fragment form is built for it)
+        def in_range(w):
+            return bool(torch.isfinite(w).all()) and float(w.abs().max()) <= 65504.0
+        pack = {"down_w": down.packed(),
+                "down_frag": ops.pack_gconv_f16x3_weight(down.weight.detach(), down.groups, stride=2) if in_range(down.weight.detach()) else None,
                 "blocks": []}
         rws = torch.stack([blk.resweight.detach().reshape(()) for blk in chain]).cpu().tolist() if len(chain) else []
         for blk, rw in zip(chain, rws):
             g = blk.conv[0]
             b = {"conv_w": g.packed(), "rw": float(rw), "fc0_split": None, "fc3_split": None, "conv_frag": None}
-            if c % 160 == 0:
+            if c % 160 == 0 and in_range(blk.fc[0].weight.detach()) and in_range(blk.fc[3].weight.detach()):
                 # hi / lo fp16 splits of the two pointwise weights: long inputs run these layers in the fp16x3
                 # form (include/tal_asrd.h), fp32-equivalent results at ~2.4x the fp32 matrix rate
                 b["fc0_split"] = ops.split_f16x3(blk.fc[0].weight.detach().reshape(c, c))
                 b["fc3_split"] = ops.split_f16x3(blk.fc[3].weight.detach().reshape(c, c))
+            if in_range(g.weight.detach()):
                 # ... and the grouped conv as fp16x3 MFMA operand fragments (widths 10 / 14 / 18 per group)
                 b["conv_frag"] = ops.pack_gconv_f16x3_weight(g.weight.detach(), g.groups)
             pack["blocks"].append(b)

@@ -174,8 +174,16 @@ def gconv_res_f16x3(x, w_frag, bias, alpha, groups, want_split=False):
 
 
 # ------------------------------------------------------------------ TDS driver
-def tds_forward(desc, x, c_out):
-    """x [B, T, C0] -> [B, T', C_last] through tal_tds_fwd (whole encoder, one C call)."""
+range_fallbacks = 0      # calls that were re-run on the exact fp32 kernels because an activation left the fp16 range
+
+
+def tds_forward(desc, x, c_out, check_range=True):
+    """x [B, T, C0] -> [B, T', C_last] through tal_tds_fwd (whole encoder, one C call).
+
+    fp16-range guard: the long-input layers run in the fp16x3 form (fp32 values as two fp16 halves), which needs
+    |activation| <= 65504.  The kernels raise a status word when a value was out of range; the call is then repeated
+    on the exact fp32-input kernels (one small device-to-host read per call; check_range=False skips it)."""
+    global range_fallbacks
     lib = N.lib()
     x = _f32c(x, "tds_forward")
     B, T, _ = x.shape
@@ -187,6 +195,16 @@ def tds_forward(desc, x, c_out):
     ws = _ws(nws, x.device)
     N.check(lib.tal_tds_fwd(C.byref(desc), N.ptr(x), B, T, N.ptr(y), N.ptr(ws), nws, N.stream_handle()),
             "tal_tds_fwd")
+    if check_range and not (desc.flags & N.TAL_TDS_EXACT_F32):
+        off = lib.tal_tds_status_offset(C.byref(desc), B, T)
+        if int(ws[off:off + 4].view(torch.int32)[0]) != 0:
+            range_fallbacks += 1
+            desc.flags |= N.TAL_TDS_EXACT_F32
+            try:
+                N.check(lib.tal_tds_fwd(C.byref(desc), N.ptr(x), B, T, N.ptr(y), N.ptr(ws), nws, N.stream_handle()),
+                        "tal_tds_fwd (exact fp32 re-run)")
+            finally:
+                desc.flags &= ~N.TAL_TDS_EXACT_F32
     return y
 
 

@@ -45,7 +45,10 @@ def test_struct_layout_matches_header():
     expect = 4 + 4 + 5 * 4 + 4 * 4          # ints
     expect = (expect + 7) // 8 * 8           # align for pointers
     expect += 4 * 8 * 2 + 4 * 8 * C.sizeof(_native.TdsBlockW) + 4 * 8
+    expect += 8                              # flags + pad
     assert C.sizeof(_native.TdsDesc) == expect
+    assert _native.TdsDesc.flags.offset == expect - 8
+    assert C.sizeof(_native.GreedyCtx) == 8 + 8 * 4 + 8 * 8 + 8 + 8 + 3 * 8    # pointer, 8 ints, 8 pointers, workspace + size, 3 pointers
 
 
 def test_error_path_no_gpu_needed():

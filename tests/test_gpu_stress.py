@@ -179,3 +179,55 @@ def test_sd_head_random_shapes():
         _, _, ids = ops.sd_head(x, we, be, wl, bl, want_logits=False, want_ids=True)
         assert torch.equal(ids, ids_ref), (M, S)
         assert torch.equal(ids.long().cpu(), logits.argmax(-1).cpu()), (M, S)
+
+
+def test_fp16_range_guard_routes_to_exact_kernels():
+    """The fp16x3 form carries fp32 activations as two fp16 halves (|x| <= 65504).  A TDSBlock fed with activations ~1e5
+    must not silently degrade: the kernels raise the status word, the call is re-run on the exact fp32-input kernels
+    and matches float64 to the fp32 path's tolerance; in-range input must not trigger the fallback."""
+    from tal_asrd_amd import TDS, ops, synth
+    torch.manual_seed(3)
+    tds = TDS(80, [80, 800], [1])                     # one stride-2 conv + one TDSBlock at 10 channels per group
+    sd = synth.fill_state_dict({"g." + k: tuple(v.shape) for k, v in tds.state_dict().items()})
+    own = tds.state_dict()
+    for k in own:
+        own[k] = torch.from_numpy(sd["g." + k].copy())
+    tds.load_state_dict(own)
+    tds64 = torch.nn.Sequential()                     # float64 reference of the same layers on the CPU
+    conv0 = torch.nn.Conv1d(80, 800, 21, stride=2, groups=80).double()
+    blk_conv = torch.nn.Conv1d(800, 800, 21, groups=80, padding=10).double()
+    fc0 = torch.nn.Conv1d(800, 800, 1).double()
+    fc3 = torch.nn.Conv1d(800, 800, 1).double()
+    with torch.no_grad():
+        conv0.weight.copy_(own["blocks.0.0.weight"]); conv0.bias.copy_(own["blocks.0.0.bias"])
+        blk_conv.weight.copy_(own["blocks.0.1.0.conv.0.weight"]); blk_conv.bias.copy_(own["blocks.0.1.0.conv.0.bias"])
+        fc0.weight.copy_(own["blocks.0.1.0.fc.0.weight"]); fc0.bias.copy_(own["blocks.0.1.0.fc.0.bias"])
+        fc3.weight.copy_(own["blocks.0.1.0.fc.3.weight"]); fc3.bias.copy_(own["blocks.0.1.0.fc.3.bias"])
+    rw = float(own["blocks.0.1.0.resweight"])
+
+    def ref(x):
+        with torch.no_grad():
+            a = conv0(x.double().permute(0, 2, 1))
+            a = a + rw * torch.relu(blk_conv(a))
+            a = a + rw * fc3(torch.relu(fc0(a)))
+            return a.permute(0, 2, 1)
+    tds.to(dev())
+    T = 2400                                          # 1190 output steps: the fp16x3 path (M > 512)
+    base = torch.randn(1, T, 80)
+    before = ops.range_fallbacks
+    y = tds.forward_time_major(base.to(dev()))
+    assert ops.range_fallbacks == before              # O(1) activations: the fast form, no fallback
+    want = ref(base)
+    assert float((y.cpu().double() - want).abs().max()) < 1e-3
+    big = base * 3.0e5                                # activations ~1e6 after the first conv: far outside the fp16 range
+    y = tds.forward_time_major(big.to(dev()))
+    assert ops.range_fallbacks == before + 1          # detected and re-run
+    want = ref(big)
+    rel = float((y.cpu().double() - want).abs().max() / want.abs().max())
+    assert rel < 2e-6, rel                            # fp32 accuracy at the data's own scale, not a clamped fp16 result
+    assert float(want.abs().max()) > 65504.0
+    # a weight beyond the fp16 range keeps that layer off the fp16x3 form at pack time
+    with torch.no_grad():
+        tds.blocks[0][1][0].fc[0].weight[0, 0, 0] = 1.0e6
+    tds._descriptor()
+    assert tds._packs[0]["blocks"][0]["fc0_split"] is None

@@ -130,6 +130,14 @@ int tal_gconv_res_f16x3_fwd(const float* x, const void* w_frag, const float* bia
                             int64_t T, int C, int groups, float* y, void* y_split, void* stream);
 int tal_gconv_s2_f16x3_fwd(const float* x, const void* w_frag, const float* bias, int B, int64_t T_in,
                            int C_in, int C_out, int groups, float* y, void* stream);
+/* The same convs on activations that live in the hi / lo split form (tal_split_f16x3_fwd's format: the canonical
+ * activation format between the kernels of a long-input TDS stage): the input slab is filled without any conversion
+ * arithmetic, the TDSBlock residual is rebuilt as hi + lo * 2^-11, and only the split form of the output is written.
+ * tal_gconv_s2_split_fwd also accepts an fp32 input (x_is_split == 0). */
+int tal_gconv_res_split_fwd(const void* x_split, const void* w_frag, const float* bias, float alpha, int B,
+                            int64_t T, int C, int groups, void* y_split, void* stream);
+int tal_gconv_s2_split_fwd(const void* x, int x_is_split, const void* w_frag, const float* bias, int B,
+                           int64_t T_in, int C_in, int C_out, int groups, void* y_split, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Whole TDS encoder: TDS.forward, tal/asr/models.py:349-397 (+TDSBlock :298-331)

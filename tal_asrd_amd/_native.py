@@ -70,6 +70,8 @@ SIGNATURES = {
     "tal_pack_gconv_f16x3_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "tal_gconv_s2_f16x3_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _p, _p]),
     "tal_gconv_res_f16x3_fwd": (_i, [_p, _p, _p, _f, _i, _i64, _i, _i, _p, _p, _p]),
+    "tal_gconv_res_split_fwd": (_i, [_p, _p, _p, _f, _i, _i64, _i, _i, _p, _p]),
+    "tal_gconv_s2_split_fwd": (_i, [_p, _i, _p, _p, _i, _i64, _i, _i, _i, _p, _p]),
     "tal_tds_out_len": (_i64, [C.POINTER(TdsDesc), _i64]),
     "tal_tds_workspace_bytes": (_sz, [C.POINTER(TdsDesc), _i, _i64]),
     "tal_tds_status_offset": (_sz, [C.POINTER(TdsDesc), _i, _i64]),

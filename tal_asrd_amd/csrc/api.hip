@@ -268,6 +268,20 @@ extern "C" int tal_gconv_s2_f16x3_fwd(const float* x, const void* w_frag, const 
     return launch_gconv_s2_f16x3(x, w_frag, bias, B, T_in, C_in, C_out, groups, y, (hipStream_t)stream);
 }
 
+extern "C" int tal_gconv_res_split_fwd(const void* x_split, const void* w_frag, const float* bias, float alpha, int B, int64_t T,
+                                       int C, int groups, void* y_split, void* stream) {
+    TAL_CHECK_ARG(C % 32 == 0, "tal_gconv_res_split_fwd: the split form needs C %% 32 == 0 (C=%d)", C);
+    return launch_gconv_res_f16x3(reinterpret_cast<const float*>(x_split), w_frag, bias, alpha, B, T, C, groups, nullptr, y_split,
+                                  (hipStream_t)stream, nullptr, true);
+}
+
+extern "C" int tal_gconv_s2_split_fwd(const void* x, int x_is_split, const void* w_frag, const float* bias, int B, int64_t T_in,
+                                      int C_in, int C_out, int groups, void* y_split, void* stream) {
+    TAL_CHECK_ARG(C_out % 32 == 0 && (!x_is_split || C_in % 32 == 0), "tal_gconv_s2_split_fwd: the split form needs channels %% 32 == 0");
+    return launch_gconv_s2_f16x3(reinterpret_cast<const float*>(x), w_frag, bias, B, T_in, C_in, C_out, groups, nullptr, (hipStream_t)stream,
+                                 nullptr, x_is_split != 0, y_split);
+}
+
 extern "C" int tal_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, void* stream) {
     return launch_argmax_rows(x, M, N, ids, (hipStream_t)stream);
 }
@@ -340,38 +354,87 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
     }
     // four rotating buffers; `ia` = index of the buffer holding the live activations (-1: caller's x).
     // No launch ever reads and writes the same buffer (workgroups read halos of their neighbours).
+    //
+    // Activation format.  Long inputs run a stage with every inter-kernel activation in the hi / lo SPLIT form of the
+    // fp16x3 dense layers (same bytes as fp32; the exact value is hi + lo * 2^-11, 22 mantissa bits): the resize conv writes
+    // it, the TDSBlock conv reads it (no conversion arithmetic in its slab phase) and writes it, fc0 reads / writes it, fc3
+    // reads it twice (operand and residual) and writes it for the next block.  No fp32 copy of an activation and no
+    // separate split pass exist inside such a stage: 7 activation-sized transfers per block instead of 10.  Short inputs,
+    // odd widths and the exact mode keep fp32 activations (the kernels below the `else`).
+    static const bool no_allsplit = getenv("TAL_TDS_NO_ALLSPLIT") != nullptr;
+    auto stage_len = [&](int i) { int64_t t = T; for (int q = 0; q <= i; ++q) t = conv_out_len(t); return t; };
+    auto s2_mfma_ok = [&](int i, int64_t Tin) {       // stride-2 resize conv of stage i on the matrix cores
+        return !force_f32 && d->down_w_frag[i] && (int64_t)B * conv_out_len(Tin) > 64 &&
+               gconv_f16x3_weight_bytes(d->channels[i], d->channels[i + 1], d->groups, 2) > 0 && gconv_f16x3_fits(Tin, d->channels[i]);
+    };
+    auto stage_allsplit = [&](int i, const float* xin, bool in_split) {
+        if (force_f32 || no_allsplit || i >= d->n_stages || d->depths[i] == 0) return false;
+        const int c = d->channels[i + 1], cin = d->channels[i];
+        const int64_t Tin = i == 0 ? T : stage_len(i - 1), To = conv_out_len(Tin), M = (int64_t)B * To;
+        if (M <= 512 || c % 160 != 0 || c % 32 != 0 || !gconv_f16x3_fits(To, c) || gconv_f16x3_weight_bytes(c, c, d->groups, 1) == 0) return false;
+        for (int j = 0; j < d->depths[i]; ++j)
+            if (!d->blocks[i][j].fc0_w_split || !d->blocks[i][j].fc3_w_split || !d->blocks[i][j].conv_w_frag) return false;
+        // the resize conv must be able to write the split form: the 1 -> 10 channel kernel or a matrix-core kernel
+        if (s2_mfma_ok(i, Tin)) return !in_split || cin % 32 == 0;
+        return !in_split && gconv_s2_can_split(cin, c, d->groups, xin);
+    };
     const float* cur = x;
+    bool cur_split = false;
     int ia = -1;
     int64_t Tc = T;
     for (int i = 0; i < d->n_stages; ++i) {
         const int cin = d->channels[i], c = d->channels[i + 1];
         const int64_t To = conv_out_len(Tc);
         const bool last_stage = i == d->n_stages - 1;
+        const int64_t M = (int64_t)B * To;
+        const bool allsplit = stage_allsplit(i, cur, cur_split);
         // resize conv: cur -> a (a buffer other than cur's)
         const int io = (ia + 1) % 4;
         float* a = (last_stage && d->depths[i] == 0) ? y : buf[io];
-        // stride-2 resize conv: on the matrix cores for long inputs when the fragments are there (10 -> 14, 14 -> 18 per group)
-        // (the matrix-core conv pays from ~a hundred output steps on: 358 steps of 18 channels per group take 13 us against 57)
-        if (!force_f32 && d->down_w_frag[i] && (int64_t)B * To > 64 && gconv_f16x3_weight_bytes(cin, c, d->groups, 2) > 0 && gconv_f16x3_fits(Tc, cin))
-            rc = launch_gconv_s2_f16x3(cur, d->down_w_frag[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s, range_flag);
-        else
-            rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s);
+        if (allsplit) {
+            if (s2_mfma_ok(i, Tc))
+                rc = launch_gconv_s2_f16x3(cur, d->down_w_frag[i], d->down_b[i], B, Tc, cin, c, d->groups, nullptr, s, range_flag, cur_split, a);
+            else
+                rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, nullptr, s, a, range_flag);
+        } else {
+            TAL_CHECK_ARG(!cur_split, "tal_tds_fwd: internal: stage %d would read a split activation through an fp32 kernel", i);
+            // stride-2 resize conv: on the matrix cores when the fragments are there (10 -> 14, 14 -> 18 per group); it pays from
+            // ~a hundred output steps on: 358 steps of 18 channels per group take 13 us against 57
+            if (s2_mfma_ok(i, Tc))
+                rc = launch_gconv_s2_f16x3(cur, d->down_w_frag[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s, range_flag);
+            else
+                rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s);
+        }
         if (rc) return rc;
         ia = io;
-        const int64_t M = (int64_t)B * To;
+        // what the next consumer of this stage's output can read: the next stage's resize conv takes the split form only if
+        // that stage runs all-split itself through a matrix-core resize conv
+        const bool next_split = !last_stage && d->channels[i + 1] % 32 == 0 && s2_mfma_ok(i + 1, To) && stage_allsplit(i + 1, nullptr, true);
         for (int j = 0; j < d->depths[i]; ++j) {
             const tal_tds_block_w& bw = d->blocks[i][j];
             TAL_CHECK_ARG(bw.conv_w && bw.conv_b && bw.fc0_w && bw.fc0_b && bw.fc3_w && bw.fc3_b, "tal_tds_fwd: null weight in block %d.%d", i, j);
             float* x1 = buf[(ia + 1) % 4];
             float* h = buf[(ia + 2) % 4];
             float* x1s = buf[(ia + 3) % 4];
-            float* outp = (last_stage && j == d->depths[i] - 1) ? y : buf[ia];
+            const bool last_block = j == d->depths[i] - 1;
+            float* outp = (last_stage && last_block) ? y : buf[ia];
+            if (allsplit) {
+                // x1 = x + rw * relu(gconv(x)): a (split) -> x1 (split); h = relu(fc0(x1)) (split); out = x1 + rw * fc3(h)
+                rc = launch_gconv_res_f16x3(a, bw.conv_w_frag, bw.conv_b, bw.resweight, B, To, c, d->groups, nullptr, x1, s, range_flag, true);
+                if (rc) return rc;
+                rc = launch_linear_f16x3(x1, bw.fc0_w_split, bw.fc0_b, nullptr, 0.f, 1, M, c, c, h, 1, skws, gemm_splitk_ws_bytes(), s, range_flag);
+                if (rc) return rc;
+                const bool out_split = !last_block || next_split;
+                rc = launch_linear_f16x3(h, bw.fc3_w_split, bw.fc3_b, x1, bw.resweight, 2, M, c, c, outp, out_split ? 1 : 0, skws,
+                                         gemm_splitk_ws_bytes(), s, range_flag, 1);
+                if (rc) return rc;
+                a = outp;
+                cur_split = out_split;
+                continue;
+            }
             const bool f16x3 = !force_f32 && bw.fc0_w_split && bw.fc3_w_split && M > 512 && c % 160 == 0;
             const bool conv_mfma = !force_f32 && M > 64 && bw.conv_w_frag && gconv_f16x3_weight_bytes(c, c, d->groups, 1) > 0 && gconv_f16x3_fits(To, c);
             // x1 = x + rw * relu(gconv(x))            : a -> x1
-            // (The matrix-core kernel can also emit x1 as the hi / lo split; measured on the 1-hour shapes that fused store
-            //  costs +0.35 / +0.21 / +0.14 ms per launch -- 8-byte pieces that fill 32-byte sectors only partially -- against
-            //  0.20 / 0.12 / 0.09 ms for the separate, fully coalesced split pass, so the driver keeps the pass.)
             static const bool fuse_split = getenv("TAL_GCONV_FUSE_SPLIT") != nullptr;
             if (conv_mfma)
                 rc = launch_gconv_res_f16x3(a, bw.conv_w_frag, bw.conv_b, bw.resweight, B, To, c, d->groups, x1, (fuse_split && f16x3) ? x1s : nullptr, s,
@@ -398,7 +461,9 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
                 if (rc) return rc;
             }
             a = outp;
+            cur_split = false;
         }
+        if (d->depths[i] == 0) cur_split = false;
         cur = a;
         Tc = To;
     }

@@ -124,6 +124,7 @@ struct GemmArgs {
     // fp32 rows (per row and 32-wide K block: 32 hi halves, then 32 lo halves scaled by 2^11); out_split: write Y in
     // the same split form (it is the next layer's A) instead of fp32.  Needs K % 32 == 0 (and N % 32 == 0 for out_split).
     int f16x3, out_split;
+    int res_split;     // mode 2: `res` is in the split form (hi / lo halves, fp32-row geometry); rebuilt as hi + lo * 2^-11
     int* range_flag;   // out_split: raised when an output value lies outside the fp16 range (may be NULL)
 };
 // mode 0: acc+b | 1: relu(acc+b) | 2: res + alpha*(acc+b) | 3: alpha*(acc+b) | 4: row arg-max partials of acc+b
@@ -141,18 +142,22 @@ size_t gemm_splitk_ws_bytes();
 int launch_split_f16x3(const float* x, void* out, int64_t rows, int K, hipStream_t s, int* range_flag = nullptr);
 // dense layer on pre-split operands (see GemmArgs::f16x3); ws as launch_linear_ws
 int launch_linear_f16x3(const void* xs, const void* wsplit, const float* b, const float* res, float alpha, int mode, int64_t M,
-                        int N, int K, void* y, int out_split, float* ws, size_t ws_bytes, hipStream_t s, int* range_flag = nullptr);
+                        int N, int K, void* y, int out_split, float* ws, size_t ws_bytes, hipStream_t s, int* range_flag = nullptr,
+                        int res_split = 0);
+// y_split != NULL: the output goes out in the hi / lo split form ONLY (first resize conv, 1 -> 10 channels per group)
 int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, int64_t T_in, int C_in, int C_out,
-                    int groups, float* y, hipStream_t s);
+                    int groups, float* y, hipStream_t s, void* y_split = nullptr, int* range_flag = nullptr);
+bool gconv_s2_can_split(int C_in, int C_out, int groups, const float* x);
 int launch_gconv_res(const float* x, const float* wp, const float* bias, float alpha, int B, int64_t T, int C,
                      int groups, float* y, hipStream_t s);
 size_t gconv_f16x3_weight_bytes(int C_in, int C_out, int groups, int stride);
 bool gconv_f16x3_fits(int64_t T, int C);
 int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C_in, int C_out, int groups, int stride, hipStream_t s);
 int launch_gconv_s2_f16x3(const float* x, const void* w_frag, const float* bias, int B, int64_t T_in, int C_in, int C_out, int groups,
-                          float* y, hipStream_t s, int* range_flag = nullptr);
+                          float* y, hipStream_t s, int* range_flag = nullptr, bool x_split = false, void* y_split = nullptr);
+// x_split: x is in the hi / lo split form; y == NULL: only the split form of the output (y_split) is written
 int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias, float alpha, int B, int64_t T, int C, int groups,
-                           float* y, void* y_split, hipStream_t s, int* range_flag = nullptr);
+                           float* y, void* y_split, hipStream_t s, int* range_flag = nullptr, bool x_split = false);
 int launch_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, hipStream_t s);
 // A-stationary speaker-logit arg-max (csrc/head.hip): partials [M, head_argmax_partials()] for argmax_partials_kernel
 bool head_argmax_applicable(int64_t M, int S, int E);

@@ -162,10 +162,12 @@ __global__ void gconv_generic_kernel(const float* __restrict__ x, const float* _
 // kernel above, a lane's 10 outputs are a 40-byte piece of a 3200-byte row: 2 TB/s.)  The mel slab of the tile sits in
 // LDS time-major ([row][groups of the workgroup]); lanes of one group read the same word (broadcast).  Four output
 // steps per iteration share their 27 input samples.  Same fmaf order as the generic kernel: bit-identical results.
-template <int COG, int NG, int TT>
+// YSPLIT: the output is written in the hi / lo split form of the fp16x3 dense layers only: lane pairs exchange halves so
+// that even lanes store two hi halves and odd lanes two lo halves (4-byte stores, 64 contiguous bytes per 32 channels).
+template <int COG, int NG, int TT, bool YSPLIT>
 __global__ __launch_bounds__(256) void gconv_s2_c1_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                          const float* __restrict__ bias, float* __restrict__ y, int64_t T_in,
-                                                         int64_t T_out, int C_in, int C_out) {
+                                                         int64_t T_out, int C_in, int C_out, int* __restrict__ range_flag) {
     constexpr int NC = NG * COG;                       // output channels of this workgroup (<= 256)
     constexpr int TIN = (TT - 1) * 2 + KS;
     static_assert(NC <= 256 && NG % 4 == 0 && TT % 4 == 0, "shape");
@@ -189,6 +191,11 @@ __global__ __launch_bounds__(256) void gconv_s2_c1_kernel(const float* __restric
     const float bv = bias[ch];
     const float* xc = xs + tid / COG;
     float* yc = y + (int64_t)b * T_out * C_out + ch;
+    // split form: row = C_out * 4 bytes; channel ch -> 32-channel block ch / 32 (128 bytes), hi half at slot ch % 32, lo 64 bytes on.
+    // This lane stores the pair (ch & ~1): the hi halves when ch is even, the lo halves when odd (ch and the lane index have
+    // the same parity: g0 * COG is even).
+    _Float16* ysp = reinterpret_cast<_Float16*>(y) + (int64_t)b * T_out * C_out * 2 + ((ch & ~1) >> 5) * 64 + ((ch & ~1) & 31) + (ch & 1) * 32;
+    float amax = 0.f;
     for (int tl = 0; tl < TT; tl += 4) {
         float xv[KS + 6];
 #pragma unroll
@@ -199,9 +206,20 @@ __global__ __launch_bounds__(256) void gconv_s2_c1_kernel(const float* __restric
 #pragma unroll
             for (int k = 0; k < KS; ++k) acc = fmaf(wk[k], xv[2 * q + k], acc);
             const int64_t t = t0 + tl + q;
-            if (t < T_out) yc[t * C_out] = acc;
+            if (YSPLIT) {
+                _Float16 hi, lo;
+                split_f16x3(acc, hi, lo);
+                amax = fmaxf(amax, fabsf(acc));
+                const unsigned short hb = __builtin_bit_cast(unsigned short, hi), lb = __builtin_bit_cast(unsigned short, lo);
+                const unsigned mine = (unsigned)hb | ((unsigned)lb << 16);
+                const unsigned other = __shfl_xor(mine, 1, 64);
+                // even lane: {hi(ch), hi(ch + 1)}; odd lane: {lo(ch - 1), lo(ch)}
+                const unsigned word = (tid & 1) ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
+                if (t < T_out) *reinterpret_cast<unsigned*>(ysp + t * C_out * 2) = word;
+            } else if (t < T_out) yc[t * C_out] = acc;
         }
     }
+    if (YSPLIT) note_range(amax, range_flag);
 }
 
 template <int CIG, int COG, int STRIDE, int GB, int TT, bool RESID>
@@ -238,9 +256,16 @@ static int launch_generic(const float* x, const float* wp, const float* bias, fl
     return TAL_OK;
 }
 
+bool gconv_s2_can_split(int C_in, int C_out, int groups, const float* x) {
+    static const bool c1_generic = getenv("TAL_GCONV_C1_GENERIC") != nullptr;
+    return groups > 0 && C_in == groups && C_out == 10 * groups && groups % 20 == 0 && C_in % 4 == 0 && C_out % 32 == 0 &&
+           (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !c1_generic;
+}
+
 int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, int64_t T_in, int C_in, int C_out,
-                    int groups, float* y, hipStream_t s) {
-    TAL_CHECK_ARG(x && wp && bias && y, "tal_gconv_s2_fwd: null pointer");
+                    int groups, float* y, hipStream_t s, void* y_split, int* range_flag) {
+    TAL_CHECK_ARG(x && wp && bias && (y || y_split), "tal_gconv_s2_fwd: null pointer");
+    TAL_CHECK_ARG(!y_split || gconv_s2_can_split(C_in, C_out, groups, x), "tal_gconv_s2_fwd: no split-output kernel for this shape");
     TAL_CHECK_ARG(groups > 0 && C_in % groups == 0 && C_out % groups == 0, "tal_gconv_s2_fwd: channels %d->%d not divisible by groups %d", C_in, C_out, groups);
     TAL_CHECK_ARG(B > 0 && T_in >= KS, "tal_gconv_s2_fwd: T_in=%lld shorter than the kernel", (long long)T_in);
     const int64_t T_out = (T_in - KS) / 2 + 1;
@@ -251,7 +276,11 @@ int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, i
         constexpr int NG = 20, TT = 256;
         dim3 grid((unsigned)cdiv(T_out, TT), (unsigned)(groups / NG), (unsigned)B);
         ProfScope prof(PROF_GCONV_S2, 2.0 * (double)B * (double)T_out * C_out * KS, s);
-        hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TT>), grid, dim3(256), 0, s, x, wp, bias, y, T_in, T_out, C_in, C_out);
+        if (y_split)
+            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TT, true>), grid, dim3(256), 0, s, x, wp, bias, reinterpret_cast<float*>(y_split), T_in,
+                               T_out, C_in, C_out, range_flag);
+        else
+            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TT, false>), grid, dim3(256), 0, s, x, wp, bias, y, T_in, T_out, C_in, C_out, range_flag);
         TAL_CHECK_LAUNCH("gconv (1 channel per group)");
         return TAL_OK;
     }
@@ -368,7 +397,10 @@ __device__ __forceinline__ f16x8 gconv_frag(const _Float16* p) {
     return *reinterpret_cast<const f16x8u*>(p);
 }
 
-template <int CIG, int COG, int STRIDE, bool RESID, int GB, int TT, bool SPLIT>
+// SPLIT: 0 = fp32 output, 1 = fp32 output + its hi / lo split, 2 = the split form only.  XSPLIT: the input is in the split
+// form (per row and 32-channel block: 32 hi halves, 32 lo halves; same bytes as fp32) -- the slab is then filled without
+// any conversion arithmetic and the TDSBlock residual is rebuilt from the slab as hi + lo * 2^-11.
+template <int CIG, int COG, int STRIDE, bool RESID, int GB, int TT, int SPLIT, bool XSPLIT = false>
 __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restrict__ x, const _Float16* __restrict__ wfrag,
                                                            const float* __restrict__ bias, float alpha, float* __restrict__ y,
                                                            _Float16* __restrict__ ysplit, int64_t T_in, int64_t T_out, int C_in,
@@ -415,6 +447,34 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
         const int voff = (int)((row0 * C_in + g0 * CIG + (active ? c4 * 4 : 0)) * 4);
         constexpr int NPASS = (TIN + RPP - 1) / RPP, UNR = NPASS > 20 ? (NPASS + 1) / 2 : NPASS;
         float amax = 0.f;      // fp16-range guard: the largest |x| this thread turns into halves
+        if constexpr (XSPLIT) {
+            // split input: channels c .. c + 3 (c % 4 == 0, so never across a 32-channel block) are 8 bytes of hi halves at
+            // block * 128 + (c % 32) * 2 of the row and 8 bytes of lo halves 64 bytes further
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const int cgl = g0 * CIG + (active ? c4 * 4 : 0);
+            const int voffs = (int)(row0 * C_in * 4) + (cgl >> 5) * 128 + (cgl & 31) * 2;
+            for (int p0 = 0; p0 < NPASS; p0 += UNR) {
+                u32x2 vh[UNR], vl[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    vh[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, voffs + (p0 + u) * RPP * C_in * 4, 0, 0);
+                    vl[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, voffs + 64 + (p0 + u) * RPP * C_in * 4, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int ti = r0 + (p0 + u) * RPP;
+                    const int row = STRIDE == 2 ? ti >> 1 : ti;
+                    const int tbase = (STRIDE == 2 && (ti & 1)) ? SL0 : 0;
+                    if (active && ti < TIN) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            *reinterpret_cast<unsigned*>(s_hi + so[q] + tbase + row * sp[q]) = vh[u][q];
+                            *reinterpret_cast<unsigned*>(s_lo + so[q] + tbase + row * sp[q]) = vl[u][q];
+                        }
+                    }
+                }
+            }
+        } else
         for (int p0 = 0; p0 < NPASS; p0 += UNR) {
             f32x4 v[UNR];
 #pragma unroll
@@ -514,15 +574,20 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
             return *reinterpret_cast<const f32x4u*>(xcol + t * C_in);
         };
         f32x4 xr[XD + 1];
-        if (RESID) {
+        if (RESID && !XSPLIT) {
 #pragma unroll
             for (int j = 0; j < XD; ++j) xr[j] = load_x(tbeg + j);
         }
+        // XSPLIT: the residual x[t][ch0 .. ch0 + 3] sits in this group's slab (row t - t0 + PADT) as hi / lo halves
+        const int rseg = (STRIDE == 1 && CIG > 16 && ch0 >= LY::nch(0)) ? 1 : 0;
+        const _Float16* rh = s_hi + gl * GS + (rseg ? SL0 + ch0 - LY::nch(0) : ch0);
+        const _Float16* rl = s_lo + gl * GS + (rseg ? SL0 + ch0 - LY::nch(0) : ch0);
+        const int rp = rseg ? P1 : P0;
         for (int tb0 = tbeg; tb0 < tend; tb0 += XD + 1) {
 #pragma unroll
             for (int j = 0; j <= XD; ++j) {
                 const int tb = tb0 + j;
-                if (RESID) xr[(j + XD) % (XD + 1)] = load_x(tb + XD < tend ? tb + XD : tb);
+                if (RESID && !XSPLIT) xr[(j + XD) % (XD + 1)] = load_x(tb + XD < tend ? tb + XD : tb);
                 f32x4 acc = bv, ax1 = {0.f, 0.f, 0.f, 0.f}, ax2 = {0.f, 0.f, 0.f, 0.f};
                 const bool more = tb + 1 < tend;
                 const int nb0 = more ? boff0 + 16 * P0 : boff0, nb1 = more ? boff1 + 16 * P1 : boff1;
@@ -552,16 +617,31 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
                 f32x4 o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = acc[i] + (ax1[i] + ax2[i]) * (1.0f / 2048.0f);
-                if (RESID) {
+                if (RESID && XSPLIT) {
+                    const int ro = (tb * 16 + col + PADT) * rp;
+                    f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (2 * q < nvalid) {
+                            const f16x2 h2 = *reinterpret_cast<const f16x2*>(rh + ro + 2 * q);
+                            const f16x2 l2 = *reinterpret_cast<const f16x2*>(rl + ro + 2 * q);
+                            xv[2 * q] = (float)h2[0] + (float)l2[0] * (1.0f / 2048.0f);
+                            xv[2 * q + 1] = (float)h2[1] + (float)l2[1] * (1.0f / 2048.0f);
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = xv[i] + alpha * fmaxf(o[i], 0.f);
+                } else if (RESID) {
                     const f32x4 xs2 = {xr[j][2], xr[j][3], 0.f, 0.f};
                     const f32x4 xv = nvalid >= 4 ? xr[j] : xs2;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] = xv[i] + alpha * fmaxf(o[i], 0.f);
                 }
                 if (t < T_out && nvalid > 0) {
-                    float* yp = yb + t * C_out + cbase;
-                    if (nvalid >= 4) *reinterpret_cast<f32x4u*>(yp) = o;
-                    else { const f32x2u q2 = {o[0], o[1]}; *reinterpret_cast<f32x2u*>(yp) = q2; }
+                    if (SPLIT != 2) {
+                        float* yp = yb + t * C_out + cbase;
+                        if (nvalid >= 4) *reinterpret_cast<f32x4u*>(yp) = o;
+                        else { const f32x2u q2 = {o[0], o[1]}; *reinterpret_cast<f32x2u*>(yp) = q2; }
+                    }
                     if (SPLIT) {
                         // the same values as hi / lo halves in the dense layers' operand geometry: per row and 32-channel
                         // block 32 hi halves, then 32 lo halves (channels cbase .. cbase + 3; cbase is even)
@@ -616,25 +696,39 @@ __global__ void pack_gconv_mfma_kernel(const float* __restrict__ src, _Float16* 
     dst[base + 64 * 8] = lo;
 }
 
+// (the split-input slab load moves 4-channel pieces that must not straddle a 32-channel block: the workgroup's first channel,
+//  g0 * CIG with g0 a multiple of GB, has to be a multiple of 4)
+template <int CIG, int GB>
+static constexpr bool g0_aligned() { return (CIG * GB) % 4 == 0; }
+
+// x_split: the input is in the split form; y == NULL with ysplit: only the split form of the output is written
 template <int CIG, int COG, int STRIDE, bool RESID, int GB, int TT>
 static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias, float alpha, float* y, void* ysplit, int B,
-                            int64_t T_in, int64_t T_out, int C_in, int C_out, int groups, hipStream_t s, int* range_flag) {
+                            int64_t T_in, int64_t T_out, int C_in, int C_out, int groups, hipStream_t s, int* range_flag,
+                            bool x_split = false) {
     using LY = GcLayout<CIG, STRIDE>;
     constexpr size_t lds = (size_t)2 * GB * (LY::slab(0, TT) + LY::slab(1, TT)) * sizeof(_Float16);
-    auto k0 = gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, false>;
-    auto k1 = gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, RESID>;     // (split output: TDSBlock conv only)
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    typedef void (*kern_t)(const float*, const _Float16*, const float*, float, float*, _Float16*, int64_t, int64_t, int, int, int*);
+    kern_t k;
+    if (x_split) k = y ? (ysplit ? (kern_t)gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, 1, true> : (kern_t)gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, 0, true>)
+                       : (kern_t)gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, 2, true>;
+    else k = y ? (ysplit ? (kern_t)gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, 1, false> : (kern_t)gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, 0, false>)
+               : (kern_t)gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, 2, false>;
+    TAL_CHECK_ARG(y || ysplit, "gconv (fp16x3): no output buffer");
+    TAL_CHECK_ARG(!ysplit || C_out % 32 == 0, "gconv (fp16x3): the split output needs C_out %% 32 == 0");
+    TAL_CHECK_ARG(!x_split || (C_in % 32 == 0 && (g0_aligned<CIG, GB>())), "gconv (fp16x3): the split input needs C_in %% 32 == 0");
+    static const void* attr_done[6] = {};          // (one slot per variant of this instantiation)
+    const int slot = (x_split ? 3 : 0) + (y ? (ysplit ? 1 : 0) : 2);
+    if (attr_done[slot] != reinterpret_cast<const void*>(k)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             set_error("gconv (fp16x3): cannot reserve %zu bytes of LDS", lds);
             return TAL_EHIP;
         }
-        attr_set = true;
+        attr_done[slot] = reinterpret_cast<const void*>(k);
     }
     dim3 grid((unsigned)cdiv(T_out, TT), (unsigned)(groups / GB), (unsigned)B);
     ProfScope prof(RESID ? PROF_GCONV_RES : PROF_GCONV_S2, 2.0 * (double)B * (double)T_out * C_out * CIG * KS, s);
-    hipLaunchKernelGGL((ysplit && RESID) ? k1 : k0, grid, dim3(256), lds, s, x, reinterpret_cast<const _Float16*>(wfrag), bias, alpha, y,
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, reinterpret_cast<const _Float16*>(wfrag), bias, alpha, y,
                        reinterpret_cast<_Float16*>(ysplit), T_in, T_out, C_in, C_out, range_flag);
     TAL_CHECK_LAUNCH("gconv (fp16x3)");
     return TAL_OK;
@@ -662,31 +756,31 @@ int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C_in, int C_ou
 }
 
 int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias, float alpha, int B, int64_t T, int C, int groups,
-                           float* y, void* y_split, hipStream_t s, int* range_flag) {
-    TAL_CHECK_ARG(x && w_frag && bias && y, "tal_gconv_res_f16x3_fwd: null pointer");
-    TAL_CHECK_ARG(x != y, "tal_gconv_res_f16x3_fwd: in-place not supported (halo reads)");
+                           float* y, void* y_split, hipStream_t s, int* range_flag, bool x_split) {
+    TAL_CHECK_ARG(x && w_frag && bias && (y || y_split), "tal_gconv_res_f16x3_fwd: null pointer");
+    TAL_CHECK_ARG((const void*)x != (const void*)y && (const void*)x != y_split, "tal_gconv_res_f16x3_fwd: in-place not supported (halo reads)");
     TAL_CHECK_ARG(gconv_f16x3_weight_bytes(C, C, groups, 1) > 0, "tal_gconv_res_f16x3_fwd: no fp16x3 kernel for C=%d groups=%d", C, groups);
     TAL_CHECK_ARG(B > 0 && T > 0, "tal_gconv_res_f16x3_fwd: bad shape");
     TAL_CHECK_ARG(!y_split || C % 32 == 0, "tal_gconv_res_f16x3_fwd: the split output needs C %% 32 == 0 (C=%d)", C);
     TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && C % 4 == 0, "tal_gconv_res_f16x3_fwd: x must be 16-byte aligned");
     TAL_CHECK_ARG(gconv_f16x3_fits(T, C), "tal_gconv_res_f16x3_fwd: one batch item must stay below 2 GiB (T=%lld, C=%d)", (long long)T, C);
     const int cg = C / groups;
-    if (cg == 10) return launch_mfma_spec<10, 10, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag);
-    if (cg == 14) return launch_mfma_spec<14, 14, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag);
-    return launch_mfma_spec<18, 18, 1, true, 2, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag);
+    if (cg == 10) return launch_mfma_spec<10, 10, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
+    if (cg == 14) return launch_mfma_spec<14, 14, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
+    return launch_mfma_spec<18, 18, 1, true, 2, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
 }
 
 int launch_gconv_s2_f16x3(const float* x, const void* w_frag, const float* bias, int B, int64_t T_in, int C_in, int C_out, int groups,
-                          float* y, hipStream_t s, int* range_flag) {
-    TAL_CHECK_ARG(x && w_frag && bias && y, "tal_gconv_s2_f16x3_fwd: null pointer");
+                          float* y, hipStream_t s, int* range_flag, bool x_split, void* y_split) {
+    TAL_CHECK_ARG(x && w_frag && bias && (y || y_split), "tal_gconv_s2_f16x3_fwd: null pointer");
     TAL_CHECK_ARG(gconv_f16x3_weight_bytes(C_in, C_out, groups, 2) > 0, "tal_gconv_s2_f16x3_fwd: no fp16x3 kernel for %d -> %d channels, groups=%d",
                   C_in, C_out, groups);
     TAL_CHECK_ARG(B > 0 && T_in >= KS, "tal_gconv_s2_f16x3_fwd: T_in=%lld shorter than the kernel", (long long)T_in);
     TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && C_in % 4 == 0, "tal_gconv_s2_f16x3_fwd: x must be 16-byte aligned");
     TAL_CHECK_ARG(gconv_f16x3_fits(T_in, C_in), "tal_gconv_s2_f16x3_fwd: one batch item must stay below 2 GiB (T=%lld, C=%d)", (long long)T_in, C_in);
     const int64_t T_out = (T_in - KS) / 2 + 1;
-    if (C_in / groups == 10) return launch_mfma_spec<10, 14, 2, false, 4, 128>(x, w_frag, bias, 0.f, y, nullptr, B, T_in, T_out, C_in, C_out, groups, s, range_flag);
-    return launch_mfma_spec<14, 18, 2, false, 2, 128>(x, w_frag, bias, 0.f, y, nullptr, B, T_in, T_out, C_in, C_out, groups, s, range_flag);
+    if (C_in / groups == 10) return launch_mfma_spec<10, 14, 2, false, 4, 128>(x, w_frag, bias, 0.f, y, y_split, B, T_in, T_out, C_in, C_out, groups, s, range_flag, x_split);
+    return launch_mfma_spec<14, 18, 2, false, 2, 128>(x, w_frag, bias, 0.f, y, y_split, B, T_in, T_out, C_in, C_out, groups, s, range_flag, x_split);
 }
 
 // reference Conv1d weight [C_out, CIG, K] -> packed [G][CIG][K][COG]

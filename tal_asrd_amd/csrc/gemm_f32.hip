@@ -155,9 +155,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                         r += 1;
                     }
                 }
+                typedef unsigned u32x2r __attribute__((ext_vector_type(2)));
+                u32x2r rh[2 * NSUB], rl[2 * NSUB];      // split residual: 4 hi halves, 4 lo halves
 #pragma unroll
                 for (int t = 0; t < 2 * NSUB; ++t) {
-                    if (MODE == 2) rv[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res[half], offr[t], 0, 0));
+                    if (MODE == 2 && g.res_split) {
+                        // the window starts on a 32-column block (n_base % 160 == 0): column cw -> block cw / 32, slot cw % 32
+                        const int cw = offb[t] >> 2;
+                        const int so = offr[t] - offb[t] + (cw >> 5) * 128 + (cw & 31) * 2;
+                        rh[t] = __builtin_amdgcn_raw_buffer_load_b64(rs_res[half], so, 0, 0);
+                        rl[t] = __builtin_amdgcn_raw_buffer_load_b64(rs_res[half], so + 64, 0, 0);
+                    } else if (MODE == 2)
+                        rv[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res[half], offr[t], 0, 0));
                     bv[t] = bias ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, offb[t], 0, 0)) : zero4;
                 }
 #pragma unroll
@@ -165,6 +174,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                     f32x4 v = *reinterpret_cast<const f32x4*>(&stage[ldsv[t]]) + bv[t];
                     if (MODE == 1) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    if (MODE == 2 && g.res_split) {
+                        const f16x4 h4 = __builtin_bit_cast(f16x4, rh[t]), l4 = __builtin_bit_cast(f16x4, rl[t]);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) rv[t][q] = (float)h4[q] + (float)l4[q] * (1.0f / 2048.0f);
                     }
                     if (MODE == 2) v = rv[t] + alpha * v;
                     if (MODE == 3 && (g.scale_cols == 0 || n_base + (offb[t] >> 2) < g.scale_cols)) v = alpha * v;
@@ -733,7 +747,13 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(const GemmArgs g
         const bool full = vec_ok && col + 3 < g.N;
         f32x4 rv = zero4, bv = zero4;
         if (full) {
-            if (MODE == 2) rv = *reinterpret_cast<const f32x4*>(g.res + row * g.ldres + col);
+            if (MODE == 2 && g.res_split) {
+                const _Float16* rr = reinterpret_cast<const _Float16*>(g.res + row * g.ldres) + (col >> 5) * 64 + (col & 31);
+                const f16x4 h4 = *reinterpret_cast<const f16x4*>(rr), l4 = *reinterpret_cast<const f16x4*>(rr + 32);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rv[q] = (float)h4[q] + (float)l4[q] * (1.0f / 2048.0f);
+            } else if (MODE == 2)
+                rv = *reinterpret_cast<const f32x4*>(g.res + row * g.ldres + col);
             if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
         }
         f32x4 v = p[0];
@@ -851,6 +871,9 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
         TAL_CHECK_ARG(!g.out_split || (g.N % 160 == 0 && g.ldy % 4 == 0), "gemm: split output needs N %% 160 == 0");
         TAL_CHECK_ARG(g.lda < (1 << 21) && g.ldw < (1 << 21), "gemm: leading dimension too large for the fp16x3 form");
     }
+    TAL_CHECK_ARG(!g.res_split || (g.f16x3 && mode == 2 && g.N % 160 == 0 && g.ldres % 32 == 0 && g.ldy < (1 << 21) && g.ldres < (1 << 21) &&
+                                  (reinterpret_cast<uintptr_t>(g.res) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.Y) & 15) == 0),
+                  "gemm: a split-form residual needs the fp16x3 form, mode 2, N %% 160 == 0");
     const bool small = g.M <= 512;
     const int bm = small ? 32 : 128, bn = small ? 128 : 160;
     g.tiles_n = (int)cdiv(g.N, bn);
@@ -967,7 +990,7 @@ int launch_split_f16x3(const float* x, void* out, int64_t rows, int K, hipStream
 }
 
 int launch_linear_f16x3(const void* xs, const void* wsplit, const float* b, const float* res, float alpha, int mode, int64_t M,
-                        int N, int K, void* y, int out_split, float* ws, size_t ws_bytes, hipStream_t s, int* range_flag) {
+                        int N, int K, void* y, int out_split, float* ws, size_t ws_bytes, hipStream_t s, int* range_flag, int res_split) {
     TAL_CHECK_ARG(xs && wsplit && y, "linear_f16x3: null pointer");
     GemmArgs g = {};
     g.A = reinterpret_cast<const float*>(xs); g.W = reinterpret_cast<const float*>(wsplit); g.bias = b; g.res = res;
@@ -981,6 +1004,7 @@ int launch_linear_f16x3(const void* xs, const void* wsplit, const float* b, cons
     g.f16x3 = 1;
     g.out_split = out_split;
     g.range_flag = range_flag;
+    g.res_split = res_split;
     return launch_gemm(g, mode, 1, s);
 }
 

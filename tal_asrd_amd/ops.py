@@ -173,6 +173,28 @@ def gconv_res_f16x3(x, w_frag, bias, alpha, groups, want_split=False):
     return (y, ys) if want_split else y
 
 
+def gconv_res_split(x_split, shape, w_frag, bias, alpha, groups):
+    """TDSBlock conv on activations in the hi / lo split form: x_split (opaque uint8 tensor, split_f16x3's format) of
+    logical shape [B, T, C] -> the split form of x + alpha * relu(gconv21(x))."""
+    lib = N.lib()
+    B, T, c = shape
+    ys = torch.empty(B * T * c * 4, dtype=torch.uint8, device=x_split.device)
+    N.check(lib.tal_gconv_res_split_fwd(N.ptr(x_split), N.ptr(w_frag), N.ptr(bias), float(alpha), B, T, c, groups, N.ptr(ys),
+                                        N.stream_handle()), "tal_gconv_res_split_fwd")
+    return ys
+
+
+def gconv_s2_split(x, shape, x_is_split, w_frag, bias, c_out, groups):
+    """Stride-2 resize conv writing the split form of its output; x is fp32 [B, T, C_in] or the split form of it."""
+    lib = N.lib()
+    B, T, c_in = shape
+    t_out = (T - 21) // 2 + 1
+    ys = torch.empty(B * t_out * c_out * 4, dtype=torch.uint8, device=x.device)
+    N.check(lib.tal_gconv_s2_split_fwd(N.ptr(x), 1 if x_is_split else 0, N.ptr(w_frag), N.ptr(bias), B, T, c_in, c_out, groups,
+                                       N.ptr(ys), N.stream_handle()), "tal_gconv_s2_split_fwd")
+    return ys
+
+
 # ------------------------------------------------------------------ TDS driver
 range_fallbacks = 0      # calls that were re-run on the exact fp32 kernels because an activation left the fp16 range
 

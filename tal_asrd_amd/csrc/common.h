@@ -81,6 +81,18 @@ __device__ __forceinline__ void note_range(float amax, int* flag) {
     if (flag && amax > 65504.f) atomicOr(flag, 1);
 }
 
+// The same split on a pair without clamps, for kernels that run under the fp16-range guard (an out-of-range value makes
+// inf / NaN halves, the status word is raised and the caller discards the call's result): packed conversions and packed
+// fp32 arithmetic, ~4 VALU instructions per pair instead of 14.
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_f16x3_pair(float a, float b, f16x2p& hi, f16x2p& lo) {
+    const f32x2p x = {a, b};
+    hi = __builtin_convertvector(x, f16x2p);
+    const f32x2p hf = __builtin_convertvector(hi, f32x2p);
+    lo = __builtin_convertvector((x - hf) * 2048.f, f16x2p);
+}
+
 // wave-uniform wave index inside the workgroup, provably uniform to the compiler
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 

@@ -645,12 +645,21 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
                     if (SPLIT) {
                         // the same values as hi / lo halves in the dense layers' operand geometry: per row and 32-channel
                         // block 32 hi halves, then 32 lo halves (channels cbase .. cbase + 3; cbase is even)
-                        _Float16 h[4], l[4];
+                        // (under the range guard: no clamps, packed conversions)
                         note_range(amax4(0.f, o), range_flag);
+                        f16x2p h01p, l01p, h23p, l23p;
+                        if (range_flag) {
+                            split_f16x3_pair(o[0], o[1], h01p, l01p);
+                            split_f16x3_pair(o[2], o[3], h23p, l23p);
+                        } else {      // unguarded call: clamped halves (a value beyond the fp16 range degrades instead of becoming inf)
+                            _Float16 hh[4], ll[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) split_f16x3(o[i], h[i], l[i]);
+                            for (int i = 0; i < 4; ++i) split_f16x3(o[i], hh[i], ll[i]);
+                            h01p = {hh[0], hh[1]}; l01p = {ll[0], ll[1]}; h23p = {hh[2], hh[3]}; l23p = {ll[2], ll[3]};
+                        }
                         _Float16* sp = ysplit + (((int64_t)b * T_out + t) * (C_out >> 5) + (cbase >> 5)) * 64 + (cbase & 31);
-                        const f16x2 h01 = {h[0], h[1]}, l01 = {l[0], l[1]}, h23 = {h[2], h[3]}, l23 = {l[2], l[3]};
+                        const f16x2 h01 = {h01p[0], h01p[1]}, l01 = {l01p[0], l01p[1]}, h23 = {h23p[0], h23p[1]}, l23 = {l23p[0], l23p[1]};
+                        _Float16 h[4] = {h01p[0], h01p[1], h23p[0], h23p[1]}, l[4] = {l01p[0], l01p[1], l23p[0], l23p[1]};
                         if (nvalid >= 4 && (cbase & 31) != 30) {
                             const f16x4u h4 = {h[0], h[1], h[2], h[3]}, l4 = {l[0], l[1], l[2], l[3]};
                             *reinterpret_cast<f16x4u*>(sp) = h4;

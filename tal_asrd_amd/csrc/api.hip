@@ -371,7 +371,7 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
         if (force_f32 || no_allsplit || i >= d->n_stages || d->depths[i] == 0) return false;
         const int c = d->channels[i + 1], cin = d->channels[i];
         const int64_t Tin = i == 0 ? T : stage_len(i - 1), To = conv_out_len(Tin), M = (int64_t)B * To;
-        if (M <= 512 || c % 160 != 0 || c % 32 != 0 || !gconv_f16x3_fits(To, c) || gconv_f16x3_weight_bytes(c, c, d->groups, 1) == 0) return false;
+        if (M <= 128 || c % 160 != 0 || c % 32 != 0 || !gconv_f16x3_fits(To, c) || gconv_f16x3_weight_bytes(c, c, d->groups, 1) == 0) return false;
         for (int j = 0; j < d->depths[i]; ++j)
             if (!d->blocks[i][j].fc0_w_split || !d->blocks[i][j].fc3_w_split || !d->blocks[i][j].conv_w_frag) return false;
         // the resize conv must be able to write the split form: the 1 -> 10 channel kernel or a matrix-core kernel
@@ -432,7 +432,7 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
                 cur_split = out_split;
                 continue;
             }
-            const bool f16x3 = !force_f32 && bw.fc0_w_split && bw.fc3_w_split && M > 512 && c % 160 == 0;
+            const bool f16x3 = !force_f32 && bw.fc0_w_split && bw.fc3_w_split && M > 128 && c % 160 == 0;
             const bool conv_mfma = !force_f32 && M > 64 && bw.conv_w_frag && gconv_f16x3_weight_bytes(c, c, d->groups, 1) > 0 && gconv_f16x3_fits(To, c);
             // x1 = x + rw * relu(gconv(x))            : a -> x1
             static const bool fuse_split = getenv("TAL_GCONV_FUSE_SPLIT") != nullptr;

@@ -867,14 +867,14 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
     if (g.M == 0) return TAL_OK;
     if (g.f16x3 || g.out_split) {
         TAL_CHECK_ARG(g.f16x3, "gemm: out_split needs the fp16x3 form");
-        TAL_CHECK_ARG(g.M > 512 && g.K % BK == 0 && mode <= 3 && nbatch == 1, "gemm: the fp16x3 form needs M > 512, K %% 32 == 0, modes 0-3");
+        TAL_CHECK_ARG(g.M > 128 && g.K % BK == 0 && mode <= 3 && nbatch == 1, "gemm: the fp16x3 form needs M > 128, K %% 32 == 0, modes 0-3");
         TAL_CHECK_ARG(!g.out_split || (g.N % 160 == 0 && g.ldy % 4 == 0), "gemm: split output needs N %% 160 == 0");
         TAL_CHECK_ARG(g.lda < (1 << 21) && g.ldw < (1 << 21), "gemm: leading dimension too large for the fp16x3 form");
     }
     TAL_CHECK_ARG(!g.res_split || (g.f16x3 && mode == 2 && g.N % 160 == 0 && g.ldres % 32 == 0 && g.ldy < (1 << 21) && g.ldres < (1 << 21) &&
                                   (reinterpret_cast<uintptr_t>(g.res) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.Y) & 15) == 0),
                   "gemm: a split-form residual needs the fp16x3 form, mode 2, N %% 160 == 0");
-    const bool small = g.M <= 512;
+    const bool small = g.M <= 512 && !g.f16x3;
     const int bm = small ? 32 : 128, bn = small ? 128 : 160;
     g.tiles_n = (int)cdiv(g.N, bn);
     const int64_t nb = cdiv(g.M, bm) * g.tiles_n;
@@ -910,7 +910,9 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
         const int64_t rem = nb % slots, full = nb - rem;
         const int nk = g.K / BK;
         int split = 0;
-        if (rem > 0 && full > 0 && nbatch == 1 && mode <= 3 && g.splitk_ws && !no_tail) {
+        // (a launch with less than a quarter of a round of tiles -- a few hundred rows -- is cut along K as a whole: its
+        //  few tiles become up to 8x as many K slices, so that most of the chip takes part)
+        if (rem > 0 && (full > 0 || 4 * rem <= slots) && nbatch == 1 && mode <= 3 && g.splitk_ws && !no_tail) {
             // cost of a candidate in rounds: the slices' own rounds + their scratch traffic (each slice
             // writes and the fix-up re-reads a 128x160 fp32 tile, ~4 TB/s) relative to one round's duration
             // (measured: 4.45 us per K step + ~14 us per tile, scripts/bench_gemm_fit.py)

@@ -276,6 +276,17 @@ class TDS(nn.Module):
             return x
         return ops.tds_forward(self._descriptor(first, last), x, self.sizes[last])
 
+    def forward_then(self, x, tail):
+        """tail(encoder output) with the fp16-range check of the encoder call read AFTER tail's kernels are enqueued (the
+        read waits for the stream: done first, it would leave the GPU idle while the host launches the heads).  If the
+        check fires, the encoder is re-run on the exact fp32 kernels and tail is applied again."""
+        N.require_cuda(x, "TDS.forward")
+        y, chk = ops.tds_forward(self._descriptor(0, len(self.sizes) - 1), x, self.sizes[-1], defer=True)
+        out = tail(y)
+        if chk.flagged():
+            out = tail(chk.rerun_exact())
+        return out
+
     def extract(self, x):
         """Feature extraction network: blocks[:extract_block_id] ([B, C, T])."""
         y = self.forward_time_major(x.permute(0, 2, 1).contiguous(), 0, self.extract_block_id)
@@ -346,10 +357,10 @@ class SDModel(nn.Module):
         """The fused form of tal/baseline/reconcile.py:76-85 (get_speaker_ids): whole-episode
         waveform [1, L] -> (feat [T', 128], ids [T'] int32[, logits]) without materialising
         the [T', 6008] logits unless asked."""
-        enc = self.encode(x_wav, None)
-        feat, logits, ids = ops.sd_head(enc["encoder_out"], self.spk_embed_proj.weight, self.spk_embed_proj.bias,
-                                        self.spk_logit_proj.weight, self.spk_logit_proj.bias,
-                                        want_logits=want_logits, want_ids=True)
+        def head(enc_out):
+            return ops.sd_head(enc_out, self.spk_embed_proj.weight, self.spk_embed_proj.bias, self.spk_logit_proj.weight,
+                               self.spk_logit_proj.bias, want_logits=want_logits, want_ids=True)
+        feat, logits, ids = self.encoder.forward_then(self.extract_features(x_wav), head)
         return (feat, ids, logits) if want_logits else (feat, ids)
 
 
@@ -430,9 +441,10 @@ class ASRModel(nn.Module):
         return self.logmelspec(x)
 
     def encode_features(self, x: torch.Tensor, audio_lens: torch.LongTensor = None):
-        x = self.encoder.forward_time_major(x)
-        spk_h = ops.linear(x, self.spk_enc_proj.weight, self.spk_enc_proj.bias) if self.use_speaker_head else None
-        x = ops.linear(x, self.decoder_proj.weight, self.decoder_proj.bias)
+        def proj(e):
+            spk = ops.linear(e, self.spk_enc_proj.weight, self.spk_enc_proj.bias) if self.use_speaker_head else None
+            return spk, ops.linear(e, self.decoder_proj.weight, self.decoder_proj.bias)
+        spk_h, x = self.encoder.forward_then(x, proj)
         mask = None if audio_lens is None else padding_mask(audio_lens, x.size(1), x.device)
         return {"speaker_out": spk_h, "encoder_out": x, "encoder_padding_mask": mask}
 

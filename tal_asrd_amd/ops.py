@@ -199,13 +199,40 @@ def gconv_s2_split(x, shape, x_is_split, w_frag, bias, c_out, groups):
 range_fallbacks = 0      # calls that were re-run on the exact fp32 kernels because an activation left the fp16 range
 
 
-def tds_forward(desc, x, c_out, check_range=True):
+class RangeCheck:
+    """Pending fp16-range check of one tal_tds_fwd call: `flagged()` reads the call's status word (a 4-byte device-to-host
+    copy, i.e. a wait for the stream), `rerun_exact()` repeats the call on the exact fp32-input kernels into the same
+    output tensor.  Deferring the read lets the caller enqueue the kernels that consume the encoder output first."""
+
+    def __init__(self, desc, x, y, ws, nws, off):
+        self.desc, self.x, self.y, self.ws, self.nws, self.off = desc, x, y, ws, nws, off
+
+    def flagged(self):
+        if self.desc.flags & N.TAL_TDS_EXACT_F32:
+            return False
+        return int(self.ws[self.off:self.off + 4].view(torch.int32)[0]) != 0
+
+    def rerun_exact(self):
+        global range_fallbacks
+        range_fallbacks += 1
+        lib = N.lib()
+        B, T, _ = self.x.shape
+        self.desc.flags |= N.TAL_TDS_EXACT_F32
+        try:
+            N.check(lib.tal_tds_fwd(C.byref(self.desc), N.ptr(self.x), B, T, N.ptr(self.y), N.ptr(self.ws), self.nws,
+                                    N.stream_handle()), "tal_tds_fwd (exact fp32 re-run)")
+        finally:
+            self.desc.flags &= ~N.TAL_TDS_EXACT_F32
+        return self.y
+
+
+def tds_forward(desc, x, c_out, check_range=True, defer=False):
     """x [B, T, C0] -> [B, T', C_last] through tal_tds_fwd (whole encoder, one C call).
 
     fp16-range guard: the long-input layers run in the fp16x3 form (fp32 values as two fp16 halves), which needs
     |activation| <= 65504.  The kernels raise a status word when a value was out of range; the call is then repeated
-    on the exact fp32-input kernels (one small device-to-host read per call; check_range=False skips it)."""
-    global range_fallbacks
+    on the exact fp32-input kernels (one small device-to-host read per call; check_range=False skips it).
+    defer=True returns (y, RangeCheck) and leaves the read to the caller (after it has enqueued the consumers of y)."""
     lib = N.lib()
     x = _f32c(x, "tds_forward")
     B, T, _ = x.shape
@@ -217,16 +244,11 @@ def tds_forward(desc, x, c_out, check_range=True):
     ws = _ws(nws, x.device)
     N.check(lib.tal_tds_fwd(C.byref(desc), N.ptr(x), B, T, N.ptr(y), N.ptr(ws), nws, N.stream_handle()),
             "tal_tds_fwd")
-    if check_range and not (desc.flags & N.TAL_TDS_EXACT_F32):
-        off = lib.tal_tds_status_offset(C.byref(desc), B, T)
-        if int(ws[off:off + 4].view(torch.int32)[0]) != 0:
-            range_fallbacks += 1
-            desc.flags |= N.TAL_TDS_EXACT_F32
-            try:
-                N.check(lib.tal_tds_fwd(C.byref(desc), N.ptr(x), B, T, N.ptr(y), N.ptr(ws), nws, N.stream_handle()),
-                        "tal_tds_fwd (exact fp32 re-run)")
-            finally:
-                desc.flags &= ~N.TAL_TDS_EXACT_F32
+    chk = RangeCheck(desc, x, y, ws, nws, lib.tal_tds_status_offset(C.byref(desc), B, T))
+    if defer:
+        return y, chk
+    if check_range and chk.flagged():
+        chk.rerun_exact()
     return y
 
 

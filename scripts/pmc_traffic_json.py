@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/r1_pmc_traffic.json from the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py:
+"""profiles/r2_pmc_traffic.json from the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py:
 call-weighted mean fabric bytes per dense-layer launch, corrected as MI355X_MICROARCH.md prescribes for gfx950
 (FETCH_SIZE x 2 for wide coalesced reads, counter unit KB; WRITE_SIZE as reported).
-usage: scripts/pmc_traffic_json.py fetch.db write.db > profiles/r1_pmc_traffic.json"""
+usage: scripts/pmc_traffic_json.py fetch.db write.db > profiles/r2_pmc_traffic.json"""
 import json
 import sqlite3
 import sys
@@ -28,4 +28,4 @@ print(json.dumps({
             "--no-cpu-baseline --steps 2 --warmup 1`; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced "
             "reads on gfx950 (Infinity-Cache hits are counted, so this is fabric traffic, an upper bound on HBM bytes); "
             "WRITE_SIZE uncorrected.  Call-weighted mean over the dense-layer launches; per-kernel values in "
-            "r1_pmc_traffic_all_kernels.txt (scripts/pmc_traffic_json.py)."}, indent=1))
+            "r2_pmc_traffic_all_kernels.txt (scripts/pmc_traffic_json.py)."}, indent=1))

@@ -1,25 +1,39 @@
 #!/bin/bash
 # One GPU job that regenerates the round's measurement artefacts (run through gpurun; copy the results from
-# gpurun_out/r1final/ into profiles/): bench lines (default + TAL_TDS_F32=1), rocprofv3 kernel stats, FETCH / WRITE
-# traffic passes, SQ counter pass.  PMC passes are separate runs with --kernel-trace only, as the pool requires.
+# gpurun_out/r2final/ into profiles/ with the r2_ prefix): bench lines of every workload, rocprofv3 kernel stats,
+# FETCH / WRITE traffic passes, SQ counter passes, decode-step and short-clip traces.  PMC passes are separate runs with
+# --kernel-trace only, as the pool requires; every profiled program is `python3 <script>` directly after `--`.
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r1final
+O=$R/gpurun_out/r2final
 mkdir -p $O
 cd $R
 python bench.py > $O/bench_1h.json 2> $O/bench_1h.err
 TAL_TDS_F32=1 python bench.py --no-cpu-baseline > $O/bench_1h_fp32.json 2> $O/bench_1h_fp32.err
+TAL_TDS_NO_ALLSPLIT=1 python bench.py --no-cpu-baseline > $O/bench_1h_fp32_activations.json 2> /dev/null
+python bench.py --workload segments --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_segments_64x5min.json 2> /dev/null
+python bench.py --workload decode --no-cpu-baseline --steps 2 --warmup 1 > $O/bench_decode_1h_episode.json 2> /dev/null
+python scripts/bench_short.py 10 30 60 300 > $O/short_clips.txt 2>&1
+python scripts/bench_greedy_step.py 1 16 32 64 128 256 > $O/decode_step.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/bench_1h_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $O/pmc_sq -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE -d $O/pmc_inst -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_inst.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/dstats -- python3 $R/scripts/bench_episode.py 300 > $O/decode_5min_under_rocprof.log 2>&1
+REPS=3 rocprofv3 --kernel-trace -d $O/gstep -- python3 $R/scripts/bench_greedy_step.py 32 > $O/gstep.log 2>&1
+REPS=3 rocprofv3 --kernel-trace -d $O/short -- python3 $R/scripts/bench_short.py 30 > $O/short.log 2>&1
 cd $R
-Q=$(find $O/pmc_sq -name "*.db" | head -1)
+Q=$(find $O/pmc_sq -name "*.db" | head -1); I=$(find $O/pmc_inst -name "*.db" | head -1)
 python scripts/pmc_sq_summary.py $Q > $O/pmc_sq_all_kernels.txt
+python scripts/pmc_generic.py $I tal > $O/pmc_inst_all_kernels.txt
 S=$(find $O/stats -name "*.db" | head -1); F=$(find $O/pmc_fetch -name "*.db" | head -1); W=$(find $O/pmc_write -name "*.db" | head -1)
-python scripts/rocpd_summary.py $S > $O/kernel_stats.txt
+python scripts/rocpd_summary.py $S > $O/bench_1h_kernel_stats.txt
 python scripts/pmc_traffic_json.py $F $W > $O/pmc_traffic.json
 (python scripts/rocpd_pmc.py $F tal::; python scripts/rocpd_pmc.py $W tal::) > $O/pmc_traffic_all_kernels.txt
-rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq
+python scripts/rocpd_summary.py $(find $O/dstats -name "*.db" | head -1) > $O/decode_5min_kernel_stats.txt
+python scripts/rocpd_sequence.py $(find $O/gstep -name "*.db" | head -1) 37 > $O/decode_step_U32_kernel_sequence.txt
+python scripts/rocpd_sequence.py $(find $O/short -name "*.db" | head -1) 70 > $O/clip_30s_kernel_sequence.txt
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_inst $O/dstats $O/gstep $O/short
 ls -la $O

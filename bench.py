@@ -352,15 +352,12 @@ def main():
         del _tmp, host
 
     # ------------------------------------------------------------------ timed region
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        drain()
+    def timed_pass(with_prof):
         sync()
         if dist is not None:
             dist.barrier()
         sync()
-        if prof:
+        if with_prof:
             lib.tal_prof_reset()
             lib.tal_prof_enable(1)
         t0 = time.perf_counter()
@@ -371,9 +368,21 @@ def main():
         if dist is not None:
             dist.barrier()
         sync()
-        elapsed = time.perf_counter() - t0
-        if prof:
+        dt = time.perf_counter() - t0
+        if with_prof:
             lib.tal_prof_enable(0)
+        return dt
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        drain()
+        # `value` comes from a pass WITHOUT the per-launch event recording; the roofline numbers from a second pass of the
+        # same K steps with it (the events cost a little host and queue time inside the region they measure)
+        elapsed = timed_pass(False)
+        if prof and args.workload != "decode":
+            elapsed_prof = timed_pass(True)
+            extra["ms_per_step_with_launch_events"] = 1e3 * elapsed_prof / args.steps
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -392,6 +401,7 @@ def main():
             "config": {"workload": workload, "frames_per_step": units_per_step, "weights": "synthetic deterministic",
                        "audio_resident_in_hbm": True},
         }
+        line.update(extra)
         if fake:
             line["data"] = "FAKE (TAL_BENCH_FAKE plumbing self-test: no GPU work, not a measurement)"
         if args.workload == "segments":

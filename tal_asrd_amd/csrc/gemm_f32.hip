@@ -188,12 +188,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                         f16x4 hi, lo;
                         amax = amax4(amax, v);
+                        if (g.range_flag) {       // guarded call: packed conversions, no clamps (an out-of-range value raises the flag)
+                            f16x2p h01, l01, h23, l23;
+                            split_f16x3_pair(v.x, v.y, h01, l01);
+                            split_f16x3_pair(v.z, v.w, h23, l23);
+                            hi = {h01[0], h01[1], h23[0], h23[1]};
+                            lo = {l01[0], l01[1], l23[0], l23[1]};
+                        } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            _Float16 h, l;
-                            split_f16x3(v[q], h, l);
-                            hi[q] = h;
-                            lo[q] = l;
+                            for (int q = 0; q < 4; ++q) {
+                                _Float16 h, l;
+                                split_f16x3(v[q], h, l);
+                                hi[q] = h;
+                                lo[q] = l;
+                            }
                         }
                         const int cw = offb[t] >> 2;                                  // column inside the window
                         const int so = offy[t] - offb[t] + (cw >> 5) * 128 + (cw & 31) * 2;   // row part + block + slot

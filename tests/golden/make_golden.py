@@ -429,7 +429,38 @@ def sec_variants(ns):
         json.dump(keys, f, indent=0)
 
 
-SECTIONS = {"variants": sec_variants, "keys": sec_keys, "unit": sec_unit, "sd": sec_sd, "asr": sec_asr,
+def sec_flow_short(ns):
+    """generate_unaligned on an episode SHORTER than the decoder window (20 s: 233 encoder frames < 357): the window
+    start is clamped to encoder_len - chunk_size < 0, so the reference's python slices wrap (system.py:347-348,480),
+    is_last_chunk is true from the first step and the loop ends at the first stall / repetition."""
+    import types
+    System = ns.system.System
+    model = _asr_model(ns)
+    tok = types.SimpleNamespace(eos_token_id=1, bos_token_id=0, pad_token_id=2)
+    L = 320000
+    audio = synth.synth_audio_batch(1, L, 555).astype(np.float16).astype(np.float32)
+    me = types.SimpleNamespace(model=model, lm=None, tokenizer=tok, args=types.SimpleNamespace(spk_weight=0.0, lm_weight=0.0))
+    margins = []
+    dec = model.decode
+
+    def spy(y_prev, e, **k):
+        lg = dec(y_prev, e, **k)
+        t2 = torch.topk(lg[0, -1], 2).values
+        margins.append(float(t2[0] - t2[1]))
+        return lg
+    model.decode = spy
+    gen, align = System.generate_unaligned(me, torch.from_numpy(audio), torch.full((1, 1), 1, dtype=torch.long),
+                                           torch.tensor([L]), max_iters=120, stall_patience=25)
+    model.decode = dec
+    print("flow_short:", gen.shape, "chunk starts", sorted({int(c[0]) for c, _ in align}), "S", align[0][1].shape,
+          "closest decisions", np.sort(np.asarray(margins))[:3])
+    save("flow_unaligned_short", audio_seed=555, audio_len=L, max_iters=120, generated=gen.numpy(),
+         chunk_start=np.asarray([int(c[0]) for c, _ in align]),
+         attn_len=np.asarray([a.shape[1] for _, a in align]),
+         attn_flat=np.concatenate([a.numpy()[0] for _, a in align]).astype(np.float32), min_margin=float(min(margins)))
+
+
+SECTIONS = {"flow_short": sec_flow_short, "variants": sec_variants, "keys": sec_keys, "unit": sec_unit, "sd": sec_sd, "asr": sec_asr,
             "decode": sec_decode, "gru": sec_gru, "flow": sec_flow,
             "transcribe": sec_transcribe, "uisrnn": sec_uisrnn}
 

@@ -82,6 +82,24 @@ def test_generate_unaligned_trajectory(asr_model):
     assert got_turns == want_turns
 
 
+def test_generate_unaligned_episode_shorter_than_the_window(asr_model):
+    """20 s episode = 233 encoder frames < the 357-frame window: the window start is clamped to a NEGATIVE value and the
+    reference's python slices wrap (tal/asr/system.py:347-348,480); windows of 233 and then 124 frames, recorded values
+    0 and -124.  Tokens, recorded window starts and the (ragged) attention rows match the reference's run."""
+    from tal_asrd_amd import synth
+    from tal_asrd_amd.system import System
+    g = golden("flow_unaligned_short")
+    L = int(g["audio_len"])
+    audio = synth.synth_audio_batch(1, L, int(g["audio_seed"])).astype(np.float16).astype(np.float32)
+    gen, align = System(asr_model).generate_unaligned(torch.from_numpy(audio).to(dev()),
+                                                      torch.ones(1, 1, dtype=torch.long, device=dev()), torch.tensor([L]),
+                                                      max_iters=int(g["max_iters"]), stall_patience=25)
+    np.testing.assert_array_equal(gen.cpu().numpy(), g["generated"])
+    np.testing.assert_array_equal(np.array([int(c[0]) for c, _ in align]), g["chunk_start"])
+    assert [a.shape[1] for _, a in align] == g["attn_len"].tolist()
+    np.testing.assert_allclose(np.concatenate([a.numpy()[0] for _, a in align]), g["attn_flat"], atol=1e-4, rtol=0)
+
+
 def test_beam_topk_kernel_matches_torch():
     from tal_asrd_amd.system import _beam_topk
     g = torch.Generator().manual_seed(11)

@@ -3,7 +3,7 @@
 // memory window).  A step is a chain of dependent launches, each far too small to fill the chip, so what counts is
 // (a) how many launches there are and (b) how long the dependent chain inside each one is.
 //
-//   skinny_gemm_kernel   Y = epilogue(X . W^T + b) for M <= 64 rows: one workgroup per 16 output columns, the four
+//   skinny_gemm_kernel   Y = epilogue(X . W^T + b) for M <= 512 rows: one workgroup per 16 output columns x 32 rows, the
 //       waves split K (one quarter each, every operand fragment a 16-byte global load issued up front, no LDS
 //       staging), `v_mfma_f32_16x16x4_f32` (fp32 in / fp32 accumulate, 32 cycles), partial tiles summed through
 //       LDS in wave order (deterministic).  N / 16 workgroups instead of N / 32 x M / 32: a 512 x 512 layer runs on
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(const SkinnyArgs g
 bool skinny_gemm_applicable(const SkinnyArgs& g) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (g.ksplit > 1 && (!g.sk_part || !g.sk_tickets || g.K % (64 * g.ksplit) != 0)) return false;
-    return g.M >= 1 && g.M <= 64 && g.N % 16 == 0 && g.K % 64 == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0 && g.ldy % 4 == 0 &&
+    return g.M >= 1 && g.M <= 512 && g.N % 16 == 0 && g.K % 64 == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0 && g.ldy % 4 == 0 &&
            al16(g.A) && al16(g.W) && al16(g.Y) && (!g.bias || al16(g.bias)) && (!g.res || (al16(g.res) && g.ldres % 4 == 0)) &&
            (!g.Yt || g.vt_begin % 16 == 0);
 }

@@ -644,7 +644,8 @@ static SkinnyArgs skinny(const float* A, int64_t lda, const float* W, const floa
 
 static bool small_layer_applicable(int B, int U, int S, int E, int H, int FF, bool have_kv_cache) {
     static const bool off = getenv("TAL_DECODE_NO_SMALL") != nullptr;
-    return !off && have_kv_cache && (int64_t)B * U <= 64 && E % 64 == 0 && FF % 64 == 0 && E % H == 0 &&
+    static const int max_rows = getenv("TAL_DECODE_SMALL_ROWS") ? atoi(getenv("TAL_DECODE_SMALL_ROWS")) : 256;   // measured: 0.36 vs 0.41 ms per step at 128 rows, even at 256, slower at 512
+    return !off && have_kv_cache && (int64_t)B * U <= max_rows && E % 64 == 0 && FF % 64 == 0 && E % H == 0 &&
            attn_small_applicable(U, S, E / H) && attn_small_applicable(U, U, E / H);
 }
 
@@ -657,6 +658,18 @@ struct DecodeScratch {
     unsigned* tickets;   // TAL_GREEDY_TICKETS words; the last one belongs to the pick
 };
 constexpr int TAL_GREEDY_TICKETS = 256;
+// floats of DecodeScratch::part for a prefix of U rows (batch 1): the key-split attention runs while its (row block, head)
+// groups fit 64 tickets, the FFN's split-K while its tiles fit the tickets 64 .. 254; the two uses never overlap in time
+static size_t decode_scratch_floats(int U, int S, int E, int H) {
+    int ua = U;
+    while (ua > 16 && attn_split_tickets(1, ua, H) > 64) ua -= 16;
+    const size_t a = attn_split_scratch_floats(1, ua, S, H, E / H);
+    int rb = (U + 31) / 32;
+    const int rb_max = (TAL_GREEDY_TICKETS - 64) / (E / 16 > 0 ? E / 16 : 1);
+    if (rb > rb_max) rb = rb_max;
+    const size_t b = (size_t)4 * (E / 16) * (rb > 0 ? rb : 1) * 512;
+    return a > b ? a : b;
+}
 
 static int decoder_layer_small(const tal_decoder_layer_w* w, const float* tgt, int B, int U, int S, int E, int H, int FF,
                                const float* tgt_mask, const uint8_t* mem_kpm, const float* ck, const float* cvt, float* out,
@@ -907,10 +920,7 @@ extern "C" size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H
     f += up64((size_t)n_layers * (size_t)U_max * S);         // attention rows: per-head last rows [L][H][S] or averaged [L][U][S]
     f += up64((size_t)n_layers * H * S);
     f += up64((size_t)(E0 > 0 ? E0 : E)) + up64((size_t)V);   // LM head intermediate, logits
-    {   // key-split attention records / split-K partial tiles (used one after the other)
-        const size_t a = attn_split_scratch_floats(1, U_max < 64 ? U_max : 64, S, H, E / H), b = (size_t)4 * (E / 16) * 2 * 512;
-        f += up64(a > b ? a : b);
-    }
+    f += up64(decode_scratch_floats(U_max, S, E, H));         // key-split attention records / split-K partial tiles
     f += up64((size_t)2 * cdiv(V, LMP_ROWS));                 // pick partials
     return f * sizeof(float);
 }
@@ -939,10 +949,7 @@ extern "C" int tal_greedy_step_fwd(const tal_greedy_ctx* c, int64_t history_star
     float* lm_t = p; p += up64((size_t)(E0 > 0 ? E0 : E));
     float* logits = p; p += up64((size_t)V);
     DecodeScratch sk = {p, c->tickets};
-    {
-        const size_t a = attn_split_scratch_floats(1, U < 64 ? U : 64, S, H, E / H), b = (size_t)4 * (E / 16) * 2 * 512;
-        p += up64(a > b ? a : b);
-    }
+    p += up64(decode_scratch_floats(U, S, E, H));
     float* pick_part = p;
     int rc = tal_embed_tokens_fwd(c->tokens + history_start, 1, U, c->emb, V, E0 > 0 ? E0 : E, E0 > 0 ? c->proj : nullptr, E, c->pe,
                                   c->max_len, h0, stream);

@@ -285,8 +285,10 @@ int tal_greedy_pick_fwd(const float* logits, int V, const float* attn_rows, int 
  * tokens[history_start : n_gen] (models.py:218-223), run the n_layers decoder layers against the cached cross-attention
  * K / V^T of the current encoder window (tal_cross_kv_fwd), the tied LM head on the last position, and the pick of
  * tal_greedy_pick_fwd; the new token is appended at tokens[n_gen].  picked_dev receives {token as int32 bits, attention
- * row [S]}.  With sync != 0 the result is also copied to picked_host (pinned host memory) and the call returns when it
- * has landed -- the one entry point of this library that waits for the stream; the loop steers on the host
+ * row [S]}.  With sync != 0 the result is also delivered to picked_host (pinned host memory) and the call returns when it
+ * has landed (sync == 1: copy command + stream wait; sync == 2: the pick kernel writes {token, row, sequence word} --
+ * 2 + S words -- straight into the pinned buffer, which must be mapped into the device's address space as
+ * hipHostMalloc memory is, and the call polls the word) -- the one entry point of this library that waits for the stream; the loop steers on the host
  * (.item() at system.py:408-411 in the reference).  Short prefixes (<= 64 tokens) run on the latency-oriented kernels
  * (8 launches per layer), longer ones on the batched-GEMM layer.  Batch 1, like the reference's loop. */
 typedef struct tal_greedy_ctx {
@@ -303,7 +305,7 @@ typedef struct tal_greedy_ctx {
     void* workspace;         /* tal_greedy_step_workspace_bytes(max prefix length, ...) */
     size_t workspace_bytes;
     float* picked_dev;       /* [1 + S] */
-    float* picked_host;      /* pinned host [1 + S], or NULL when sync == 0 */
+    float* picked_host;      /* pinned host [2 + S], or NULL when sync == 0 */
     uint32_t* tickets;       /* 256 words, ZERO before the first call (the kernels leave them zero): arrival tickets of the
                               * kernels that merge partial results in-launch (key-split cross-attention, LM head + pick);
                               * NULL: the unmerged forms (more launches).  One context per stream. */

@@ -8,6 +8,9 @@
 // because softmax rows sum to one.  The only non-GEMM kernels are the token embedding, the
 // masked row softmax (which also emits the head-averaged probabilities the decode loop
 // steers by, system.py:392-408) and small row utilities.
+#include <atomic>
+#include <chrono>
+
 #include "common.h"
 
 namespace tal {
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(256) void lm_pick_kernel(const float* __restrict__ 
                                                      const float* __restrict__ emb, int V, const float* __restrict__ attn,
                                                      int n_layers, int64_t layer_stride, int H, int64_t head_stride, int S,
                                                      float* __restrict__ partial, unsigned* __restrict__ ticket_word,
-                                                     float* __restrict__ out, int64_t* __restrict__ token_out) {
+                                                     float* __restrict__ out, int64_t* __restrict__ token_out, unsigned host_seq) {
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [E] h | [K0] t | [128] logits
     float* hs = sm;
     float* ts = sm + E;
@@ -479,6 +482,13 @@ __global__ __launch_bounds__(256) void lm_pick_kernel(const float* __restrict__ 
             out[0] = __int_as_float(bi);
             if (token_out) *token_out = bi;
         }
+    }
+    if (host_seq) {
+        // `out` is pinned host memory mapped into the device's address space: the result lands there without a copy
+        // command, and the host, which polls the sequence word behind the row, sees it without a driver wake-up
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(out + 1 + S), host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -970,14 +980,32 @@ extern "C" int tal_greedy_step_fwd(const tal_greedy_ctx* c, int64_t history_star
     // tied factorised LM head on the last position (models.py:243-246; system.py:355-361 reads only that row)
     const float* hl = cur + (size_t)(U - 1) * E;
     const int K0 = E0 > 0 ? E0 : E;
+    // sync == 2: the pick kernel writes {token, row, sequence word} straight into the pinned host buffer (1 + S + 1 words)
+    // and this call polls the word instead of queueing a copy and sleeping on the stream
+    static unsigned seq_counter = 0;
+    const bool host_direct = sync == 2 && c->tickets;
+    const unsigned seq = host_direct ? (++seq_counter ? seq_counter : ++seq_counter) : 0u;
     if (c->tickets && E % 16 == 0 && K0 % 8 == 0 && (reinterpret_cast<uintptr_t>(c->emb) & 15) == 0 &&
         (!c->proj_t || (reinterpret_cast<uintptr_t>(c->proj_t) & 15) == 0)) {
         const float* rows = small ? probs : avg + (size_t)(U - 1) * S;
         hipLaunchKernelGGL(lm_pick_kernel, dim3((unsigned)cdiv(V, LMP_ROWS)), dim3(256), (size_t)(E + K0 + LMP_ROWS) * sizeof(float), s, hl,
                            E0 > 0 ? c->proj_t : nullptr, E, K0, c->emb, V, rows, L, small ? (int64_t)H * S : (int64_t)U * S,
                            small ? H : 1, small ? (int64_t)S : (int64_t)0, S, pick_part, c->tickets + (TAL_GREEDY_TICKETS - 1),
-                           c->picked_dev, c->tokens + n_gen);
+                           host_direct ? c->picked_host : c->picked_dev, c->tokens + n_gen, host_direct ? seq : 0u);
         TAL_CHECK_LAUNCH("tal_greedy_step_fwd(lm head + pick)");
+        if (host_direct) {
+            // poll the sequence word (bounded: a lost launch must not hang the caller)
+            volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(c->picked_host + 1 + S);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0; *flag != seq; ++spins) {
+                if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                    set_error("tal_greedy_step_fwd: no result after 20 s (stream error: %s)", hipGetErrorString(hipStreamQuery(s)));
+                    return TAL_EHIP;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return TAL_OK;
+        }
     } else {
     if (E0 > 0) {
         rc = tal_lm_head_fwd(hl, 1, E, E, c->proj_t, E0, c->emb, V, logits, lm_t, (size_t)E0 * sizeof(float), stream);

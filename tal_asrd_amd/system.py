@@ -78,6 +78,8 @@ class _GreedySession:
         self.S = -1
         self.ws = None
         self._ctx_ref = C.byref(self.ctx)
+        import os
+        self._sync_mode = 1 if os.environ.get("TAL_GREEDY_COPY_SYNC") else 2    # 2: result written straight to pinned memory, polled
         self.set_tokens(gen_dev)
 
     def set_tokens(self, gen_dev):
@@ -101,13 +103,13 @@ class _GreedySession:
             self.ws = ops._ws(nws, self.dev)
             c.workspace, c.workspace_bytes = self.ws.data_ptr(), nws
             self.picked_dev = torch.empty(1 + S, dtype=torch.float32, device=self.dev)
-            self.picked_host = torch.empty(1 + S, dtype=torch.float32).pin_memory()
-            self.picked_np = self.picked_host.numpy()
+            self.picked_host = torch.zeros(2 + S, dtype=torch.float32).pin_memory()    # {token, row [S], sequence word}
+            self.picked_np = self.picked_host.numpy()[:1 + S]
             c.picked_dev, c.picked_host = self.picked_dev.data_ptr(), self.picked_host.data_ptr()
 
     def step(self, history_start, n_gen):
         """-> (token, attention row [S] float32 copy); the token is also appended at gen_dev[n_gen] on the device."""
-        rc = self.lib.tal_greedy_step_fwd(self._ctx_ref, history_start, n_gen, 1, self._stream)
+        rc = self.lib.tal_greedy_step_fwd(self._ctx_ref, history_start, n_gen, self._sync_mode, self._stream)
         if rc:
             N.check(rc, "tal_greedy_step_fwd")
         return int(self.picked_np[:1].view(np.int32)[0]), self.picked_np[1:].copy()

@@ -16,10 +16,14 @@
  *     encode_features returns, so the reference's two permutes
  *     (tal/asr/models.py:167,170) disappear;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it,
- *     nothing synchronises, nothing allocates;
+ *     nothing allocates and nothing synchronises -- except tal_logmel_plan_init
+ *     (one-time), tal_prof_collect and tal_greedy_step_fwd with sync != 0, which
+ *     returns the token the host loop steers by;
  *   - return value: 0 (TAL_OK) or a negative TAL_E* code; no C++ exception
  *     crosses the boundary; tal_last_error() gives a thread-local message;
- *   - re-entrant per stream; no global mutable state besides the error string.
+ *   - re-entrant per stream; no global mutable state besides the error string
+ *     and the tal_prof_* measurement hooks (a process-wide switch for
+ *     single-stream benchmarking, off by default).
  */
 #ifndef TAL_ASRD_H
 #define TAL_ASRD_H

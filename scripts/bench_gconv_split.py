@@ -50,4 +50,5 @@ for T, cin, cout in ((179991, 10, 14), (89986, 14, 18)):
     e2 = float((unsplit(ys2, To, G * cout) - y.view(To, -1)).abs().max())
     t0 = timeit(lambda: ops.gconv_s2_f16x3(x, wf, b, G * cout, G))
     t2 = timeit(lambda: ops.gconv_s2_split(xs, (1, T, G * cin), True, wf, b, G * cout, G))
-    print("gconv_s2 %d->%d T=%d: fp32->fp32 %.3f ms | split->split %.3f | err split-in %.2e fp32-in %.2e" % (cin, cout, T, t0, t2, e1, e2), flush=True)
+    t3 = timeit(lambda: ops.gconv_s2_split(x, (1, T, G * cin), False, wf, b, G * cout, G))
+    print("gconv_s2 %d->%d T=%d: fp32->fp32 %.3f ms | split->split %.3f | fp32->split %.3f | err split-in %.2e fp32-in %.2e" % (cin, cout, T, t0, t2, t3, e1, e2), flush=True)

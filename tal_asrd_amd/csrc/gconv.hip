@@ -338,6 +338,12 @@ int launch_gconv_res(const float* x, const float* wp, const float* bias, float a
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef _Float16 f16x8u __attribute__((ext_vector_type(8), aligned(4)));
+typedef _Float16 f16x8a8 __attribute__((ext_vector_type(8), aligned(8)));
+// slab row pitch (halves) of a 10-channel group: 10 = compact (20-byte rows: every fragment read is 4-byte aligned and half
+// of the LDS cycles are bank conflicts), 12 = 24-byte rows (8-byte aligned reads, one more K chunk of 32)
+#ifndef GC_P10
+#define GC_P10 12
+#endif
 typedef _Float16 f16x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
@@ -345,7 +351,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int CIG, int STRIDE>
 struct GcLayout {
     static constexpr int NSEG = (STRIDE == 2 || CIG > 16) ? 2 : 1;
-    static constexpr int pitch(int s) { return STRIDE == 2 ? 16 : (CIG > 16 ? (s == 0 ? 16 : 8) : (CIG == 10 ? 10 : 16)); }
+    static constexpr int pitch(int s) { return STRIDE == 2 ? 16 : (CIG > 16 ? (s == 0 ? 16 : 8) : (CIG == 10 ? GC_P10 : 16)); }
     static constexpr int ntap(int s) { return STRIDE == 2 ? (s == 0 ? (KS + 1) / 2 : KS / 2) : KS; }
     static constexpr int nch(int s) { return CIG > 16 ? (s == 0 ? 16 : CIG - 16) : CIG; }
     static constexpr int choff(int s) { return (CIG > 16 && s == 1) ? 16 : 0; }
@@ -394,6 +400,7 @@ static bool gconv_mfma_desc(int cig, int cog, int stride, int groups, GcPackDesc
 template <int P>
 __device__ __forceinline__ f16x8 gconv_frag(const _Float16* p) {
     if (P % 8 == 0) return *reinterpret_cast<const f16x8*>(p);
+    if (P % 4 == 0) return *reinterpret_cast<const f16x8a8*>(p);
     return *reinterpret_cast<const f16x8u*>(p);
 }
 

@@ -416,6 +416,13 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
     constexpr int NKS = LY::NKS, NK0 = LY::nk(0), MT = (COG + 15) / 16;
     constexpr int P0 = LY::pitch(0), P1 = LY::pitch(1);
     constexpr int PADT = RESID ? KS / 2 : 0;
+    // STAGED: the output tile goes through LDS and leaves as 16-byte (8-byte) pieces.  Rows below (tb + 1) * 16 of a group's
+    // slab are dead once block tb has its operands, so the block's output halves are written over them (channels 0-15 into
+    // the row of segment 0, 16-17 into the row of segment 1); with one wave per group that needs no synchronisation, with two
+    // (MT == 2) one workgroup barrier per block.  Why: a store instruction costs by the 128-byte lines it touches, not by
+    // its bytes -- the direct path (lane = time step) pays 16 lines per instruction, 4-6 instructions per block.
+    constexpr bool STAGED = SPLIT == 2 && GB * MT == 4 && (GB * COG) % 4 == 0 && P0 % 4 == 0 && P0 >= (COG < 16 ? 4 * ((COG + 3) / 4) : 16) &&
+                            (MT == 1 || (MT == 2 && LY::NSEG == 2 && P1 >= 4));
     constexpr int TIN = (TT - 1) * STRIDE + KS;                     // input rows a tile of TT outputs reads
     constexpr int SL0 = LY::slab(0, TT), SL1 = LY::slab(1, TT), GS = SL0 + SL1;   // halves per group and (hi | lo) array
     constexpr int CH = GB * CIG, CH4 = CH / 4;
@@ -590,6 +597,11 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
         const _Float16* rh = s_hi + gl * GS + (rseg ? SL0 + ch0 - LY::nch(0) : ch0);
         const _Float16* rl = s_lo + gl * GS + (rseg ? SL0 + ch0 - LY::nch(0) : ch0);
         const int rp = rseg ? P1 : P0;
+        constexpr int r01 = 0;
+        const int r23 = nvalid >= 4 ? 2 : 0;   // (a lane without valid channels reads initialised slab bytes it never uses)
+        // rows of this tile that exist, seen from this lane: block tb holds one iff 16 tb < rows_left
+        const int rows_left = (int)(T_out - t0 < (int64_t)TT ? T_out - t0 : (int64_t)TT) - col;
+        float am = 0.f;        // fp16-range guard: the largest |y| this lane stores in the split form
         for (int tb0 = tbeg; tb0 < tend; tb0 += XD + 1) {
 #pragma unroll
             for (int j = 0; j <= XD; ++j) {
@@ -620,55 +632,89 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
                 c0h = bh[NKS % 3]; c0l = bl[NKS % 3]; c1h = bh[(NKS + 1) % 3]; c1l = bl[(NKS + 1) % 3];
                 boff0 = nb0;
                 boff1 = nb1;
-                const int64_t t = t0 + tb * 16 + col;
-                f32x4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = acc[i] + (ax1[i] + ax2[i]) * (1.0f / 2048.0f);
+                // ---- epilogue (every vector instruction here is time taken from the matrix pipe: kept to ~40) ----
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 s11 = {1.0f / 2048.0f, 1.0f / 2048.0f}, z0 = {0.f, 0.f}, al2 = {alpha, alpha};
+                f32x2 oa = {acc[0], acc[1]}, ob = {acc[2], acc[3]};
+                {
+                    const f32x2 xa = {ax1[0] + ax2[0], ax1[1] + ax2[1]}, xb2 = {ax1[2] + ax2[2], ax1[3] + ax2[3]};
+                    oa = xa * s11 + oa;
+                    ob = xb2 * s11 + ob;
+                }
+#ifdef GC_ABL_NOSTORE      // ablation build (scripts/build_ablation.sh): everything but the epilogue + stores
+                if (oa[0] != 12345.678f) continue;
+#endif
                 if (RESID && XSPLIT) {
+                    // branch-free: every lane reads two channel pairs (a lane with fewer valid channels re-reads valid
+                    // ones, r01 / r23 below), so its unused results stay ordinary finite activations
                     const int ro = (tb * 16 + col + PADT) * rp;
-                    f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        if (2 * q < nvalid) {
-                            const f16x2 h2 = *reinterpret_cast<const f16x2*>(rh + ro + 2 * q);
-                            const f16x2 l2 = *reinterpret_cast<const f16x2*>(rl + ro + 2 * q);
-                            xv[2 * q] = (float)h2[0] + (float)l2[0] * (1.0f / 2048.0f);
-                            xv[2 * q + 1] = (float)h2[1] + (float)l2[1] * (1.0f / 2048.0f);
-                        }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = xv[i] + alpha * fmaxf(o[i], 0.f);
+                    const f16x2 h01 = *reinterpret_cast<const f16x2*>(rh + ro + r01), l01 = *reinterpret_cast<const f16x2*>(rl + ro + r01);
+                    const f16x2 h23 = *reinterpret_cast<const f16x2*>(rh + ro + r23), l23 = *reinterpret_cast<const f16x2*>(rl + ro + r23);
+                    const f32x2 xa = __builtin_convertvector(l01, f32x2) * s11 + __builtin_convertvector(h01, f32x2);
+                    const f32x2 xb2 = __builtin_convertvector(l23, f32x2) * s11 + __builtin_convertvector(h23, f32x2);
+                    oa = al2 * __builtin_elementwise_max(oa, z0) + xa;
+                    ob = al2 * __builtin_elementwise_max(ob, z0) + xb2;
                 } else if (RESID) {
                     const f32x4 xs2 = {xr[j][2], xr[j][3], 0.f, 0.f};
                     const f32x4 xv = nvalid >= 4 ? xr[j] : xs2;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = xv[i] + alpha * fmaxf(o[i], 0.f);
+                    const f32x2 xa = {xv[0], xv[1]}, xb2 = {xv[2], xv[3]};
+                    oa = al2 * __builtin_elementwise_max(oa, z0) + xa;
+                    ob = al2 * __builtin_elementwise_max(ob, z0) + xb2;
                 }
-                if (t < T_out && nvalid > 0) {
+                if constexpr (STAGED) {
+                    if constexpr (MT > 1) __syncthreads();     // the partner wave has read its operands of this block
+                    if (nvalid > 0) {
+                        float am2 = __builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(oa[0]), __builtin_fabsf(oa[1])));
+                        if (nvalid >= 4) am2 = __builtin_fmaxf(am2, __builtin_fmaxf(__builtin_fabsf(ob[0]), __builtin_fabsf(ob[1])));
+                        am = tb * 16 < rows_left ? am2 : am;       // (rows past the end of the sequence are never stored)
+                        f16x2p h01p, l01p, h23p, l23p;
+                        if (range_flag) {
+                            split_f16x3_pair(oa[0], oa[1], h01p, l01p);
+                            split_f16x3_pair(ob[0], ob[1], h23p, l23p);
+                        } else {
+                            _Float16 hh[4], ll[4];
+                            split_f16x3(oa[0], hh[0], ll[0]); split_f16x3(oa[1], hh[1], ll[1]);
+                            split_f16x3(ob[0], hh[2], ll[2]); split_f16x3(ob[1], hh[3], ll[3]);
+                            h01p = {hh[0], hh[1]}; l01p = {ll[0], ll[1]}; h23p = {hh[2], hh[3]}; l23p = {ll[2], ll[3]};
+                        }
+                        typedef _Float16 f16x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+                        const int so2 = gl * GS + (mt == 0 ? (tb * 16 + col) * P0 + 4 * kg : SL0 + (tb * 16 + col) * P1 + 4 * kg);
+                        *reinterpret_cast<f16x4a8*>(s_hi + so2) = f16x4a8{h01p[0], h01p[1], h23p[0], h23p[1]};
+                        *reinterpret_cast<f16x4a8*>(s_lo + so2) = f16x4a8{l01p[0], l01p[1], l23p[0], l23p[1]};
+                    }
+                } else
+                if (tb * 16 < rows_left && nvalid > 0) {
+                    const int64_t t = t0 + tb * 16 + col;
                     if (SPLIT != 2) {
                         float* yp = yb + t * C_out + cbase;
+                        const f32x4 o = {oa[0], oa[1], ob[0], ob[1]};
                         if (nvalid >= 4) *reinterpret_cast<f32x4u*>(yp) = o;
-                        else { const f32x2u q2 = {o[0], o[1]}; *reinterpret_cast<f32x2u*>(yp) = q2; }
+                        else *reinterpret_cast<f32x2u*>(yp) = f32x2u{oa[0], oa[1]};
                     }
                     if (SPLIT) {
                         // the same values as hi / lo halves in the dense layers' operand geometry: per row and 32-channel
                         // block 32 hi halves, then 32 lo halves (channels cbase .. cbase + 3; cbase is even)
                         // (under the range guard: no clamps, packed conversions)
-                        note_range(amax4(0.f, o), range_flag);
+                        am = __builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(oa[0]), __builtin_fabsf(oa[1])));
+                        if (nvalid >= 4) am = __builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(ob[0]), __builtin_fabsf(ob[1])));
                         f16x2p h01p, l01p, h23p, l23p;
                         if (range_flag) {
-                            split_f16x3_pair(o[0], o[1], h01p, l01p);
-                            split_f16x3_pair(o[2], o[3], h23p, l23p);
+                            split_f16x3_pair(oa[0], oa[1], h01p, l01p);
+                            split_f16x3_pair(ob[0], ob[1], h23p, l23p);
                         } else {      // unguarded call: clamped halves (a value beyond the fp16 range degrades instead of becoming inf)
                             _Float16 hh[4], ll[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) split_f16x3(o[i], hh[i], ll[i]);
+                            split_f16x3(oa[0], hh[0], ll[0]); split_f16x3(oa[1], hh[1], ll[1]);
+                            split_f16x3(ob[0], hh[2], ll[2]); split_f16x3(ob[1], hh[3], ll[3]);
                             h01p = {hh[0], hh[1]}; l01p = {ll[0], ll[1]}; h23p = {hh[2], hh[3]}; l23p = {ll[2], ll[3]};
                         }
                         _Float16* sp = ysplit + (((int64_t)b * T_out + t) * (C_out >> 5) + (cbase >> 5)) * 64 + (cbase & 31);
                         const f16x2 h01 = {h01p[0], h01p[1]}, l01 = {l01p[0], l01p[1]}, h23 = {h23p[0], h23p[1]}, l23 = {l23p[0], l23p[1]};
-                        _Float16 h[4] = {h01p[0], h01p[1], h23p[0], h23p[1]}, l[4] = {l01p[0], l01p[1], l23p[0], l23p[1]};
+#ifdef GC_ABL_ONE_STORE    // ablation build: the whole epilogue, ONE store instruction (wrong results; what do the others cost?)
+                        const f16x4u h4 = {h01[0] + l01[0], h01[1] + l01[1], h23[0] + l23[0], h23[1] + l23[1]};
+                        *reinterpret_cast<f16x4u*>(ysplit + (((int64_t)b * T_out + t) * (C_out >> 5)) * 64 + 4 * kg) = h4;
+#else
                         if (nvalid >= 4 && (cbase & 31) != 30) {
-                            const f16x4u h4 = {h[0], h[1], h[2], h[3]}, l4 = {l[0], l[1], l[2], l[3]};
+                            const f16x4u h4 = {h01[0], h01[1], h23[0], h23[1]}, l4 = {l01[0], l01[1], l23[0], l23[1]};
                             *reinterpret_cast<f16x4u*>(sp) = h4;
                             *reinterpret_cast<f16x4u*>(sp + 32) = l4;
                         } else {
@@ -679,8 +725,50 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
                                 *reinterpret_cast<f16x2*>(sp + 66) = l23;
                             }
                         }
+#endif
                     }
                 }
+            }
+        }
+        if (SPLIT) note_range(am, range_flag);
+    }
+    if constexpr (STAGED) {
+        // ---- the tile leaves LDS as pieces of PW words (8 channels from a multiple of 8, or 4 from a multiple of 4 -- g0 * COG
+        // is one -- so a piece never crosses a 32-channel block).  thread = (row inside a pass, piece): the lanes of a store
+        // instruction walk along rows, a row's pieces sit in its 2-3 consecutive 128-byte lines (one row per lane, 64 lines per
+        // instruction, made this phase 23-36 % of the kernel) ----
+        __syncthreads();
+        constexpr int CW = GB * COG, PW = CW % 8 == 0 ? 4 : 2, NPC = CW / (2 * PW), WPG = COG / 2, NPR = 2 * NPC;
+        constexpr int RP = 256 / NPR, NPO = (TT + RP - 1) / RP;
+        typedef unsigned u32xp __attribute__((ext_vector_type(PW)));
+        int nrows = (int)(T_out - t0 < (int64_t)TT ? T_out - t0 : (int64_t)TT);
+#ifdef GC_ABL_NOTAIL       // ablation build: the staged epilogue without its store phase
+        if (alpha != 12345.678f) nrows = 0;
+#endif
+        const int r = tid / NPR, q = tid - r * NPR;
+        const int a = q / NPC, p = q - a * NPC;          // a: 0 = hi halves, 1 = lo halves
+        int wo[PW], wp[PW];                              // per word of the piece: LDS offset (halves) in row 0, row pitch
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const int idx = PW * p + j, gl = idx / WPG, i = idx - gl * WPG;
+            wp[j] = i < 8 ? P0 : P1;
+            wo[j] = (a * GB + gl) * GS + (i < 8 ? 2 * i : SL0 + 2 * (i - 8)) + r * wp[j];
+        }
+        const int c = g0 * COG + 2 * PW * p;
+        char* op = reinterpret_cast<char*>(ysplit) + ((int64_t)b * T_out + t0 + r) * C_out * 4 + (c >> 5) * 128 + (c & 31) * 2 + a * 64;
+        const int64_t pstep = (int64_t)RP * C_out * 4;
+        if (r < RP) {
+            constexpr int CHK = 4;
+            for (int p0 = 0; p0 < NPO; p0 += CHK) {
+                u32xp v[CHK];
+#pragma unroll
+                for (int u = 0; u < CHK; ++u)
+#pragma unroll
+                    for (int j = 0; j < PW; ++j)
+                        v[u][j] = *reinterpret_cast<const unsigned*>(slab + wo[j] + (p0 + u) * RP * wp[j]);
+#pragma unroll
+                for (int u = 0; u < CHK; ++u)
+                    if ((p0 + u) * RP + r < nrows) *reinterpret_cast<u32xp*>(op + (p0 + u) * pstep) = v[u];
             }
         }
     }

@@ -102,6 +102,12 @@ int tal_split_f16x3_fwd(const float* x, void* out, int64_t rows, int K, void* st
 int tal_linear_f16x3_fwd(const void* x_split, const void* w_split, const float* b, const float* res, float alpha,
                          int mode, int64_t M, int N, int K, void* y, int out_split, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* The same layer as tal_tds_fwd runs it inside a TDS block: under the fp16-range guard (range_flag: device int, OR-ed
+ * with 1 when a value turned into halves lies outside the fp16 range; may be NULL) and, for mode 2, optionally with the
+ * residual in the split form (res_split != 0: res points to split data, N % 160 == 0). */
+int tal_linear_f16x3_guarded_fwd(const void* x_split, const void* w_split, const float* b, const void* res, int res_split,
+                                 float alpha, int mode, int64_t M, int N, int K, void* y, int out_split,
+                                 int* range_flag, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Grouped temporal convolutions of the TDS encoder.

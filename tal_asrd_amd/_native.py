@@ -63,6 +63,7 @@ SIGNATURES = {
     "tal_split_f16x3_fwd": (_i, [_p, _p, _i64, _i, _p]),
     "tal_linear_f16x3_fwd": (_i, [_p, _p, _p, _p, _f, _i, _i64, _i, _i, _p, _i, _p, _sz, _p]),
     "tal_linear_ws_fwd": (_i, [_p, _p, _p, _p, _f, _i, _i64, _i, _i, _p, _p, _sz, _p]),
+    "tal_linear_f16x3_guarded_fwd": (_i, [_p, _p, _p, _p, _i, _f, _i, _i64, _i, _i, _p, _i, _p, _p, _sz, _p]),
     "tal_pack_gconv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "tal_gconv_s2_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _p, _p]),
     "tal_gconv_res_fwd": (_i, [_p, _p, _p, _f, _i, _i64, _i, _i, _p, _p]),

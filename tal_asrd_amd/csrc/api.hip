@@ -482,6 +482,16 @@ extern "C" int tal_linear_f16x3_fwd(const void* x_split, const void* w_split, co
                                (hipStream_t)stream);
 }
 
+// the same layer under the fp16-range guard of tal_tds_fwd (range_flag: a device int that is OR-ed with 1 when a value
+// turned into halves lies outside the fp16 range) and, for mode 2, with the residual in the split form too
+extern "C" int tal_linear_f16x3_guarded_fwd(const void* x_split, const void* w_split, const float* b, const void* res, int res_split,
+                                            float alpha, int mode, int64_t M, int N, int K, void* y, int out_split,
+                                            int* range_flag, void* workspace, size_t workspace_bytes, void* stream) {
+    TAL_CHECK_ARG(workspace || workspace_bytes == 0, "tal_linear_f16x3_guarded_fwd: null workspace with %zu bytes", workspace_bytes);
+    return launch_linear_f16x3(x_split, w_split, b, reinterpret_cast<const float*>(res), alpha, mode, M, N, K, y, out_split,
+                               (float*)workspace, workspace_bytes, (hipStream_t)stream, range_flag, res_split);
+}
+
 // ---------------------------------------------------------------------------------------
 // Diarization head
 // ---------------------------------------------------------------------------------------

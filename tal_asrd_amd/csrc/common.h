@@ -121,6 +121,7 @@ struct GemmArgs {
     float alpha;
     int scale_cols;  // mode 3: alpha applies to columns < scale_cols only (0 = all; must be a multiple of 4)
     int tiles_n;  // filled by launch_gemm
+    unsigned tiles_n_magic;   // 2^32 / tiles_n + 1: tile / tiles_n == umulhi(tile, magic) for tile * tiles_n < 2^32 (launch_gemm)
     // mode 4 (row arg-max instead of a store): per row and per 32*NSUB-column wave slice the best
     // (value, column) goes to part_val / part_idx [M, part_ld]; Y is not written.
     float* part_val;

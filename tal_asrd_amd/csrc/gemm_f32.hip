@@ -264,6 +264,94 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
     }
 }
 
+// The TDS block's two hot epilogues (EPI = 1): relu -> split form (MODE 1) and split-form residual + alpha * v -> split form
+// (MODE 2), both under the range guard; the bias is already in the accumulators (gemm_glds_kernel starts them from it).
+// On a gfx950 SIMD the vector ALU and the matrix pipe do not overlap, and all tiles of a launch reach their epilogue
+// together (same K), so every vector instruction of a tile is exposed time.  The generic epilogue spends ~50 of them per
+// 16-byte output piece on address arithmetic and run-time flags (per wave and tile ~1000, against 1350 MFMAs at K = 1440;
+// 10-15 us of fixed cost per round of tiles, scripts/bench_gemm_f16x3_fit.py).  Here a store iteration is (rg, b) = (8-row
+// group, 32-column block): lane -> row rg * 8 + lane / 8, columns b * 32 + (lane % 8) * 4, so every address is one lane
+// constant + an immediate -- no vector arithmetic left but the conversions themselves (7-8 us per round for MODE 1, the
+// same as a plain fp32 store).  Rows past M are outside the buffer descriptors (loads return 0, stores are dropped).
+template <int MODE, int NSUB>
+__device__ __forceinline__ void gemm_epilogue_split(const GemmArgs& g, const f32x16 (&acc)[NSUB], float* lds, float* Y,
+                                                    const float* res, int64_t m0, int n0, int lane, int w) {
+    static_assert(MODE == 1 || MODE == 2, "relu or residual");
+    constexpr int CW = 32 * NSUB;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int64_t M = g.M;
+    const int colb = lane & 31, rowb = 4 * (lane >> 5);
+    float* stage = lds + w * (16 * CW);
+    auto uptr = [](const float* p) {
+        const uint64_t v = reinterpret_cast<uint64_t>(p);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    };
+    const int lr = lane >> 3, lp = lane & 7;
+    const int ldy4 = (int)g.ldy * 4, ldr4 = (int)g.ldres * 4;
+    // lane offsets of the two 8-row groups: row part + this lane's 8-byte slot inside a 64-byte hi (lo) run
+    const int vy0 = lr * ldy4 + lp * 8, vy1 = vy0 + 8 * ldy4;
+    const int vr0 = lr * ldr4 + lp * 8, vr1 = vr0 + 8 * ldr4;
+    const float* sp = stage + lr * CW + lp * 4;
+    const float alpha = g.alpha;
+    const f32x2 al2 = {alpha, alpha}, s11 = {1.0f / 2048.0f, 1.0f / 2048.0f};
+    float amax = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int64_t row0 = m0 + w * 32 + half * 16;
+        const int rows_valid = (int)(M - row0 < 0 ? 0 : (M - row0 > 16 ? 16 : M - row0));
+        const int ext_y = rows_valid > 0 ? (rows_valid - 1) * ldy4 + CW * 4 : 0;
+        const int ext_r = rows_valid > 0 && MODE == 2 ? (rows_valid - 1) * ldr4 + CW * 4 : 0;
+        __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(uptr(Y + row0 * g.ldy + n0), 0, __builtin_amdgcn_readfirstlane(ext_y), 0x00020000);
+        __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(uptr(MODE == 2 ? res + row0 * g.ldres + n0 : Y), 0,
+                                                                      __builtin_amdgcn_readfirstlane(ext_r), 0x00020000);
+        u32x2 rh[2 * NSUB], rl[2 * NSUB];
+        if (MODE == 2) {
+#pragma unroll
+            for (int t = 0; t < 2 * NSUB; ++t) {
+                const int rg = t / NSUB, b = t % NSUB;
+                rh[t] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, (rg ? vr1 : vr0) + b * 128, 0, 0);
+                rl[t] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, (rg ? vr1 : vr0) + b * 128 + 64, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+                const int r = rowb + (e8 & 3) + 8 * (e8 >> 2);
+                stage[r * CW + j * 32 + colb] = acc[j][half * 8 + e8];
+            }
+        f32x4 sv[2 * NSUB];
+#pragma unroll
+        for (int t = 0; t < 2 * NSUB; ++t) sv[t] = *reinterpret_cast<const f32x4*>(sp + (t / NSUB) * 8 * CW + (t % NSUB) * 32);
+#pragma unroll
+        for (int t = 0; t < 2 * NSUB; ++t) {
+            const int rg = t / NSUB, b = t % NSUB;
+            f32x2 va = {sv[t][0], sv[t][1]}, vb = {sv[t][2], sv[t][3]};
+            if (MODE == 1) {
+                va = __builtin_elementwise_max(va, f32x2{0.f, 0.f});
+                vb = __builtin_elementwise_max(vb, f32x2{0.f, 0.f});
+            } else {
+                const f16x4 h4 = __builtin_bit_cast(f16x4, rh[t]), l4 = __builtin_bit_cast(f16x4, rl[t]);
+                const f32x2 ha = {(float)h4[0], (float)h4[1]}, hb = {(float)h4[2], (float)h4[3]};
+                const f32x2 la = {(float)l4[0], (float)l4[1]}, lb = {(float)l4[2], (float)l4[3]};
+                va = al2 * va + (la * s11 + ha);
+                vb = al2 * vb + (lb * s11 + hb);
+            }
+            amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(va[0]), __builtin_fabsf(va[1])));
+            amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(vb[0]), __builtin_fabsf(vb[1])));
+            f16x2p h01, l01, h23, l23;
+            split_f16x3_pair(va[0], va[1], h01, l01);
+            split_f16x3_pair(vb[0], vb[1], h23, l23);
+            const f16x4 hi = {h01[0], h01[1], h23[0], h23[1]}, lo = {l01[0], l01[1], l23[0], l23[1]};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rs_y, (rg ? vy1 : vy0) + b * 128, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rs_y, (rg ? vy1 : vy0) + b * 128 + 64, 0, 0);
+        }
+    }
+    note_range(amax, g.range_flag);
+}
+
 // XCD-aware bijective remap: XCD x (= blockIdx % 8) walks a contiguous range of logical tiles,
 // N-tiles of one M-tile first, so the A panel is re-read from that XCD's L2.
 __device__ __forceinline__ unsigned logical_tile_of(unsigned nb, unsigned bid) {
@@ -276,7 +364,7 @@ __device__ __forceinline__ unsigned logical_tile() { return logical_tile_of(grid
 // hot kernel: direct-to-LDS operand loads, double buffer, one barrier per K step
 // ---------------------------------------------------------------------------------------------
 // (the fp16x3 form carries two accumulator sets: it is held to 256 registers = 2 workgroups per CU explicitly)
-template <int MODE, int NSUB, bool SPLITK, int STAGE, bool F16X3 = false>
+template <int MODE, int NSUB, bool SPLITK, int STAGE, bool F16X3 = false, int EPI = 0>
 __global__ __launch_bounds__(256, F16X3 ? 2 : 1) void gemm_glds_kernel(const GemmArgs g) {
     // Set-up and epilogue are short VALU / memory sequences; the co-resident workgroup is usually deep in
     // its MFMA loop, and at equal priority every one of these instructions queues behind a 64-cycle MFMA.
@@ -295,11 +383,13 @@ __global__ __launch_bounds__(256, F16X3 ? 2 : 1) void gemm_glds_kernel(const Gem
     const int slice = is_slice ? (int)(sbid / (unsigned)g.tail_tiles) : 0;
     const unsigned logical = is_slice ? (unsigned)g.tile_base + sbid % (unsigned)g.tail_tiles
                                       : (SPLITK ? logical_tile_of((unsigned)g.tile_base, blockIdx.x) : logical_tile());
-    const int64_t m0 = (int64_t)(logical / (unsigned)g.tiles_n) * BM;
-    const int n0 = (int)(logical % (unsigned)g.tiles_n) * BN;
+    // (tile row by a multiply-high with the launch's magic number: a run-time division is ~40 vector instructions)
+    const unsigned tile_m = g.tiles_n == 1 ? logical : __umulhi(logical, g.tiles_n_magic);
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = (int)(logical - tile_m * (unsigned)g.tiles_n) * BN;
     const int64_t M = g.M;
     const int N = g.N, K = g.K;
-    const int z1 = (int)blockIdx.y / g.nb2, z2 = (int)blockIdx.y % g.nb2;
+    const int z1 = EPI ? 0 : (int)blockIdx.y / g.nb2, z2 = EPI ? 0 : (int)blockIdx.y % g.nb2;    // (EPI: never batched)
     const float* A = g.A + z1 * g.a_s1 + z2 * g.a_s2;
     const float* W = g.W + z1 * g.w_s1 + z2 * g.w_s2;
     float* Y = g.Y + z1 * g.y_s1 + z2 * g.y_s2;
@@ -369,9 +459,13 @@ __global__ __launch_bounds__(256, F16X3 ? 2 : 1) void gemm_glds_kernel(const Gem
     f32x16 acc[NSUB];
     f32x16 accx[F16X3 ? NSUB : 1];     // fp16x3: the cross terms hi*lo + lo*hi (scaled by 2^11)
 #pragma unroll
-    for (int j = 0; j < NSUB; ++j)
+    for (int j = 0; j < NSUB; ++j) {
+        // EPI: the accumulators start from the bias (all 16 elements of acc[j] belong to column n0 + 32 j + lane % 32);
+        // a K slice starts from zero, its bias is added by the fix-up kernel
+        const float b0 = (EPI && bias && !is_slice) ? bias[n0 + j * 32 + (lane & 31)] : 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[j][e] = b0;
+    }
 #pragma unroll
     for (int j = 0; j < (F16X3 ? NSUB : 1); ++j)
 #pragma unroll
@@ -386,6 +480,7 @@ __global__ __launch_bounds__(256, F16X3 ? 2 : 1) void gemm_glds_kernel(const Gem
     const int nk = is_slice ? (int)((int64_t)(slice + 1) * nk_all / g.split) : nk_all;
     issue(kt0, kt0 & 1);
     __builtin_amdgcn_s_setprio(0);
+    __builtin_assume(kt0 < nk);       // (K >= 32: without this the accumulators are initialised twice, 160 moves)
     for (int kt = kt0; kt < nk; ++kt) {
         // tile kt has landed (vmcnt(0) is part of the barrier while LDS-DMA is in flight) and every
         // wave is done reading the other buffer (it finished step kt-1 before arriving here)
@@ -453,10 +548,17 @@ __global__ __launch_bounds__(256, F16X3 ? 2 : 1) void gemm_glds_kernel(const Gem
     __syncthreads();  // all waves done with the operand buffers before they become the store stage
     __builtin_amdgcn_s_setprio(3);
     if (F16X3) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 s11 = {1.0f / 2048.0f, 1.0f / 2048.0f};
 #pragma unroll
         for (int j = 0; j < NSUB; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][e] = fmaf(accx[F16X3 ? j : 0][e], 1.0f / 2048.0f, acc[j][e]);
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 x2 = {accx[F16X3 ? j : 0][e], accx[F16X3 ? j : 0][e + 1]}, a2 = {acc[j][e], acc[j][e + 1]};
+                const f32x2 o2 = __builtin_elementwise_fma(x2, s11, a2);
+                acc[j][e] = o2[0];
+                acc[j][e + 1] = o2[1];
+            }
     }
     if (is_slice) {
         // raw accumulators of this K slice -> scratch tile [(tile, slice)][128][BN]; the fix-up kernel
@@ -469,7 +571,8 @@ __global__ __launch_bounds__(256, F16X3 ? 2 : 1) void gemm_glds_kernel(const Gem
         float* tile_ws = g.splitk_ws + ((size_t)(logical - g.tile_base) * g.split + slice) * (BM * BN);
         gemm_epilogue<0, NSUB>(gp, acc, lds, tile_ws - (m0 * BN + n0), nullptr, nullptr, m0, n0, lane, w, wm, wn);
     } else {
-        gemm_epilogue<MODE, NSUB>(g, acc, lds, Y, bias, res, m0, n0, lane, w, wm, wn);
+        if constexpr (EPI != 0) gemm_epilogue_split<MODE, NSUB>(g, acc, lds, Y, res, m0, n0, lane, w);
+        else gemm_epilogue<MODE, NSUB>(g, acc, lds, Y, bias, res, m0, n0, lane, w, wm, wn);
     }
 }
 
@@ -832,6 +935,15 @@ static void launch_glds_stage(const GemmArgs& g, dim3 grid, hipStream_t s) {
     // the buffer form of the operand loads (default) needs the tile's lane offsets to fit 32 bits
     static const int want = getenv("TAL_GEMM_STAGE") ? atoi(getenv("TAL_GEMM_STAGE")) : 2;
     if (g.f16x3) {
+        if constexpr (MODE == 1 || MODE == 2) {
+            // the TDS block's layers: split-form output under the range guard (MODE 2: split-form residual too)
+            const bool y_ok = g.ldy % 4 == 0 && g.ldy < (1 << 21) && (reinterpret_cast<uintptr_t>(g.Y) & 15) == 0 && g.N % (32 * NSUB) == 0;
+            const bool r_ok = MODE != 2 || (g.res_split && g.ldres % 4 == 0 && g.ldres < (1 << 21) && (reinterpret_cast<uintptr_t>(g.res) & 15) == 0);
+            if (g.out_split && g.range_flag && y_ok && r_ok && grid.y == 1) {
+                hipLaunchKernelGGL((gemm_glds_kernel<MODE, NSUB, SPLITK, 2, true, 1>), grid, dim3(256), 0, s, g);
+                return;
+            }
+        }
         if constexpr (MODE <= 3) hipLaunchKernelGGL((gemm_glds_kernel<MODE, NSUB, SPLITK, 2, true>), grid, dim3(256), 0, s, g);
         return;
     }
@@ -885,8 +997,9 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
     const bool small = g.M <= 512 && !g.f16x3;
     const int bm = small ? 32 : 128, bn = small ? 128 : 160;
     g.tiles_n = (int)cdiv(g.N, bn);
+    g.tiles_n_magic = g.tiles_n > 1 ? (unsigned)((1ull << 32) / (unsigned)g.tiles_n) + 1u : 0u;
     const int64_t nb = cdiv(g.M, bm) * g.tiles_n;
-    TAL_CHECK_ARG(nb < (1ll << 31), "gemm: grid too large");
+    TAL_CHECK_ARG(nb < (1ll << 31) && nb * g.tiles_n < (1ll << 32), "gemm: grid too large");
     dim3 grid((unsigned)nb, (unsigned)nbatch);
     ProfScope prof(PROF_GEMM, 2.0 * (double)g.M * (double)g.N * (double)g.K * nbatch, s);
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) == 0;

@@ -19,6 +19,8 @@ Everything here works on any torch.distributed backend: "nccl" (= RCCL) on the G
 import torch
 import torch.distributed as dist
 
+from . import tiling
+
 
 def shard_indices(n_items: int, rank: int, world: int, weights=None):
     """Indices of the items `rank` processes.
@@ -116,3 +118,21 @@ def gather_segments(local: dict, n_items: int, dst: int = 0, like=None):
         result[i] = out[r][cursor[r]: cursor[r] + n]
         cursor[r] += n
     return result
+
+
+def encode_clip_sharded(encoder, mel: torch.Tensor, out_tile: int, dst: int = 0, batch: int = 8):
+    """ONE clip over all ranks ("single hour-long clip across GPUs"): every rank holds the clip's
+    log-mel [1, T, C] (0.9 ms per hour of audio: not worth sharding, and its mean needs the whole clip anyway), encodes
+    the tiles `rank::world` of tiling.plan_tiles with their [-640, +780]-frame halo, and rank `dst` receives the
+    stitched encoder output [1, T', C'] (None elsewhere).  No collective but the final gather."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    plan = tiling.plan_tiles(int(mel.shape[1]), out_tile, tuple(encoder.depths))
+    if not plan:
+        return torch.zeros(1, 0, encoder.sizes[-1], dtype=torch.float32, device=mel.device) if rank == dst else None
+    mine = tiling.shard_tiles(plan, rank, world)
+    done = tiling.encode_tiles(encoder, mel, mine, batch)
+    local = {plan.index(t): y.contiguous() for t, y in done.items()}
+    like = torch.empty(0, encoder.sizes[-1], dtype=torch.float32, device=mel.device)
+    parts = gather_segments(local, len(plan), dst=dst, like=like)
+    return torch.cat(parts, dim=0)[None] if parts is not None else None

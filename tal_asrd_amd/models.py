@@ -27,6 +27,7 @@ import torch.nn as nn
 
 from . import _native as N
 from . import ops
+from . import tiling
 from .modules import PositionalEncoding, weight_init
 
 DEFAULT_SR = 16000  # tal/asr/data/__init__.py:6
@@ -181,6 +182,8 @@ class TDS(nn.Module):
         self.extract_block_id = 1
         self.sizes = sizes
         self.depths = list(depths)
+        self.max_item_frames = tiling.max_item_frames()     # longer single items are encoded tile by tile
+        self.tile_frames = 32768                            # output frames per tile then (4.4 min of audio)
         self.input_size = input_size
         self.blocks = nn.Sequential(*[
             nn.Sequential(
@@ -269,11 +272,18 @@ class TDS(nn.Module):
         self._descs[(first, last)] = d
         return d
 
+    def _needs_tiles(self, x, first, last):
+        """One item longer than the kernels' 2 GiB-per-item limit (~3.7 h of audio): the whole stack runs tile by tile with
+        the receptive-field halo (tiling.py) instead of falling back to the slow generic kernels."""
+        return first == 0 and last == len(self.sizes) - 1 and x.shape[0] == 1 and x.shape[1] > self.max_item_frames
+
     def forward_time_major(self, x, first=0, last=None):
         N.require_cuda(x, "TDS.forward")
         last = len(self.sizes) - 1 if last is None else last
         if first == last:
             return x
+        if self._needs_tiles(x, first, last):
+            return tiling.encode_tiled(self, x, self.tile_frames)
         return ops.tds_forward(self._descriptor(first, last), x, self.sizes[last])
 
     def forward_then(self, x, tail):
@@ -281,6 +291,8 @@ class TDS(nn.Module):
         read waits for the stream: done first, it would leave the GPU idle while the host launches the heads).  If the
         check fires, the encoder is re-run on the exact fp32 kernels and tail is applied again."""
         N.require_cuda(x, "TDS.forward")
+        if self._needs_tiles(x, 0, len(self.sizes) - 1):
+            return tail(self.forward_time_major(x))
         y, chk = ops.tds_forward(self._descriptor(0, len(self.sizes) - 1), x, self.sizes[-1], defer=True)
         out = tail(y)
         if chk.flagged():

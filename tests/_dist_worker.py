@@ -61,6 +61,29 @@ def main():
     mean = D.allreduce_logmel_stats(stats)
     assert abs(float(mean) - float(full.mean())) < 1e-6
 
+    # 5) one clip over both ranks: tiles with their halo through a stand-in encoder (the oracle's TDS on CPU), stitched on
+    #    rank 0, equal to the whole-clip result
+    from oracle import tal_oracle as O
+    from tests.test_oracle_golden import _fill, _tds_shapes
+
+    class OracleEncoder:
+        sizes, depths = [8, 16, 24, 32], [1, 1, 2]
+
+        def __init__(self):
+            self.sd = _fill(_tds_shapes(self.sizes, self.depths, 8), "tds_small.")
+
+        def forward_time_major(self, x):
+            return O.tds_forward(x.permute(0, 2, 1), self.sd, prefix="", depths=tuple(self.depths), groups=8).permute(0, 2, 1).contiguous()
+
+    enc = OracleEncoder()
+    mel = torch.randn(1, 2100, 8, generator=torch.Generator().manual_seed(9))
+    got = D.encode_clip_sharded(enc, mel, out_tile=48, dst=0)
+    if rank == 0:
+        want = enc.forward_time_major(mel)
+        assert got.shape == want.shape and float((got - want).abs().max()) < 5e-6
+    else:
+        assert got is None
+
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d ok" % rank)

@@ -273,14 +273,21 @@ int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, i
     static const bool c1_generic = getenv("TAL_GCONV_C1_GENERIC") != nullptr;
     if (cig == 1 && cog == 10 && groups % 20 == 0 && C_in % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !c1_generic) {
         // channel-major lanes: coalesced 256-byte stores (0.29 -> 0.16 ms on the 1-hour shape)
-        constexpr int NG = 20, TT = 256;
-        dim3 grid((unsigned)cdiv(T_out, TT), (unsigned)(groups / NG), (unsigned)B);
+        constexpr int NG = 20, TT = 256, TTS = 32;
         ProfScope prof(PROF_GCONV_S2, 2.0 * (double)B * (double)T_out * C_out * KS, s);
-        if (y_split)
-            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TT, true>), grid, dim3(256), 0, s, x, wp, bias, reinterpret_cast<float*>(y_split), T_in,
-                               T_out, C_in, C_out, range_flag);
+        // a lane walks its tile's time steps one after the other: short inputs (a 30-second clip is 6 tiles of 256 steps x 4
+        // group blocks = 24 workgroups, 42 us) take 32-step tiles so that the launch covers the chip
+        const bool small = cdiv(T_out, TT) * (groups / NG) * B < 256;
+        dim3 grid((unsigned)cdiv(T_out, small ? TTS : TT), (unsigned)(groups / NG), (unsigned)B);
+        float* yo = y_split ? reinterpret_cast<float*>(y_split) : y;
+        if (y_split && small)
+            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TTS, true>), grid, dim3(256), 0, s, x, wp, bias, yo, T_in, T_out, C_in, C_out, range_flag);
+        else if (y_split)
+            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TT, true>), grid, dim3(256), 0, s, x, wp, bias, yo, T_in, T_out, C_in, C_out, range_flag);
+        else if (small)
+            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TTS, false>), grid, dim3(256), 0, s, x, wp, bias, yo, T_in, T_out, C_in, C_out, range_flag);
         else
-            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TT, false>), grid, dim3(256), 0, s, x, wp, bias, y, T_in, T_out, C_in, C_out, range_flag);
+            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TT, false>), grid, dim3(256), 0, s, x, wp, bias, yo, T_in, T_out, C_in, C_out, range_flag);
         TAL_CHECK_LAUNCH("gconv (1 channel per group)");
         return TAL_OK;
     }

@@ -116,6 +116,53 @@ def test_gconv_f16x3_random_shapes():
         np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), atol=3e-5, rtol=1e-5, err_msg=str((cig, cog, T, B)))
 
 
+def _unsplit(buf, rows, C):
+    """hi / lo split form (per row and 32-channel block: 32 hi halves, 32 lo halves) -> float64 [rows, C]"""
+    h = buf.view(torch.float16).view(rows, C // 32, 2, 32).double()
+    return (h[:, :, 0] + h[:, :, 1] / 2048.0).reshape(rows, C)
+
+
+def test_gconv_split_form_random_shapes():
+    """the grouped convs on activations that live in the hi / lo split form (input and output; the output tile is staged
+    through the dead rows of the LDS slab and leaves along rows): odd time axes around the 16-step blocks and the 256- /
+    128-step tiles, two batch items, every channel width."""
+    from tal_asrd_amd import ops
+    rng = np.random.default_rng(41)
+    G = 80
+    for _ in range(12):
+        cg = int(rng.choice([10, 14, 18]))
+        T = int(rng.choice([1, 15, 16, 17, 255, 256, 257, 271, 300, 513, 777, 1031]))
+        B = int(rng.integers(1, 3))
+        C = G * cg
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn(B, T, C, generator=g) * 3.0
+        w = torch.randn(C, cg, 21, generator=g) / (21 * cg) ** 0.5
+        b = torch.randn(C, generator=g)
+        xs = ops.split_f16x3(x.reshape(B * T, C).to(dev()))
+        xq = _unsplit(xs, B * T, C).reshape(B, T, C).cpu()          # what the kernel sees: x to 22 mantissa bits
+        ref = xq + 0.4 * torch.relu(torch.nn.functional.conv1d(xq.permute(0, 2, 1), w.double(), b.double(), padding=10, groups=G)).permute(0, 2, 1)
+        wf = ops.pack_gconv_f16x3_weight(w.to(dev()), G)
+        ys = ops.gconv_res_split(xs, (B, T, C), wf, b.to(dev()), 0.4, G)
+        got = _unsplit(ys, B * T, C).reshape(B, T, C).cpu()
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=3e-5, rtol=1e-5, err_msg=str((cg, T, B)))
+    for _ in range(10):
+        cig, cog = [(10, 14), (14, 18)][int(rng.integers(0, 2))]
+        T = int(rng.choice([21, 22, 23, 53, 275, 276, 277, 300, 511, 531, 1000]))
+        B = int(rng.integers(1, 3))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn(B, T, G * cig, generator=g) * 3.0
+        w = torch.randn(G * cog, cig, 21, generator=g) / (21 * cig) ** 0.5
+        b = torch.randn(G * cog, generator=g)
+        xs = ops.split_f16x3(x.reshape(B * T, G * cig).to(dev()))
+        xq = _unsplit(xs, B * T, G * cig).reshape(B, T, G * cig).cpu()
+        ref = torch.nn.functional.conv1d(xq.permute(0, 2, 1), w.double(), b.double(), stride=2, groups=G).permute(0, 2, 1)
+        T_out = ref.shape[1]
+        wf = ops.pack_gconv_f16x3_weight(w.to(dev()), G, stride=2)
+        ys = ops.gconv_s2_split(xs, (B, T, G * cig), True, wf, b.to(dev()), G * cog, G)
+        got = _unsplit(ys, B * T_out, G * cog).reshape(B, T_out, G * cog).cpu()
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=3e-5, rtol=1e-5, err_msg=str((cig, cog, T, B)))
+
+
 def test_first_resize_conv_channel_major():
     """the 1 -> 10 channels-per-group conv (channel-major lanes, coalesced stores) against float64, incl. the shortest input."""
     from tal_asrd_amd import ops

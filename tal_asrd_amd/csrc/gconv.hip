@@ -351,17 +351,29 @@ typedef _Float16 f16x8a8 __attribute__((ext_vector_type(8), aligned(8)));
 #ifndef GC_P10
 #define GC_P10 12
 #endif
+#ifndef GC_P18
+#define GC_P18 20
+#endif
+// workgroups per CU the register budget is held to (ablation: GC_LB18 = 3 for the 18-channel stride-1 kernels)
+#ifndef GC_LB18
+#define GC_LB18 2
+#endif
+#define GC_LB(CIG, STRIDE) (((CIG) > 16 && (STRIDE) == 1) ? GC_LB18 : 2)
 typedef _Float16 f16x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // K-segment layout (host + device, compile time)
 template <int CIG, int STRIDE>
 struct GcLayout {
-    static constexpr int NSEG = (STRIDE == 2 || CIG > 16) ? 2 : 1;
-    static constexpr int pitch(int s) { return STRIDE == 2 ? 16 : (CIG > 16 ? (s == 0 ? 16 : 8) : (CIG == 10 ? GC_P10 : 16)); }
+    // 18 channels per group, stride 1: one segment of 40-byte rows (GC_P18 = 20: 14 K chunks, 8-byte aligned fragment reads;
+    // -10 % on the kernel alone, -0.5 % on the 1-hour step) or, with GC_P18 = 0, two K segments (16 channels at pitch 16 + 2 at
+    // pitch 8: 17 K chunks, every fragment one aligned 16-byte read -- round 1's form; a 48-byte pitch lost 37 % to bank conflicts)
+    static constexpr bool SPLIT18 = CIG > 16 && STRIDE == 1 && GC_P18 == 0;
+    static constexpr int NSEG = (STRIDE == 2 || SPLIT18) ? 2 : 1;
+    static constexpr int pitch(int s) { return STRIDE == 2 ? 16 : (SPLIT18 ? (s == 0 ? 16 : 8) : (CIG > 16 ? GC_P18 : (CIG == 10 ? GC_P10 : 16))); }
     static constexpr int ntap(int s) { return STRIDE == 2 ? (s == 0 ? (KS + 1) / 2 : KS / 2) : KS; }
-    static constexpr int nch(int s) { return CIG > 16 ? (s == 0 ? 16 : CIG - 16) : CIG; }
-    static constexpr int choff(int s) { return (CIG > 16 && s == 1) ? 16 : 0; }
+    static constexpr int nch(int s) { return SPLIT18 ? (s == 0 ? 16 : CIG - 16) : CIG; }
+    static constexpr int choff(int s) { return (SPLIT18 && s == 1) ? 16 : 0; }
     static constexpr int tap0(int s) { return STRIDE == 2 ? s : 0; }
     static constexpr int nk(int s) { return s < NSEG ? ((ntap(s) - 1) * pitch(s) + nch(s) + 31) / 32 : 0; }
     static constexpr int NKS = nk(0) + nk(1);
@@ -415,7 +427,7 @@ __device__ __forceinline__ f16x8 gconv_frag(const _Float16* p) {
 // form (per row and 32-channel block: 32 hi halves, 32 lo halves; same bytes as fp32) -- the slab is then filled without
 // any conversion arithmetic and the TDSBlock residual is rebuilt from the slab as hi + lo * 2^-11.
 template <int CIG, int COG, int STRIDE, bool RESID, int GB, int TT, int SPLIT, bool XSPLIT = false>
-__global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restrict__ x, const _Float16* __restrict__ wfrag,
+__global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(const float* __restrict__ x, const _Float16* __restrict__ wfrag,
                                                            const float* __restrict__ bias, float alpha, float* __restrict__ y,
                                                            _Float16* __restrict__ ysplit, int64_t T_in, int64_t T_out, int C_in,
                                                            int C_out, int* __restrict__ range_flag) {
@@ -429,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
     // (MT == 2) one workgroup barrier per block.  Why: a store instruction costs by the 128-byte lines it touches, not by
     // its bytes -- the direct path (lane = time step) pays 16 lines per instruction, 4-6 instructions per block.
     constexpr bool STAGED = SPLIT == 2 && GB * MT == 4 && (GB * COG) % 4 == 0 && P0 % 4 == 0 && P0 >= (COG < 16 ? 4 * ((COG + 3) / 4) : 16) &&
-                            (MT == 1 || (MT == 2 && LY::NSEG == 2 && P1 >= 4));
+                            (MT == 1 || (MT == 2 && ((LY::NSEG == 2 && P1 >= 4) || (LY::NSEG == 1 && P0 >= 4 * ((COG + 3) / 4)))));
     constexpr int TIN = (TT - 1) * STRIDE + KS;                     // input rows a tile of TT outputs reads
     constexpr int SL0 = LY::slab(0, TT), SL1 = LY::slab(1, TT), GS = SL0 + SL1;   // halves per group and (hi | lo) array
     constexpr int CH = GB * CIG, CH4 = CH / 4;
@@ -600,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
             for (int j = 0; j < XD; ++j) xr[j] = load_x(tbeg + j);
         }
         // XSPLIT: the residual x[t][ch0 .. ch0 + 3] sits in this group's slab (row t - t0 + PADT) as hi / lo halves
-        const int rseg = (STRIDE == 1 && CIG > 16 && ch0 >= LY::nch(0)) ? 1 : 0;
+        const int rseg = (STRIDE == 1 && LY::NSEG == 2 && ch0 >= LY::nch(0)) ? 1 : 0;
         const _Float16* rh = s_hi + gl * GS + (rseg ? SL0 + ch0 - LY::nch(0) : ch0);
         const _Float16* rl = s_lo + gl * GS + (rseg ? SL0 + ch0 - LY::nch(0) : ch0);
         const int rp = rseg ? P1 : P0;
@@ -685,7 +697,7 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
                             h01p = {hh[0], hh[1]}; l01p = {ll[0], ll[1]}; h23p = {hh[2], hh[3]}; l23p = {ll[2], ll[3]};
                         }
                         typedef _Float16 f16x4a8 __attribute__((ext_vector_type(4), aligned(8)));
-                        const int so2 = gl * GS + (mt == 0 ? (tb * 16 + col) * P0 + 4 * kg : SL0 + (tb * 16 + col) * P1 + 4 * kg);
+                        const int so2 = gl * GS + ((mt == 0 || LY::NSEG == 1) ? (tb * 16 + col) * P0 + mt * 16 + 4 * kg : SL0 + (tb * 16 + col) * P1 + 4 * kg);
                         *reinterpret_cast<f16x4a8*>(s_hi + so2) = f16x4a8{h01p[0], h01p[1], h23p[0], h23p[1]};
                         *reinterpret_cast<f16x4a8*>(s_lo + so2) = f16x4a8{l01p[0], l01p[1], l23p[0], l23p[1]};
                     }
@@ -758,8 +770,9 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
             const int idx = PW * p + j, gl = idx / WPG, i = idx - gl * WPG;
-            wp[j] = i < 8 ? P0 : P1;
-            wo[j] = (a * GB + gl) * GS + (i < 8 ? 2 * i : SL0 + 2 * (i - 8)) + r * wp[j];
+            const bool first = i < 8 || (LY::NSEG == 1);      // channels 16, 17 of a two-segment slab sit in segment 1
+            wp[j] = first ? P0 : P1;
+            wo[j] = (a * GB + gl) * GS + (first ? 2 * i : SL0 + 2 * (i - 8)) + r * wp[j];
         }
         const int c = g0 * COG + 2 * PW * p;
         char* op = reinterpret_cast<char*>(ysplit) + ((int64_t)b * T_out + t0 + r) * C_out * 4 + (c >> 5) * 128 + (c & 31) * 2 + a * 64;

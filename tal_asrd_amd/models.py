@@ -182,7 +182,7 @@ class TDS(nn.Module):
         self.extract_block_id = 1
         self.sizes = sizes
         self.depths = list(depths)
-        self.max_item_frames = tiling.max_item_frames()     # longer single items are encoded tile by tile
+        self.max_item_frames = tiling.max_item_frames(list(sizes))     # longer single items are encoded tile by tile
         self.tile_frames = 32768                            # output frames per tile then (4.4 min of audio)
         self.input_size = input_size
         self.blocks = nn.Sequential(*[

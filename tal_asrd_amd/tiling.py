@@ -65,10 +65,15 @@ def plan_tiles(T: int, out_tile: int, depths: Sequence[int] = (2, 3, 6)) -> List
     return tiles
 
 
-def max_item_frames(c_max: int = 1440) -> int:
-    """Mel frames one call may carry before a stage's activation ([T / 2, 800] floats is the largest) passes the 2 GiB
-    per-item limit of the fp16x3 kernels' 32-bit buffer offsets."""
-    return ((1 << 31) // (4 * 800) - 64) * 2
+def max_item_frames(sizes: Sequence[int] = (80, 800, 1120, 1440)) -> int:
+    """Input frames one call may carry before some stage's activation ([T / 2^s, sizes[s]] floats) passes the 2 GiB per-item
+    limit of the fp16x3 kernels' 32-bit buffer offsets (the 2x model: stage 1, [T / 2, 800] -> ~3.7 h of audio)."""
+    limit = None
+    for s, c in enumerate(sizes):
+        rows = (1 << 31) // (4 * int(c)) - 64           # rows of this stage that fit, with a margin for the conv halo
+        frames = rows << s
+        limit = frames if limit is None else min(limit, frames)
+    return int(limit)
 
 
 def encode_tiles(encoder, mel: torch.Tensor, tiles: Sequence[Tile], batch: int = 8) -> dict:

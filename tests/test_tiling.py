@@ -110,7 +110,7 @@ def test_long_item_goes_tile_by_tile(sd_weights):
             tiled = model.encoder.forward_time_major(mel)
             feat1, ids1 = model.speaker_ids(wav)
         finally:
-            model.encoder.max_item_frames = tiling.max_item_frames()
+            model.encoder.max_item_frames = tiling.max_item_frames(model.encoder.sizes)
             model.encoder.tile_frames = 32768
     np.testing.assert_allclose(tiled.cpu().numpy(), whole.cpu().numpy(), atol=1e-5, rtol=0)
     np.testing.assert_allclose(feat1.cpu().numpy(), feat0.cpu().numpy(), atol=1e-5, rtol=0)

@@ -571,8 +571,25 @@ __global__ __launch_bounds__(256, F16X3 ? 2 : 1) void gemm_glds_kernel(const Gem
         float* tile_ws = g.splitk_ws + ((size_t)(logical - g.tile_base) * g.split + slice) * (BM * BN);
         gemm_epilogue<0, NSUB>(gp, acc, lds, tile_ws - (m0 * BN + n0), nullptr, nullptr, m0, n0, lane, w, wm, wn);
     } else {
+#ifdef GEMM_ABL_NOEPI      // ablation build: no epilogue at all (what do set-up + K loop cost alone?)
+        {
+            float ssum = 0.f;      // (every accumulator stays live: 80 adds instead of an epilogue)
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) ssum += acc[j][e];
+            if (ssum == 12345.678f) Y[0] = ssum;
+        }
+#else
+#ifdef GEMM_ABL_STORESMALL  // ablation build: the tiles of every round store into the same 512 tile positions (42 MB: stays in the Infinity Cache)
+        const unsigned lt = logical % 512u;
+        const int64_t m0s = (int64_t)(lt / (unsigned)g.tiles_n) * BM;
+        if constexpr (EPI != 0) gemm_epilogue_split<MODE, NSUB>(g, acc, lds, Y, res, m0s, n0, lane, w);
+#else
         if constexpr (EPI != 0) gemm_epilogue_split<MODE, NSUB>(g, acc, lds, Y, res, m0, n0, lane, w);
+#endif
         else gemm_epilogue<MODE, NSUB>(g, acc, lds, Y, bias, res, m0, n0, lane, w, wm, wn);
+#endif
     }
 }
 

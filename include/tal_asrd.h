@@ -378,7 +378,8 @@ int tal_gru_cell_fwd(const float* x, const float* h, int B, int In, int H, const
  * tal_prof_collect synchronises on the recorded events and returns the summed
  * duration (ms), the number of launches and the summed algorithmic work
  * (flops for 0-2, HBM bytes for 3-4) since the last tal_prof_reset.
- * Not thread-safe; a process-wide switch meant for single-stream benchmarking.
+ * A process-wide switch meant for benchmarking (slots are handed out atomically; reset / collect while launches
+ * are in flight on other threads is the caller's race).
  * ------------------------------------------------------------------ */
 int tal_prof_enable(int on);
 int tal_prof_reset(void);

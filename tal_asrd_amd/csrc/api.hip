@@ -2,6 +2,8 @@
 // layer, TDS encoder driver, diarization head.
 #include <string.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace tal {
@@ -16,25 +18,28 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- per-launch event timing ------------------------------------------------------------
+// (a process-wide switch for benchmarking; slots are handed out atomically so that launches from several host threads
+//  cannot corrupt the table -- with the switch off, the default, nothing here is touched)
 static const int PROF_MAX = 8192;
-static bool g_prof_on = false;
-static int g_prof_n = 0;
+static std::atomic<bool> g_prof_on{false};
+static std::atomic<int> g_prof_n{0};
 static hipEvent_t g_prof_ev[PROF_MAX][2];
-static int g_prof_cls[PROF_MAX];
+static std::atomic<int> g_prof_have[PROF_MAX];       // 1: the slot's event pair exists
+static int g_prof_cls[PROF_MAX];                     // -1: slot taken but not timed
 static double g_prof_work[PROF_MAX];
-static int g_prof_created = 0;
 
 ProfScope::ProfScope(int cls, double work, hipStream_t stream) : slot(-1), s(stream) {
-    if (!g_prof_on || g_prof_n >= PROF_MAX) return;
-    slot = g_prof_n++;
-    if (slot >= g_prof_created) {
-        if (hipEventCreate(&g_prof_ev[slot][0]) != hipSuccess || hipEventCreate(&g_prof_ev[slot][1]) != hipSuccess) {
-            --g_prof_n;          // (measurement hook only: a launch without events is simply not timed)
-            slot = -1;
-            return;
-        }
-        g_prof_created = slot + 1;
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    const int mine = g_prof_n.fetch_add(1, std::memory_order_relaxed);
+    if (mine >= PROF_MAX) return;
+    g_prof_cls[mine] = -1;
+    if (!g_prof_have[mine].load(std::memory_order_acquire)) {
+        // (a slot index is owned by one launch at a time, so nobody else creates this pair)
+        if (hipEventCreate(&g_prof_ev[mine][0]) != hipSuccess || hipEventCreate(&g_prof_ev[mine][1]) != hipSuccess)
+            return;              // (measurement hook only: a launch without events is simply not timed)
+        g_prof_have[mine].store(1, std::memory_order_release);
     }
+    slot = mine;
     g_prof_cls[slot] = cls;
     g_prof_work[slot] = work;
     (void)hipEventRecord(g_prof_ev[slot][0], s);
@@ -203,7 +208,8 @@ extern "C" int tal_prof_collect(int cls, double* total_ms, int64_t* launches, do
     TAL_CHECK_ARG(cls >= 0 && cls < PROF_NCLASS && total_ms && launches && total_work, "tal_prof_collect: bad argument");
     double ms = 0.0, work = 0.0;
     int64_t n = 0;
-    for (int i = 0; i < g_prof_n; ++i) {
+    const int n_used = g_prof_n.load() < PROF_MAX ? g_prof_n.load() : PROF_MAX;
+    for (int i = 0; i < n_used; ++i) {
         if (g_prof_cls[i] != cls) continue;
         if (hipEventSynchronize(g_prof_ev[i][1]) != hipSuccess) {
             set_error("tal_prof_collect: event sync failed");

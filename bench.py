@@ -16,7 +16,10 @@ Workloads (a step = one pass of the hot path over synthetic input already reside
             (tal/asr/models.py:52: one log-mel mean couples the batch), sharded over the ranks by
             distributed.shard_indices, every rank's share one batched call, the call's global mean restored with one
             (sum, count) scalar all-reduce, ids + features returned to rank 0 through distributed.gather_segments
-            inside the timed region.  Strong scaling (the 64 segments are fixed).
+            (ONE collective per step: ids bit-cast into a 129th feature column, plan built once outside the timed loop)
+            inside the timed region.  Strong scaling (the 64 segments are fixed).  At N > 1 rank 0 first runs the SAME
+            64 segments alone (`one_gpu_same_workload`), so the line carries its own 1-GPU reference and
+            `speedup_vs_one_gpu` -- the default N = 1 line is the 1-hour clip, a different workload.
   decode    configs[4]: the joint decode of a 1-hour episode end to end -- ASR encode + sliding-window greedy decode
             (System.generate_unaligned) + SDModel pass + word-level WDER-format pooling / voting; one episode per GPU.
 
@@ -43,6 +46,8 @@ F16_MATRIX_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/FP16 MFMA dense (v
 HBM_PEAK_GBS = 8000.0
 POINTWISE_MAC_PER_FRAME = 6_272_000   # the 22 pointwise layers of the TDS blocks: fp16x3 form
 METRIC = "audio frames/sec (16 kHz, 10 ms hop) end-to-end log-mel -> TDS encoder -> diarization head"
+METRIC_DECODE = ("audio frames/sec (16 kHz, 10 ms hop) of the full joint ASR + diarization decode of an episode: ASR encode + "
+                 "sliding-window greedy decode + SD pass + WDER-format pooling (NOT the encode-only headline metric)")
 
 
 def parse():
@@ -58,6 +63,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=300.0, help="clip length of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event timing")
+    ap.add_argument("--no-exact-pass", action="store_true", help="clip workload: skip the extra pass on the exact fp32 kernels (value_exact_f32)")
+    ap.add_argument("--no-one-gpu-reference", action="store_true", help="segments workload at N > 1: skip rank 0's solo pass over all segments")
+    ap.add_argument("--cpu-threads", type=str, default="8,16,32,64,128", help="thread counts the CPU baseline is swept over")
     a = ap.parse_args()
     if a.workload is None:
         a.workload = "clip" if a.gpus == 1 else "segments"
@@ -82,9 +90,25 @@ def self_launch(args):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+    # a rank that dies (before the rendezvous, say) must not leave the others waiting for the collective timeout
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()
+                    codes[i] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write("".join(out0))
     sys.stdout.flush()
     return max(abs(c) for c in codes)
 
@@ -134,25 +158,37 @@ def dense_layer_algorithmic_bytes(frames, batch=1):
     return total, launches
 
 
-def cpu_baseline(sd, seconds):
-    """The oracle (CPU restatement of the reference's PyTorch-CPU path) on a bounded sample."""
+def cpu_baseline(sd, seconds, thread_counts):
+    """The oracle (CPU restatement of the reference's PyTorch-CPU path) on a bounded sample, swept over thread counts: an
+    oversubscribed pool is slower than a smaller one, so the best count is what `value` reports."""
     import torch
     from oracle import tal_oracle as O
     from tal_asrd_amd import synth
     L = int(seconds * 16000)
     audio = synth.synth_audio_batch(1, L, 1234)
     frames = 1 + L // 160
-    cores = torch.get_num_threads()
-    O.sd_path(audio, sd)  # warm-up
-    times = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        O.sd_path(audio, sd)
-        times.append(time.perf_counter() - t0)
-    med = sorted(times)[1]
-    return {"value": frames / med, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%.0f s synthetic clip (%d frames), torch-CPU fp32, %d threads, median of 3 after 1 warm-up "
-                      "(a 5-minute sample, not the 1-hour clip `value` is measured on)" % (seconds, frames, cores)}
+    ncpu = os.cpu_count() or 1
+    counts = sorted({min(int(c), ncpu) for c in thread_counts if int(c) > 0}) or [torch.get_num_threads()]
+    default_threads = torch.get_num_threads()
+    sweep = {}
+    try:
+        for c in counts:
+            torch.set_num_threads(c)
+            O.sd_path(audio, sd)                      # warm-up at this pool size
+            times = []
+            for _ in range(2 if seconds <= 600 else 1):
+                t0 = time.perf_counter()
+                O.sd_path(audio, sd)
+                times.append(time.perf_counter() - t0)
+            sweep[c] = frames / min(times)
+    finally:
+        torch.set_num_threads(default_threads)
+    best = max(sweep, key=sweep.get)
+    return {"value": sweep[best], "unit": "frames/s", "cores": best, "kind": "port", "host_cpus": ncpu,
+            "threads_swept": {str(k): v for k, v in sweep.items()},
+            "sample": "%.0f s synthetic clip (%d frames), torch-CPU fp32, best of %s threads (1 warm-up + best of %d timed runs "
+                      "per thread count)%s" % (seconds, frames, counts, 2 if seconds <= 600 else 1,
+                                               "" if seconds >= 3600 else "; a bounded sample, not the 1-hour clip `value` is measured on")}
 
 
 class FakeSD:
@@ -214,6 +250,8 @@ def main():
     lib = None if fake else _native.lib()
     prof = not args.no_prof and not fake
     extra = {}
+    exact_mode = bool(lib is not None and _native.get_option("tds_exact_f32"))      # TAL_OPTIONS=tds_exact_f32 runs
+    one_gpu_ref = {}
 
     # ------------------------------------------------------------------ workload set-up
     if args.workload == "decode":
@@ -254,47 +292,64 @@ def main():
         n_seg = args.segments
         lengths = [L] * n_seg
         mine = D.shard_indices(n_seg, rank, world, weights=lengths)
+        tp = ((((frames - 21) // 2 + 1) - 21) // 2 + 1 - 21) // 2 + 1          # encoder frames of one segment
         if fake:
             model, sd = FakeSD(), None
         else:
             model, sd = build_sd_model(dev)
             if dist is not None:
-                D.broadcast_module(model)     # weights come from rank 0 over RCCL / xGMI (start-up only)
+                D.broadcast_module(model)     # weights come from rank 0 over RCCL / xGMI (start-up only, one flat buffer)
             from tal_asrd_amd import ops
-            batch = torch.cat([torch.from_numpy(synth.synth_audio_batch(1, L, 1234 + i)) for i in mine]).to(dev) if mine else None
+
+        def load_batch(idx):
+            return torch.cat([torch.from_numpy(synth.synth_audio_batch(1, L, 1234 + i)) for i in idx]).to(dev) if idx else None
+
+        def run_share(idx, batch, reduce_mean):
+            """This rank's share `idx` of ONE reference call over the [n_seg, L] batch -> {item: [tp, 129]} (128 features +
+            the arg-max id bit-cast into the last column)."""
+            if fake:
+                res = model.speaker_ids_batch(idx, frames)
+                return {i: D.pack_feat_ids(res[i][0], res[i][1]) for i in idx}
+            # log-mel without the mean, the call's global (sum, count) over all ranks, subtract, encoder + head
+            if batch is not None:
+                mel, _, st = ops.logmel(model.logmelspec.plan(), batch, eps=model.logmelspec.eps, subtract_mean=False,
+                                        return_stats=True)
+            else:
+                st = torch.zeros(2, dtype=torch.float64, device=dev)
+            mean = D.allreduce_logmel_stats(st) if reduce_mean else (st[0] / st[1]).to(torch.float32).reshape(1)
+            out = {}
+            if batch is not None:
+                ops.subtract_scalar_(mel, mean)
+                enc = model.encode_features(mel, None)
+                feat, _, ids = ops.sd_head(enc["encoder_out"], model.spk_embed_proj.weight, model.spk_embed_proj.bias,
+                                           model.spk_logit_proj.weight, model.spk_logit_proj.bias, want_logits=False,
+                                           want_ids=True)
+                for k, i in enumerate(idx):
+                    out[i] = D.pack_feat_ids(feat[k], ids[k])
+            return out
+
+        batch = None if fake else load_batch(mine)
+        # the gather plan (who holds which segment, how many rows) is static: built once, outside the timed loop
+        gdev = dev if (fake or backend == "nccl") else torch.device("cpu")
+        plan = D.SegmentGather({i: tp for i in mine}, n_seg, trailing=(129,) if mine else None,
+                               dtype=torch.float32 if mine else None, device=gdev, dst=0) if dist is not None else None
         gathered = {}
 
         def step():
-            if fake:
-                res = model.speaker_ids_batch(mine, frames)
-                feat_l = {i: res[i][0] for i in mine}
-                ids_l = {i: res[i][1] for i in mine}
+            local = run_share(mine, batch, dist is not None)
+            if plan is None:
+                packed = [local[i] for i in range(n_seg)]
             else:
-                feat_l, ids_l = {}, {}
-                # this rank's share of ONE reference call over the [n_seg, L] batch: log-mel without the mean, the call's
-                # global (sum, count) over all ranks, subtract, encoder + head
-                if batch is not None:
-                    mel, _, st = ops.logmel(model.logmelspec.plan(), batch, eps=model.logmelspec.eps, subtract_mean=False,
-                                            return_stats=True)
-                else:
-                    st = torch.zeros(2, dtype=torch.float64, device=dev)
-                mean = D.allreduce_logmel_stats(st)
-                if batch is not None:
-                    ops.subtract_scalar_(mel, mean)
-                    enc = model.encode_features(mel, None)
-                    feat, _, ids = ops.sd_head(enc["encoder_out"], model.spk_embed_proj.weight, model.spk_embed_proj.bias,
-                                               model.spk_logit_proj.weight, model.spk_logit_proj.bias, want_logits=False,
-                                               want_ids=True)
-                    for k, i in enumerate(mine):
-                        feat_l[i], ids_l[i] = feat[k], ids[k]
-            gathered["feat"] = D.gather_segments(feat_l, n_seg, dst=0)
-            gathered["ids"] = D.gather_segments(ids_l, n_seg, dst=0)
+                if gdev != dev:
+                    local = {i: v.to(gdev) for i, v in local.items()}
+                packed = plan.gather(local)
+            gathered["packed"] = packed
         units_per_step = n_seg * frames
         scaling = "strong"
         workload = ("%d x %.0f s 16 kHz segments = one reference call over a [%d, L] batch, sharded over %d GPU(s) by "
                     "distributed.shard_indices, each rank's share one batched call, one scalar (sum, count) all-reduce for "
-                    "the call's log-mel mean, ids + features gathered to rank 0 (BASELINE.json configs[3]; SDModel path: "
-                    "log-mel -> TDS 80-800-1120-1440 -> 128-d feat + argmax over 6008 speakers)"
+                    "the call's log-mel mean, ids + features gathered to rank 0 in one collective per step (BASELINE.json "
+                    "configs[3]; SDModel path: log-mel -> TDS 80-800-1120-1440 -> 128-d feat + argmax over 6008 speakers)"
                     % (n_seg, args.seconds, n_seg, world))
     else:
         model, sd = build_sd_model(dev)
@@ -383,19 +438,54 @@ def main():
         if prof and args.workload != "decode":
             elapsed_prof = timed_pass(True)
             extra["ms_per_step_with_launch_events"] = 1e3 * elapsed_prof / args.steps
+        if args.workload == "clip" and not fake and not exact_mode and not args.no_exact_pass:
+            # the same K steps on the exact fp32-input kernels (v_mfma_f32_32x32x2_f32 everywhere, fp32 activations):
+            # the driver-observed figure of the mode whose results are bit-for-bit fmaf chains
+            _native.set_option("tds_exact_f32", 1)
+            try:
+                step(); drain()
+                elapsed_exact = timed_pass(False)
+            finally:
+                _native.set_option("tds_exact_f32", 0)
+            if dist is not None:
+                t = torch.tensor([elapsed_exact], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed_exact = float(t.item())
+            extra["value_exact_f32"] = units_per_step * args.steps / elapsed_exact
+            extra["ms_per_step_exact_f32"] = 1e3 * elapsed_exact / args.steps
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    with torch.no_grad():
+        if args.workload == "segments" and world > 1 and not args.no_one_gpu_reference:
+            # the SAME workload on one GPU: rank 0 alone runs all n_seg segments as one batched call (the other ranks wait),
+            # so that a scaling sweep has a same-workload reference (the default N = 1 line is the 1-hour clip)
+            if rank == 0:
+                all_idx = list(range(n_seg))
+                full = None if fake else load_batch(all_idx)
+                run_share(all_idx, full, False)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    run_share(all_idx, full, False)
+                sync()
+                dt1 = time.perf_counter() - t0
+                del full
+                one_gpu_ref.update(one_gpu_same_workload={"value": units_per_step * args.steps / dt1, "unit": "frames/s",
+                                                          "ms_per_step": 1e3 * dt1 / args.steps, "n_gpus": 1,
+                                                          "what": "rank 0 alone, the same %d segments as ONE batched call, no collective" % n_seg},
+                                   speedup_vs_one_gpu=dt1 / elapsed)
+            dist.barrier()
 
     if rank == 0:
         total_frames = units_per_step * args.steps
         line = {
-            "metric": METRIC, "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC_DECODE if args.workload == "decode" else METRIC, "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None,
-            "dtype": "f32" if os.environ.get("TAL_TDS_F32") or args.workload == "decode"
+            "dtype": "f32" if exact_mode or args.workload == "decode"
                      else "f32 (dense layers: 3 x f16 MFMA hi/lo split, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": workload, "frames_per_step": units_per_step, "weights": "synthetic deterministic",
@@ -405,8 +495,9 @@ def main():
         if fake:
             line["data"] = "FAKE (TAL_BENCH_FAKE plumbing self-test: no GPU work, not a measurement)"
         if args.workload == "segments":
-            got = gathered.get("ids")
+            got = gathered.get("packed")
             line["gathered_segments"] = len(got) if got is not None else 0
+            line.update(one_gpu_ref)
         if args.workload == "decode":
             line["episode"] = stats
             steps_n = max(stats.get("tokens", 1), 1)
@@ -427,17 +518,19 @@ def main():
                 kern[name] = {"ms_total": ms.value, "launches": n.value, "work": work.value}
             gm = kern["gemm_nt_f32"]
             achieved = gm["work"] / (gm["ms_total"] * 1e-3) / 1e12 if gm["ms_total"] > 0 else 0.0
-            traffic = None
-            try:   # HBM-side bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-                for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            traffic = traffic_source = None
+            try:   # fabric-side bytes per launch: NOT measured in this run -- the figure of the builder's separate
+                   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/profile_round.sh), committed under profiles/
+                for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
                     path = os.path.join(ROOT, "profiles", name)
                     if os.path.exists(path):
                         with open(path) as f:
                             traffic = json.load(f)["hbm_bytes_per_launch"]
+                        traffic_source = "profiles/%s (builder-run rocprofv3 --pmc passes of the 1-hour clip workload, not this run)" % name
                         break
             except Exception:
                 pass
-            f32_only = bool(os.environ.get("TAL_TDS_F32"))
+            f32_only = exact_mode
             peak = FP32_MATRIX_PEAK_TFLOPS if f32_only else F16_MATRIX_PEAK_TFLOPS
             # MFMA flops actually issued: the pointwise layers run as 3 fp16 MFMAs per fp32 product (hi*hi, hi*lo, lo*hi)
             per_rank_frames = (len(mine) if args.workload == "segments" else args.segments) * frames
@@ -449,7 +542,7 @@ def main():
                                           "products as 3 f16 MFMAs, fp32 accumulate)" if not f32_only else
                                           "tal::gemm_glds_kernel (fp32 MFMA dense layer, all epilogues)",
                                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                                "frac": achieved / peak, "traffic": traffic,
+                                "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
                                 "achieved_is": "algorithmic fp32 flops (2 M N K per dense layer) / HIP-event time (rank 0)",
                                 "issued_mfma_tflops": issued / (gm["ms_total"] * 1e-3) / 1e12 if gm["ms_total"] > 0 else 0.0,
                                 "issued_frac": (issued / (gm["ms_total"] * 1e-3) / 1e12 / peak) if gm["ms_total"] > 0 else 0.0,
@@ -465,7 +558,7 @@ def main():
             line["h2d_ms_per_clip"] = h2d_ms
             line["value_including_h2d"] = total_frames / (elapsed + 1e-3 * h2d_ms * args.segments * args.steps)
         if not args.no_cpu_baseline and world == 1 and not fake:
-            line["cpu_baseline"] = cpu_baseline(sd, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(sd, args.cpu_seconds, [c for c in args.cpu_threads.split(",") if c.strip()])
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -21,9 +21,10 @@
  *     returns the token the host loop steers by;
  *   - return value: 0 (TAL_OK) or a negative TAL_E* code; no C++ exception
  *     crosses the boundary; tal_last_error() gives a thread-local message;
- *   - re-entrant per stream; no global mutable state besides the error string
- *     and the tal_prof_* measurement hooks (a process-wide switch for
- *     single-stream benchmarking, off by default).
+ *   - re-entrant per stream; no global mutable state besides the error string,
+ *     the tal_prof_* measurement hooks (a process-wide switch for
+ *     single-stream benchmarking, off by default) and the tal_set_option
+ *     switches; the environment is never read.
  */
 #ifndef TAL_ASRD_H
 #define TAL_ASRD_H
@@ -43,8 +44,23 @@ extern "C" {
 #define TAL_MAX_STAGES 4
 #define TAL_MAX_DEPTH 8
 
-int tal_version(void);
+int tal_version(void);          /* 300 = 0.3.0 */
 const char* tal_last_error(void);
+
+/* Process-wide behaviour switches.  The library never reads the environment: which kernels a caller gets depends on its
+ * arguments and on these calls only (the host-side mirror applies TAL_OPTIONS="name=value,..." at load time, for the
+ * measurement scripts).  Names (all default 0 unless stated):
+ *   tds_exact_f32         every layer of tal_tds_fwd and the head arg-max on the exact fp32-input kernels
+ *                         (per call: tal_tds_desc.flags & TAL_TDS_EXACT_F32)
+ *   tds_fp32_activations  fp16x3 layers, but fp32 activations between the kernels of a stage
+ *   gconv_fuse_split, gconv_c1_generic, head_no_astationary, gemm_global_loads, gemm_no_splitk4, gemm_no_glds,
+ *   gemm_no_splitk_tail, logmel_no_fold, decode_no_small
+ *                         kernel-selection switches of the ablation measurements
+ *   decode_small_rows     largest prefix the latency-oriented decoder layer takes (default 256)
+ * tal_set_option returns TAL_EINVAL for an unknown name; tal_option_name(i) enumerates the names (NULL past the end). */
+int tal_set_option(const char* name, int value);
+int tal_get_option(const char* name, int* value);
+const char* tal_option_name(int index);
 
 /* ------------------------------------------------------------------ *
  * Log-mel front-end: LogMelSpec.forward, tal/asr/models.py:35-53
@@ -319,9 +335,19 @@ typedef struct tal_greedy_ctx {
     uint32_t* tickets;       /* 256 words, ZERO before the first call (the kernels leave them zero): arrival tickets of the
                               * kernels that merge partial results in-launch (key-split cross-attention, LM head + pick);
                               * NULL: the unmerged forms (more launches).  One context per stream. */
+    float* picked_host_dev;  /* device alias of picked_host; NULL: resolved (hipHostGetDevicePointer) by the first sync 2 / 3 step */
+    uint32_t seq;            /* library-owned: sequence value of the latest sync 2 / 3 step (start at 0) */
+    uint32_t _pad;
 } tal_greedy_ctx;
 size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H, int FF, int V, int E0, int n_layers);
-int tal_greedy_step_fwd(const tal_greedy_ctx* c, int64_t history_start, int64_t n_gen, int sync, void* stream);
+/* sync: 0 = enqueue only; 1 = copy {token, attention row} to picked_host and wait for the stream; 2 = the last kernel writes
+ * {token, row, sequence word} into picked_host itself and the call polls the word (no copy command, no driver wake-up;
+ * after 20 s without a result it waits for the stream and returns TAL_EHIP: nothing is left in flight); 3 = as 2 without
+ * the polling -- the caller asks tal_greedy_step_poll, which lets ONE host thread keep several sessions (one context and
+ * one stream each) in flight. */
+int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int64_t n_gen, int sync, void* stream);
+/* 1: the context's latest sync 2 / 3 step has delivered; 0: not after wait_ms milliseconds (0 = one look); < 0: error. */
+int tal_greedy_step_poll(const tal_greedy_ctx* c, int wait_ms);
 /* HOST helper (no device work, `row` is a host pointer): ngram_repeat_mask(row, n).sum() of tal/asr/util.py:5-17, the
  * repetition detector System.generate_unaligned evaluates once per generated token (system.py:418-421). */
 int64_t tal_ngram_repeat_count(const int64_t* row, int64_t len, int n);

@@ -1,6 +1,10 @@
 #!/bin/bash
-# Ablation builds of the library (kernel experiments only): build/abl/<name>.so with extra -D flags; select one with
-# TAL_ASRD_LIB=build/abl/<name>.so.   usage: scripts/build_ablation.sh name -DFLAG [-DFLAG ...]
+# Ablation builds of the library (kernel experiments only): build/abl/<name>.so with extra -D flags (layout constants such as
+# -DGC_P10=10, -DGC_P18=0, -DGC_LB18=3); select one with TAL_ASRD_LIB=build/abl/<name>.so.
+# The wrong-result ablation blocks of round 2 (GEMM_ABL_NOEPI / _STORESMALL, GC_ABL_NOSTORE / _ONE_STORE / _NOTAIL: what the
+# epilogues and store phases cost, profiles/r2_gemm_f16x3_fit.txt, r2_gconv_ablations.txt) are no longer in the product
+# sources; check out commit ab04c04 to rebuild them.
+# usage: scripts/build_ablation.sh name -DFLAG [-DFLAG ...]
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift

@@ -1,5 +1,5 @@
 """Max deviation of the SD path from the vectors recorded from the reference (tests/golden/sd_5min.npz) -- run once as
-is (fp16x3 dense layers) and once with TAL_TDS_F32=1 (pure fp32 dense layers)."""
+is (fp16x3 dense layers) and once with TAL_OPTIONS=tds_exact_f32 (pure fp32 dense layers)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -19,7 +19,7 @@ with torch.no_grad():
     enc = m.encode(audio, None)
     logits = m.decode(enc)
 eo = enc["encoder_out"]
-print("mode: %s" % ("fp32 dense layers" if os.environ.get("TAL_TDS_F32") else "fp16x3 dense layers"))
+print("mode: %s" % ("fp32 dense layers" if "tds_exact_f32" in os.environ.get("TAL_OPTIONS", "") else "fp16x3 dense layers"))
 print("  encoder_out  max |err| vs reference sample: %.3e" % np.abs(eo[:, gold["enc_rows"]].cpu().numpy() - gold["enc_sample"]).max())
 print("  logits       max |err| vs reference sample: %.3e" % np.abs(logits[:, gold["logit_rows"]].cpu().numpy() - gold["logit_sample"]).max())
 ids = ops.argmax_rows(logits).cpu().numpy()

@@ -9,8 +9,8 @@ O=$R/gpurun_out/r2final
 mkdir -p $O
 cd $R
 python bench.py > $O/bench_1h.json 2> $O/bench_1h.err
-TAL_TDS_F32=1 python bench.py --no-cpu-baseline > $O/bench_1h_fp32.json 2> $O/bench_1h_fp32.err
-TAL_TDS_NO_ALLSPLIT=1 python bench.py --no-cpu-baseline > $O/bench_1h_fp32_activations.json 2> /dev/null
+TAL_OPTIONS=tds_exact_f32 python bench.py --no-cpu-baseline > $O/bench_1h_fp32.json 2> $O/bench_1h_fp32.err
+TAL_OPTIONS=tds_fp32_activations python bench.py --no-cpu-baseline > $O/bench_1h_fp32_activations.json 2> /dev/null
 python bench.py --workload segments --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_segments_64x5min.json 2> /dev/null
 python bench.py --workload decode --no-cpu-baseline --steps 2 --warmup 1 > $O/bench_decode_1h_episode.json 2> /dev/null
 python scripts/bench_short.py 10 30 60 300 > $O/short_clips.txt 2>&1

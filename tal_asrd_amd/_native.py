@@ -43,7 +43,8 @@ class GreedyCtx(C.Structure):
                 ("emb", C.c_void_p), ("proj", C.c_void_p), ("proj_t", C.c_void_p), ("pe", C.c_void_p),
                 ("k_cache", C.c_void_p), ("vt_cache", C.c_void_p), ("mem_kpm", C.c_void_p), ("tokens", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("picked_dev", C.c_void_p),
-                ("picked_host", C.c_void_p), ("tickets", C.c_void_p)]
+                ("picked_host", C.c_void_p), ("tickets", C.c_void_p), ("picked_host_dev", C.c_void_p),
+                ("seq", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/tal_asrd.h declares
@@ -52,6 +53,9 @@ _i, _i64, _sz, _f, _p = C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_void_p
 SIGNATURES = {
     "tal_version": (_i, []),
     "tal_last_error": (C.c_char_p, []),
+    "tal_set_option": (_i, [C.c_char_p, _i]),
+    "tal_get_option": (_i, [C.c_char_p, C.POINTER(C.c_int)]),
+    "tal_option_name": (C.c_char_p, [_i]),
     "tal_logmel_num_frames": (_i64, [_i64]),
     "tal_logmel_plan_bytes": (_sz, []),
     "tal_logmel_plan_init": (_i, [_p, _p, _p, _p]),
@@ -92,6 +96,7 @@ SIGNATURES = {
     "tal_transpose_fwd": (_i, [_p, _i, _i, _p, _p]),
     "tal_greedy_step_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "tal_greedy_step_fwd": (_i, [C.POINTER(GreedyCtx), _i64, _i64, _i, _p]),
+    "tal_greedy_step_poll": (_i, [C.POINTER(GreedyCtx), _i]),
     "tal_ngram_repeat_count": (_i64, [_p, _i64, _i]),
     "tal_greedy_pick_fwd": (_i, [_p, _i, _p, _i, _i64, _i, _p, _p, _p]),
     "tal_log_softmax_rows": (_i, [_p, _i64, _i, _p, _p]),
@@ -128,7 +133,23 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        # measurement scripts select kernels with TAL_OPTIONS="name=value,name,..." (a bare name means 1); the library
+        # itself never reads the environment -- a C caller uses tal_set_option
+        for item in filter(None, (x.strip() for x in os.environ.get("TAL_OPTIONS", "").split(","))):
+            name, _, val = item.partition("=")
+            set_option(name.strip(), int(val) if val.strip() else 1)
     return _lib
+
+
+def set_option(name, value=1):
+    """tal_set_option: a process-wide kernel-selection switch (include/tal_asrd.h lists the names)."""
+    check(lib().tal_set_option(name.encode(), int(value)), "tal_set_option(%s)" % name)
+
+
+def get_option(name):
+    v = C.c_int()
+    check(lib().tal_get_option(name.encode(), C.byref(v)), "tal_get_option(%s)" % name)
+    return v.value
 
 
 def check(rc, what=""):

@@ -17,6 +17,13 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- behaviour switches (tal_set_option) ---------------------------------------------------
+static const char* const g_opt_names[OPT_COUNT] = {
+    "tds_exact_f32", "tds_fp32_activations", "gconv_fuse_split", "gconv_c1_generic", "head_no_astationary", "gemm_global_loads",
+    "gemm_no_splitk4", "gemm_no_glds", "gemm_no_splitk_tail", "logmel_no_fold", "decode_no_small", "decode_small_rows"};
+static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {256}};
+int opt(Option o) { return g_opt[o].load(std::memory_order_relaxed); }
+
 // ---- per-launch event timing ------------------------------------------------------------
 // (a process-wide switch for benchmarking; slots are handed out atomically so that launches from several host threads
 //  cannot corrupt the table -- with the switch off, the default, nothing here is touched)
@@ -165,7 +172,7 @@ static int64_t conv_out_len(int64_t t) { return t < 21 ? 0 : (t - 21) / 2 + 1; }
 
 using namespace tal;
 
-extern "C" int tal_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int tal_version(void) { return 300; /* 0.3.0: tal_set_option; tal_attn_pool_fwd half_mode, tal_tds_desc flags (0.2) */ }
 
 // Host-side helper of the decode loop (no device work): ngram_repeat_mask(row, n).sum() of tal/asr/util.py:5-17 -- the number
 // of positions covered by an n-gram that already occurred earlier in the row; like the reference, n-gram starts run to
@@ -193,6 +200,30 @@ extern "C" int64_t tal_ngram_repeat_count(const int64_t* row, int64_t len, int n
 }
 
 extern "C" const char* tal_last_error(void) { return g_err; }
+
+static int find_option(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (strcmp(name, g_opt_names[i]) == 0) return i;
+    return -1;
+}
+
+extern "C" int tal_set_option(const char* name, int value) {
+    const int i = find_option(name);
+    TAL_CHECK_ARG(i >= 0, "tal_set_option: unknown option '%s'", name ? name : "(null)");
+    TAL_CHECK_ARG(i != OPT_DECODE_SMALL_ROWS || value >= 0, "tal_set_option: decode_small_rows must be >= 0");
+    g_opt[i].store(value, std::memory_order_relaxed);
+    return TAL_OK;
+}
+
+extern "C" int tal_get_option(const char* name, int* value) {
+    const int i = find_option(name);
+    TAL_CHECK_ARG(i >= 0 && value, "tal_get_option: unknown option '%s'", name ? name : "(null)");
+    *value = g_opt[i].load(std::memory_order_relaxed);
+    return TAL_OK;
+}
+
+extern "C" const char* tal_option_name(int index) { return index >= 0 && index < OPT_COUNT ? g_opt_names[index] : nullptr; }
 
 extern "C" int tal_prof_enable(int on) {
     g_prof_on = on != 0;
@@ -350,8 +381,7 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
     float* buf[4];
     for (int q = 0; q < 4; ++q) buf[q] = reinterpret_cast<float*>(workspace) + q * nf;
     float* skws = reinterpret_cast<float*>(workspace) + 4 * nf;   // split-K scratch of the dense layers
-    static const bool env_f32 = getenv("TAL_TDS_F32") != nullptr;
-    const bool force_f32 = env_f32 || (d->flags & TAL_TDS_EXACT_F32) != 0;
+    const bool force_f32 = opt(OPT_TDS_EXACT_F32) != 0 || (d->flags & TAL_TDS_EXACT_F32) != 0;
     // status word: raised by any kernel that turns an fp32 value outside the finite fp16 range into hi / lo halves
     int* range_flag = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + tal_tds_status_offset(d, B, T));
     if (hipMemsetAsync(range_flag, 0, 64, s) != hipSuccess) {
@@ -367,7 +397,7 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
     // reads it twice (operand and residual) and writes it for the next block.  No fp32 copy of an activation and no
     // separate split pass exist inside such a stage: 7 activation-sized transfers per block instead of 10.  Short inputs,
     // odd widths and the exact mode keep fp32 activations (the kernels below the `else`).
-    static const bool no_allsplit = getenv("TAL_TDS_NO_ALLSPLIT") != nullptr;
+    const bool no_allsplit = opt(OPT_TDS_FP32_ACTIVATIONS) != 0;
     auto stage_len = [&](int i) { int64_t t = T; for (int q = 0; q <= i; ++q) t = conv_out_len(t); return t; };
     auto s2_mfma_ok = [&](int i, int64_t Tin) {       // stride-2 resize conv of stage i on the matrix cores
         return !force_f32 && d->down_w_frag[i] && (int64_t)B * conv_out_len(Tin) > 64 &&
@@ -441,7 +471,7 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
             const bool f16x3 = !force_f32 && bw.fc0_w_split && bw.fc3_w_split && M > 128 && c % 160 == 0;
             const bool conv_mfma = !force_f32 && M > 64 && bw.conv_w_frag && gconv_f16x3_weight_bytes(c, c, d->groups, 1) > 0 && gconv_f16x3_fits(To, c);
             // x1 = x + rw * relu(gconv(x))            : a -> x1
-            static const bool fuse_split = getenv("TAL_GCONV_FUSE_SPLIT") != nullptr;
+            const bool fuse_split = opt(OPT_GCONV_FUSE_SPLIT) != 0;
             if (conv_mfma)
                 rc = launch_gconv_res_f16x3(a, bw.conv_w_frag, bw.conv_b, bw.resweight, B, To, c, d->groups, x1, (fuse_split && f16x3) ? x1s : nullptr, s,
                                             range_flag);
@@ -540,7 +570,7 @@ extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_
         int32_t* pi = reinterpret_cast<int32_t*>(pv + (size_t)M * P);
         // the speaker-logit weights as hi / lo fp16 split in the unused tail of the workspace (3 MB, one ~5 us pass per call):
         // the arg-max GEMM then runs in the fp16x3 form of the dense layers
-        static const bool head_f32 = getenv("TAL_TDS_F32") != nullptr;
+        const bool head_f32 = opt(OPT_TDS_EXACT_F32) != 0;
         void* wsplit = nullptr;
         const size_t used = ((size_t)M * P * 8 + 255) & ~(size_t)255;
         if (!head_f32 && E % 32 == 0 && (reinterpret_cast<uintptr_t>(w_logit) & 15) == 0 && used + (size_t)S * E * 4 <= workspace_bytes) {

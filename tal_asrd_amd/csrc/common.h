@@ -93,6 +93,25 @@ __device__ __forceinline__ void split_f16x3_pair(float a, float b, f16x2p& hi, f
     lo = __builtin_convertvector((x - hf) * 2048.f, f16x2p);
 }
 
+// Process-wide behaviour switches (tal_set_option / tal_get_option, include/tal_asrd.h).  Nothing in the library reads the
+// environment: which kernels a caller of the C ABI gets depends on its arguments and on these explicit calls only.
+enum Option {
+    OPT_TDS_EXACT_F32 = 0,        // every layer of tal_tds_fwd / the head arg-max on the exact fp32-input kernels
+    OPT_TDS_FP32_ACTIVATIONS,     // fp16x3 layers but fp32 activations between the kernels of a stage (round-1 data flow)
+    OPT_GCONV_FUSE_SPLIT,         // fp32-activation flow: the TDSBlock conv also stores the split form (instead of the split pass)
+    OPT_GCONV_C1_GENERIC,         // first resize conv (1 -> 10 channels per group) on the generic tiled kernel
+    OPT_HEAD_NO_ASTATIONARY,      // speaker-logit arg-max through the dense layer's fused arg-max epilogue
+    OPT_GEMM_GLOBAL_LOADS,        // dense layers: 64-bit-address LDS-DMA loads instead of the buffer form
+    OPT_GEMM_NO_SPLITK4,          // short problems (M <= 512) on the register-staged tile instead of the split-K-in-workgroup kernel
+    OPT_GEMM_NO_GLDS,             // large problems on the register-staged kernel instead of the LDS-DMA kernel
+    OPT_GEMM_NO_SPLITK_TAIL,      // no K slices for the tiles of the last partial scheduling round
+    OPT_LOGMEL_NO_FOLD,           // plans built afterwards use the direct 400-term DFT (no symmetric-window folding)
+    OPT_DECODE_NO_SMALL,          // decoder layers on the batched-GEMM path even for a decode step
+    OPT_DECODE_SMALL_ROWS,        // largest prefix (rows) the latency-oriented decoder layer takes (default 256)
+    OPT_COUNT
+};
+int opt(Option o);
+
 // wave-uniform wave index inside the workgroup, provably uniform to the compiler
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 

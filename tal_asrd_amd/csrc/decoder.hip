@@ -653,8 +653,8 @@ static SkinnyArgs skinny(const float* A, int64_t lda, const float* W, const floa
 }
 
 static bool small_layer_applicable(int B, int U, int S, int E, int H, int FF, bool have_kv_cache) {
-    static const bool off = getenv("TAL_DECODE_NO_SMALL") != nullptr;
-    static const int max_rows = getenv("TAL_DECODE_SMALL_ROWS") ? atoi(getenv("TAL_DECODE_SMALL_ROWS")) : 256;   // measured: 0.36 vs 0.41 ms per step at 128 rows, even at 256, slower at 512
+    const bool off = opt(OPT_DECODE_NO_SMALL) != 0;
+    const int max_rows = opt(OPT_DECODE_SMALL_ROWS);   // default 256; measured: 0.36 vs 0.41 ms per step at 128 rows, even at 256, slower at 512
     return !off && have_kv_cache && (int64_t)B * U <= max_rows && E % 64 == 0 && FF % 64 == 0 && E % H == 0 &&
            attn_small_applicable(U, S, E / H) && attn_small_applicable(U, U, E / H);
 }
@@ -935,14 +935,32 @@ extern "C" size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H
     return f * sizeof(float);
 }
 
-extern "C" int tal_greedy_step_fwd(const tal_greedy_ctx* c, int64_t history_start, int64_t n_gen, int sync, void* stream) {
+// 1: the result of the context's latest host-direct step (sync 2 / 3) is in picked_host; 0: not yet, after waiting up to
+// wait_ms milliseconds (0: one look); < 0: bad argument.  Host-only: reads the sequence word the pick kernel writes last.
+extern "C" int tal_greedy_step_poll(const tal_greedy_ctx* c, int wait_ms) {
+    TAL_CHECK_ARG(c && c->picked_host && c->S > 0 && wait_ms >= 0, "tal_greedy_step_poll: bad argument");
+    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(c->picked_host + 1 + c->S);
+    const unsigned seq = c->seq;
+    if (*flag != seq && wait_ms > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; *flag != seq; ++spins)
+            if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(wait_ms)) break;
+    }
+    if (*flag != seq) return 0;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 1;
+}
+
+extern "C" int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int64_t n_gen, int sync, void* stream) {
     TAL_CHECK_ARG(c && c->layers && c->emb && c->pe && c->k_cache && c->vt_cache && c->tokens && c->workspace && c->picked_dev,
                   "tal_greedy_step_fwd: null pointer");
     const int E = c->E, H = c->H, FF = c->FF, S = c->S, V = c->V, E0 = c->E0, L = c->n_layers;
     const int64_t U64 = n_gen - history_start;
     TAL_CHECK_ARG(history_start >= 0 && U64 >= 1 && U64 <= c->max_len, "tal_greedy_step_fwd: prefix [%lld, %lld) must hold 1..%d tokens",
                   (long long)history_start, (long long)n_gen, c->max_len);
+    TAL_CHECK_ARG(sync >= 0 && sync <= 3, "tal_greedy_step_fwd: sync=%d", sync);
     TAL_CHECK_ARG(!sync || c->picked_host, "tal_greedy_step_fwd: sync needs the pinned host buffer");
+    TAL_CHECK_ARG(sync != 3 || c->tickets, "tal_greedy_step_fwd: sync 3 (result written to pinned memory, polled by the caller) needs the merged kernels (tickets)");
     const int U = (int)U64;
     if (c->workspace_bytes < tal_greedy_step_workspace_bytes(U, S, E, H, FF, V, E0, L)) {
         set_error("tal_greedy_step_fwd: workspace %zu < %zu bytes", c->workspace_bytes, tal_greedy_step_workspace_bytes(U, S, E, H, FF, V, E0, L));
@@ -980,31 +998,38 @@ extern "C" int tal_greedy_step_fwd(const tal_greedy_ctx* c, int64_t history_star
     // tied factorised LM head on the last position (models.py:243-246; system.py:355-361 reads only that row)
     const float* hl = cur + (size_t)(U - 1) * E;
     const int K0 = E0 > 0 ? E0 : E;
-    // sync == 2: the pick kernel writes {token, row, sequence word} straight into the pinned host buffer (1 + S + 1 words)
-    // and this call polls the word instead of queueing a copy and sleeping on the stream
-    static unsigned seq_counter = 0;
-    const bool host_direct = sync == 2 && c->tickets;
-    const unsigned seq = host_direct ? (++seq_counter ? seq_counter : ++seq_counter) : 0u;
+    // sync == 2 / 3: the pick kernel writes {token, row, sequence word} straight into the pinned host buffer (1 + S + 1 words)
+    // through its device alias; sync 2 polls the word here, sync 3 leaves the polling to the caller (tal_greedy_step_poll:
+    // several sessions in flight on several streams).  The sequence value is per context (one context per stream).
+    const bool host_direct = sync >= 2 && c->tickets;
+    if (host_direct && !c->picked_host_dev) {
+        void* alias = nullptr;
+        if (hipHostGetDevicePointer(&alias, c->picked_host, 0) != hipSuccess || !alias) {
+            set_error("tal_greedy_step_fwd: picked_host is not mapped pinned host memory (%s)", hipGetErrorString(hipGetLastError()));
+            return TAL_EINVAL;
+        }
+        c->picked_host_dev = reinterpret_cast<float*>(alias);
+    }
+    if (host_direct && ++c->seq == 0) ++c->seq;         // (0 is the value of a buffer nobody has written yet)
+    const unsigned seq = host_direct ? c->seq : 0u;
     if (c->tickets && E % 16 == 0 && K0 % 8 == 0 && (reinterpret_cast<uintptr_t>(c->emb) & 15) == 0 &&
         (!c->proj_t || (reinterpret_cast<uintptr_t>(c->proj_t) & 15) == 0)) {
         const float* rows = small ? probs : avg + (size_t)(U - 1) * S;
         hipLaunchKernelGGL(lm_pick_kernel, dim3((unsigned)cdiv(V, LMP_ROWS)), dim3(256), (size_t)(E + K0 + LMP_ROWS) * sizeof(float), s, hl,
                            E0 > 0 ? c->proj_t : nullptr, E, K0, c->emb, V, rows, L, small ? (int64_t)H * S : (int64_t)U * S,
                            small ? H : 1, small ? (int64_t)S : (int64_t)0, S, pick_part, c->tickets + (TAL_GREEDY_TICKETS - 1),
-                           host_direct ? c->picked_host : c->picked_dev, c->tokens + n_gen, host_direct ? seq : 0u);
+                           host_direct ? c->picked_host_dev : c->picked_dev, c->tokens + n_gen, host_direct ? seq : 0u);
         TAL_CHECK_LAUNCH("tal_greedy_step_fwd(lm head + pick)");
+        if (sync == 3) return TAL_OK;
         if (host_direct) {
-            // poll the sequence word (bounded: a lost launch must not hang the caller)
-            volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(c->picked_host + 1 + S);
-            const auto t0 = std::chrono::steady_clock::now();
-            for (unsigned spins = 0; *flag != seq; ++spins) {
-                if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
-                    set_error("tal_greedy_step_fwd: no result after 20 s (stream error: %s)", hipGetErrorString(hipStreamQuery(s)));
-                    return TAL_EHIP;
-                }
+            const int got = tal_greedy_step_poll(c, 20000);
+            if (got == 1) return TAL_OK;
+            if (got == 0) {
+                // nothing may stay in flight when the caller is told the step failed: it is free to release the pinned buffer
+                const hipError_t e = hipStreamSynchronize(s);
+                set_error("tal_greedy_step_fwd: no result after 20 s (stream after the wait: %s)", hipGetErrorString(e));
             }
-            std::atomic_thread_fence(std::memory_order_acquire);
-            return TAL_OK;
+            return TAL_EHIP;
         }
     } else {
     if (E0 > 0) {
@@ -1021,7 +1046,7 @@ extern "C" int tal_greedy_step_fwd(const tal_greedy_ctx* c, int64_t history_star
                            (int64_t)0, S, c->picked_dev, c->tokens + n_gen);
     TAL_CHECK_LAUNCH("tal_greedy_step_fwd(pick)");
     }
-    if (sync) {
+    if (sync) {       // (sync 2 without the merged kernels: the copy form)
         if (hipMemcpyAsync(c->picked_host, c->picked_dev, (size_t)(1 + S) * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) {
             set_error("tal_greedy_step_fwd: device-to-host copy failed: %s", hipGetErrorString(hipGetLastError()));

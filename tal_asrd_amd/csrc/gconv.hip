@@ -257,7 +257,7 @@ static int launch_generic(const float* x, const float* wp, const float* bias, fl
 }
 
 bool gconv_s2_can_split(int C_in, int C_out, int groups, const float* x) {
-    static const bool c1_generic = getenv("TAL_GCONV_C1_GENERIC") != nullptr;
+    const bool c1_generic = opt(OPT_GCONV_C1_GENERIC) != 0;
     return groups > 0 && C_in == groups && C_out == 10 * groups && groups % 20 == 0 && C_in % 4 == 0 && C_out % 32 == 0 &&
            (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !c1_generic;
 }
@@ -270,7 +270,7 @@ int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, i
     TAL_CHECK_ARG(B > 0 && T_in >= KS, "tal_gconv_s2_fwd: T_in=%lld shorter than the kernel", (long long)T_in);
     const int64_t T_out = (T_in - KS) / 2 + 1;
     const int cig = C_in / groups, cog = C_out / groups;
-    static const bool c1_generic = getenv("TAL_GCONV_C1_GENERIC") != nullptr;
+    const bool c1_generic = opt(OPT_GCONV_C1_GENERIC) != 0;
     if (cig == 1 && cog == 10 && groups % 20 == 0 && C_in % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !c1_generic) {
         // channel-major lanes: coalesced 256-byte stores (0.29 -> 0.16 ms on the 1-hour shape)
         constexpr int NG = 20, TT = 256, TTS = 32;
@@ -660,9 +660,6 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
                     oa = xa * s11 + oa;
                     ob = xb2 * s11 + ob;
                 }
-#ifdef GC_ABL_NOSTORE      // ablation build (scripts/build_ablation.sh): everything but the epilogue + stores
-                if (oa[0] != 12345.678f) continue;
-#endif
                 if (RESID && XSPLIT) {
                     // branch-free: every lane reads two channel pairs (a lane with fewer valid channels re-reads valid
                     // ones, r01 / r23 below), so its unused results stay ordinary finite activations
@@ -728,10 +725,6 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
                         }
                         _Float16* sp = ysplit + (((int64_t)b * T_out + t) * (C_out >> 5) + (cbase >> 5)) * 64 + (cbase & 31);
                         const f16x2 h01 = {h01p[0], h01p[1]}, l01 = {l01p[0], l01p[1]}, h23 = {h23p[0], h23p[1]}, l23 = {l23p[0], l23p[1]};
-#ifdef GC_ABL_ONE_STORE    // ablation build: the whole epilogue, ONE store instruction (wrong results; what do the others cost?)
-                        const f16x4u h4 = {h01[0] + l01[0], h01[1] + l01[1], h23[0] + l23[0], h23[1] + l23[1]};
-                        *reinterpret_cast<f16x4u*>(ysplit + (((int64_t)b * T_out + t) * (C_out >> 5)) * 64 + 4 * kg) = h4;
-#else
                         if (nvalid >= 4 && (cbase & 31) != 30) {
                             const f16x4u h4 = {h01[0], h01[1], h23[0], h23[1]}, l4 = {l01[0], l01[1], l23[0], l23[1]};
                             *reinterpret_cast<f16x4u*>(sp) = h4;
@@ -744,7 +737,6 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
                                 *reinterpret_cast<f16x2*>(sp + 66) = l23;
                             }
                         }
-#endif
                     }
                 }
             }
@@ -760,10 +752,7 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
         constexpr int CW = GB * COG, PW = CW % 8 == 0 ? 4 : 2, NPC = CW / (2 * PW), WPG = COG / 2, NPR = 2 * NPC;
         constexpr int RP = 256 / NPR, NPO = (TT + RP - 1) / RP;
         typedef unsigned u32xp __attribute__((ext_vector_type(PW)));
-        int nrows = (int)(T_out - t0 < (int64_t)TT ? T_out - t0 : (int64_t)TT);
-#ifdef GC_ABL_NOTAIL       // ablation build: the staged epilogue without its store phase
-        if (alpha != 12345.678f) nrows = 0;
-#endif
+        const int nrows = (int)(T_out - t0 < (int64_t)TT ? T_out - t0 : (int64_t)TT);
         const int r = tid / NPR, q = tid - r * NPR;
         const int a = q / NPC, p = q - a * NPC;          // a: 0 = hi halves, 1 = lo halves
         int wo[PW], wp[PW];                              // per word of the piece: LDS offset (halves) in row 0, row pitch

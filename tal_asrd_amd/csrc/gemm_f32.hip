@@ -571,25 +571,8 @@ __global__ __launch_bounds__(256, F16X3 ? 2 : 1) void gemm_glds_kernel(const Gem
         float* tile_ws = g.splitk_ws + ((size_t)(logical - g.tile_base) * g.split + slice) * (BM * BN);
         gemm_epilogue<0, NSUB>(gp, acc, lds, tile_ws - (m0 * BN + n0), nullptr, nullptr, m0, n0, lane, w, wm, wn);
     } else {
-#ifdef GEMM_ABL_NOEPI      // ablation build: no epilogue at all (what do set-up + K loop cost alone?)
-        {
-            float ssum = 0.f;      // (every accumulator stays live: 80 adds instead of an epilogue)
-#pragma unroll
-            for (int j = 0; j < NSUB; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) ssum += acc[j][e];
-            if (ssum == 12345.678f) Y[0] = ssum;
-        }
-#else
-#ifdef GEMM_ABL_STORESMALL  // ablation build: the tiles of every round store into the same 512 tile positions (42 MB: stays in the Infinity Cache)
-        const unsigned lt = logical % 512u;
-        const int64_t m0s = (int64_t)(lt / (unsigned)g.tiles_n) * BM;
-        if constexpr (EPI != 0) gemm_epilogue_split<MODE, NSUB>(g, acc, lds, Y, res, m0s, n0, lane, w);
-#else
         if constexpr (EPI != 0) gemm_epilogue_split<MODE, NSUB>(g, acc, lds, Y, res, m0, n0, lane, w);
-#endif
         else gemm_epilogue<MODE, NSUB>(g, acc, lds, Y, bias, res, m0, n0, lane, w, wm, wn);
-#endif
     }
 }
 
@@ -950,7 +933,7 @@ size_t gemm_splitk_ws_bytes() { return (size_t)SPLITK_MAX_SLICES * 128 * 160 * s
 template <int MODE, int NSUB, bool SPLITK>
 static void launch_glds_stage(const GemmArgs& g, dim3 grid, hipStream_t s) {
     // the buffer form of the operand loads (default) needs the tile's lane offsets to fit 32 bits
-    static const int want = getenv("TAL_GEMM_STAGE") ? atoi(getenv("TAL_GEMM_STAGE")) : 2;
+    const int want = opt(OPT_GEMM_GLOBAL_LOADS) ? 0 : 2;
     if (g.f16x3) {
         if constexpr (MODE == 1 || MODE == 2) {
             // the TDS block's layers: split-form output under the range guard (MODE 2: split-form residual too)
@@ -1020,9 +1003,8 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
     dim3 grid((unsigned)nb, (unsigned)nbatch);
     ProfScope prof(PROF_GEMM, 2.0 * (double)g.M * (double)g.N * (double)g.K * nbatch, s);
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) == 0;
-    // ablation switches, read once per process (a decode step is ~60 launches: no getenv on the launch path)
-    static const bool no_splitk4 = getenv("TAL_GEMM_NO_SPLITK4") != nullptr, no_glds = getenv("TAL_GEMM_NO_GLDS") != nullptr,
-                      no_tail = getenv("TAL_GEMM_NO_SPLITK_TAIL") != nullptr;
+    // measurement switches (tal_set_option; three relaxed atomic loads per launch)
+    const bool no_splitk4 = opt(OPT_GEMM_NO_SPLITK4) != 0, no_glds = opt(OPT_GEMM_NO_GLDS) != 0, no_tail = opt(OPT_GEMM_NO_SPLITK_TAIL) != 0;
     // small problems are latency-bound (a K step costs one L2 round trip, not its 16 MFMAs): a
     // 128-deep K slab quarters the number of dependent round trips
     if (small && mode != 4 && aligned16 && !no_splitk4) {

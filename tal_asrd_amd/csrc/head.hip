@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void head_argmax_kernel(const float* __rest
 bool head_argmax_applicable(int64_t M, int S, int E) {
     if (E != HK || S < HBN) return false;
     const int64_t units = cdiv(M, HBM) * cdiv(S, HBN);
-    static const bool no_astationary = getenv("TAL_HEAD_NO_ASTATIONARY") != nullptr;
+    const bool no_astationary = opt(OPT_HEAD_NO_ASTATIONARY) != 0;
     static int cus = 0;           // (one query per process: hipGetDeviceProperties costs tens of microseconds per call)
     if (!cus) {
         int dev = 0;

@@ -274,7 +274,7 @@ extern "C" int tal_logmel_plan_init(const float* window, const float* fb, void* 
         const double d = fabs((double)hwin[n] - (double)hwin[NFFT - n]) * 0.5;
         asym = d > asym ? d : asym;
     }
-    hp->folded = (hwin[0] == 0.f && asym <= 4e-7 * wmax && !getenv("TAL_LOGMEL_NO_FOLD")) ? 1 : 0;
+    hp->folded = (hwin[0] == 0.f && asym <= 4e-7 * wmax && !opt(OPT_LOGMEL_NO_FOLD)) ? 1 : 0;
     for (int j = 0; j < NTILE; ++j)
         for (int n = 0; n < NFOLD; ++n)
             for (int c = 0; c < 16; ++c) {

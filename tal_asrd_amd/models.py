@@ -53,6 +53,17 @@ def _htk_filterbank(n_freqs, n_mels, sample_rate, f_min=0.0, f_max=None):
     return torch.clamp(torch.min(falling, rising), min=0.0)
 
 
+# bumped whenever any nn.Module registers a Parameter (cached parameter lists compare against it, TDS._param_key)
+_PARAM_EPOCH = [0]
+
+
+def _note_parameter_registration(module, name, param):
+    _PARAM_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_note_parameter_registration)
+
+
 class _Spectrogram(nn.Module):
     def __init__(self, n_fft):
         super().__init__()
@@ -192,6 +203,7 @@ class TDS(nn.Module):
                                 for _ in range(depths[i - 1])]))
             for i in range(1, len(sizes))])
         self._plist = None
+        self._plist_epoch = -1
         self._descs = {}        # (first, last) -> tal_tds_desc
         self._packs = {}        # stage -> packed / split weights (kept alive here)
         self._desc_key = None   # parameter versions the caches were built for
@@ -200,10 +212,15 @@ class TDS(nn.Module):
         self._plist = None          # .to() / .cuda() may replace the Parameter objects
         return super()._apply(fn, *a, **kw)
 
+
     def _param_key(self):
         # (walking the module tree costs ~200 us per call, the cached list ~15 us: it matters for 30-second clips)
-        if self._plist is None:
+        # The list is rebuilt whenever ANY module registered a Parameter since it was taken (_PARAM_EPOCH: direct
+        # `layer.weight = nn.Parameter(...)` assignments and load_state_dict(assign=True) go through register_parameter)
+        # or this module was converted (_apply); in-place updates show in p._version, storage moves in data_ptr().
+        if self._plist is None or self._plist_epoch != _PARAM_EPOCH[0]:
             self._plist = list(self.parameters())
+            self._plist_epoch = _PARAM_EPOCH[0]
         return tuple((p.data_ptr(), p._version) for p in self._plist)
 
     def _stage_pack(self, s):

@@ -48,7 +48,7 @@ class _GreedySession:
     embedding / LM-head tensors, one workspace sized for the longest prefix, the {token, attention row} result buffer
     and its pinned host mirror.  `set_window` points it at the cached cross-attention K / V^T of an encoder window."""
 
-    def __init__(self, model, gen_dev, max_positions):
+    def __init__(self, model, gen_dev, max_positions, sync_mode=2):
         from . import decoder as D
         lib = N.lib()
         self.lib = lib
@@ -78,8 +78,7 @@ class _GreedySession:
         self.S = -1
         self.ws = None
         self._ctx_ref = C.byref(self.ctx)
-        import os
-        self._sync_mode = 1 if os.environ.get("TAL_GREEDY_COPY_SYNC") else 2    # 2: result written straight to pinned memory, polled
+        self._sync_mode = sync_mode      # 2: result written straight to pinned memory and polled; 1: copy command + stream wait
         self.set_tokens(gen_dev)
 
     def set_tokens(self, gen_dev):
@@ -106,12 +105,28 @@ class _GreedySession:
             self.picked_host = torch.zeros(2 + S, dtype=torch.float32).pin_memory()    # {token, row [S], sequence word}
             self.picked_np = self.picked_host.numpy()[:1 + S]
             c.picked_dev, c.picked_host = self.picked_dev.data_ptr(), self.picked_host.data_ptr()
+            c.picked_host_dev = None         # (the library resolves the new buffer's device alias on the next step)
 
     def step(self, history_start, n_gen):
         """-> (token, attention row [S] float32 copy); the token is also appended at gen_dev[n_gen] on the device."""
         rc = self.lib.tal_greedy_step_fwd(self._ctx_ref, history_start, n_gen, self._sync_mode, self._stream)
         if rc:
             N.check(rc, "tal_greedy_step_fwd")
+        return self.result()
+
+    # the same step in two halves, for a host thread that keeps several sessions (one stream each) in flight
+    def enqueue(self, history_start, n_gen):
+        rc = self.lib.tal_greedy_step_fwd(self._ctx_ref, history_start, n_gen, 3, self._stream)
+        if rc:
+            N.check(rc, "tal_greedy_step_fwd")
+
+    def ready(self, wait_ms=0):
+        got = self.lib.tal_greedy_step_poll(self._ctx_ref, wait_ms)
+        if got < 0:
+            N.check(got, "tal_greedy_step_poll")
+        return got == 1
+
+    def result(self):
         return int(self.picked_np[:1].view(np.int32)[0]), self.picked_np[1:].copy()
 
 

@@ -209,6 +209,10 @@ def aligned_to_wder(utterances, ep_sd_features, ep_sd_ids, num_ids=None, half_mo
             n = int(ids.max()) + 1 if num_ids is None else num_ids
             vid, _ = majority_vote(ids, [[st_frame, e_frame]], n)
             spk = int(vid[0])
+            if spk < 0:      # the reference: Counter([]).most_common(1)[0] -> IndexError (:332-333)
+                raise IndexError("aligned utterance [%.2f s, %.2f s) of episode %r lies outside the diarizer's %d frames: "
+                                 "no speaker id to vote on (the reference raises 'list index out of range' here)"
+                                 % (u_start, u_end, ep, int(ids.numel())))
         if hyp_dict.get("attention") is None and ep_sd_features:
             emb = feats[st_frame:e_frame]            # the reference's features are `.half()` (:313)
             emb = emb.half().float() if half_mode else emb

@@ -54,6 +54,35 @@ def main():
     else:
         assert ids is None and feat is None
 
+    # 3b) the planned form: plan built once, features + ids in ONE collective per call (ids bit-cast into an extra column),
+    #     re-used for a second call with other values
+    plan = D.SegmentGather({i: lengths[i] for i in mine}, n, trailing=(9,), dtype=torch.float32, device="cpu", dst=0)
+    for rep in range(2):
+        packed_local = {i: D.pack_feat_ids(feat_local[i] + rep, ids_local[i]) for i in mine}
+        got = plan.gather(packed_local)
+        if rank == 0:
+            for i in range(n):
+                want_ids, want_feat = fake_segment_result(i, lengths[i])
+                f, d = D.unpack_feat_ids(got[i])
+                assert torch.equal(f, want_feat + rep) and torch.equal(d, want_ids), (rep, i)
+        else:
+            assert got is None
+    # 3c) a rank WITHOUT items needs no `like`, and learns shape / dtype from the others
+    solo = D.gather_segments({0: torch.full((3, 2), 7.0)} if rank == 1 else {}, 1, dst=0)
+    if rank == 0:
+        assert solo[0].shape == (3, 2) and float(solo[0].min()) == 7.0
+    # 3d) inconsistent calls fail on EVERY rank (nobody is left inside a collective): an item nobody holds, an item two
+    #     ranks claim
+    for bad in ({0: 4} if rank == 0 else {}, {0: 4, 1: 4} if rank == 0 else {1: 4}):
+        try:
+            D.SegmentGather(bad, 2 if rank == 0 or len(bad) else 2, trailing=(1,) if bad else None,
+                            dtype=torch.float32 if bad else None, device="cpu")
+        except RuntimeError as e:
+            assert "SegmentGather" in str(e)
+        else:
+            raise AssertionError("inconsistent gather plan accepted on rank %d" % rank)
+    dist.barrier()
+
     # 4) one reference "call" split across ranks: the global log-mel mean via (sum, count)
     full = torch.arange(24, dtype=torch.float64).reshape(2, 3, 4)   # the [B, T, 80]-like tensor of one call
     part = full[rank]

@@ -505,11 +505,97 @@ def unit_pool(ns):
     print("wrote pool_unit.npz / pool_unit.json")
 
 
+def unit_aligned(ns):
+    """The ALIGNED branch of tal/utils/aligned_to_wder_format.py (:294-379), run as the script it is WITHOUT --unaligned on
+    a small test_result.pkl: reference utterances with utterance_start / utterance_end, hypotheses with and without a
+    speakerId (-> Counter(...).most_common(1) over the separate diarizer's ids[st_frame:e_frame]), with and without
+    attention (-> attention-weighted pooling vs the plain feature slice), an example whose hypotheses are all empty (skipped)
+    and examples out of time order (the script sorts by utterance_start).  Records inputs and the script's pickle."""
+    install_text_standins(ns)
+    work = os.path.join(CACHE, "work_aligned_unit")
+    os.makedirs(work, exist_ok=True)
+    p = lambda n: os.path.join(work, n)
+    rng = np.random.RandomState(11)
+    eps = {"ep-a": 1500, "ep-b": 900}
+    feats = {e: rng.randn(T, 128).astype(np.float32) for e, T in eps.items()}
+    ids = {}
+    for e, T in eps.items():          # piecewise-constant speaker ids with noise, so that votes have ties and clear winners
+        base = np.repeat(rng.randint(0, 6, size=T // 50 + 1), 50)[:T]
+        noise = rng.randint(0, 6, size=T)
+        ids[e] = np.where(rng.rand(T) < 0.3, noise, base).astype(np.int32)
+    examples, meta = [], []
+    spans = [("ep-a", 61.3, 70.9), ("ep-a", 3.0, 11.52), ("ep-b", 0.0, 0.5), ("ep-a", 100.0, 100.9), ("ep-b", 40.07, 52.2),
+             ("ep-a", 20.5, 33.0), ("ep-b", 10.0, 25.0), ("ep-a", 110.0, 118.0)]
+    for k, (e, st, en) in enumerate(spans):
+        ref = {"episode": e, "utterance": "ref words number %d here" % k, "speaker": 100 + k % 3, "role": "host" if k % 2 else "guest",
+               "utterance_start": st, "utterance_end": en}
+        T = eps[e]
+        hyp = {"utterance": "hyp words of example %d" % k, "speakerId": (7 if k % 4 == 1 else None)}
+        if k % 2 == 0:                      # attention-weighted pooling over ntok tokens
+            ntok = 3 + k
+            attn = rng.rand(ntok, 357).astype(np.float32) ** 5
+            attn /= attn.sum(-1, keepdims=True)
+            cs = np.sort(rng.randint(0, T - 357, size=ntok)).astype(np.int64)
+            hyp["attention"] = torch.from_numpy(attn)
+            hyp["chunkStart"] = torch.from_numpy(cs)
+        hyps = [hyp]
+        if k == 3:
+            hyps = [{"utterance": "   ", "speakerId": None}, hyp]            # an empty hypothesis beside the valid one
+        if k == 7:
+            hyps = [{"utterance": "", "speakerId": None}]                    # nothing valid: the example contributes a reference only
+        examples.append(([ref], hyps))
+        meta.append({"episode": e, "utterance_start": st, "utterance_end": en, "ref_utterance": ref["utterance"], "ref_speaker": ref["speaker"],
+                     "role": ref["role"], "hyps": [{"utterance": h["utterance"], "speakerId": h["speakerId"],
+                                                    "has_attention": "attention" in h} for h in hyps]})
+    with open(p("test_result.pkl"), "wb") as f:
+        pickle.dump(examples, f)
+    with open(p("hyp_speaker_ids.pkl"), "wb") as f:
+        pickle.dump({e: v.tolist() for e, v in ids.items()}, f)
+    with open(p("hyp_speaker_features.pkl"), "wb") as f:
+        pickle.dump(feats, f)
+    with open(p("role_map.json"), "w") as f:
+        json.dump({"0": "host"}, f)
+    argv = ["aligned_to_wder_format", "--in-file", p("test_result.pkl"), "--out-file", p("wder_ready_aligned.pkl"),
+            "--speaker-id-hyp", p("hyp_speaker_ids.pkl"), "--speaker-feat-hyp", p("hyp_speaker_features.pkl"),
+            "--role-map", p("role_map.json"), "--cache-path", "unused", "--workers", "1"]          # no --unaligned
+    real_device, old = torch.device, sys.argv
+    sys.argv = argv
+    torch.device = lambda *a, **k: real_device("cpu")      # the script hard-codes torch.device('cuda')
+    try:
+        runpy.run_path(os.path.join(REF, "tal/utils/aligned_to_wder_format.py"), run_name="__main__")
+    finally:
+        torch.device = real_device
+        sys.argv = old
+    with open(p("wder_ready_aligned.pkl"), "rb") as f:
+        wder_input = pickle.load(f)
+    arrays = {}
+    for e in eps:
+        arrays["feat_" + e] = feats[e]
+        arrays["ids_" + e] = ids[e]
+    for k, (_, hyps) in enumerate(examples):
+        for h in hyps:
+            if "attention" in h:
+                arrays["attn_%d" % k] = h["attention"].numpy()
+                arrays["cs_%d" % k] = h["chunkStart"].numpy()
+    out = []
+    for gi, (refs, hyps) in enumerate(wder_input):
+        rec = {"refs": [[u, s, r] for u, s, r in refs], "hyps": []}
+        for hi, (u, (emb, spk), r) in enumerate(hyps):
+            arrays["out_emb_%d_%d" % (gi, hi)] = emb.float().numpy()
+            rec["hyps"].append({"utterance": u, "speaker": int(spk), "role": r, "emb_dtype": str(emb.dtype).replace("torch.", "")})
+        out.append(rec)
+    np.savez_compressed(os.path.join(HERE, "aligned_unit.npz"), **arrays)
+    with open(os.path.join(HERE, "aligned_unit.json"), "w") as f:
+        json.dump({"examples": meta, "episodes": list(eps), "wder_input": out}, f, indent=1)
+    print("wrote aligned_unit.npz / aligned_unit.json:", [(len(r["refs"]), len(r["hyps"])) for r in out])
+
+
 if __name__ == "__main__":
     if "--unit" in sys.argv:
         ns = load_reference()
         unit_wder(ns)
         unit_pool(ns)
+        unit_aligned(ns)
         sys.exit(0)
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=3600.0)

@@ -48,7 +48,7 @@ def test_struct_layout_matches_header():
     expect += 8                              # flags + pad
     assert C.sizeof(_native.TdsDesc) == expect
     assert _native.TdsDesc.flags.offset == expect - 8
-    assert C.sizeof(_native.GreedyCtx) == 8 + 8 * 4 + 8 * 8 + 8 + 8 + 3 * 8    # pointer, 8 ints, 8 pointers, workspace + size, 3 pointers
+    assert C.sizeof(_native.GreedyCtx) == 8 + 8 * 4 + 8 * 8 + 8 + 8 + 3 * 8 + 8 + 8    # pointer, 8 ints, 8 pointers, workspace + size, 3 pointers, device alias, seq + pad
 
 
 def test_error_path_no_gpu_needed():
@@ -122,3 +122,31 @@ def test_synth_is_deterministic():
     w = synth.fill_state_dict({"x.weight": (4, 8), "x.bias": (4,), "b.resweight": (1,)})
     assert w["x.weight"].shape == (4, 8) and 0.2 <= float(w["b.resweight"][0]) <= 0.32
     assert abs(w["x.weight"]).max() <= 1 / np.sqrt(8)
+
+
+def test_options_are_explicit_calls_not_environment():
+    """Kernel-selection switches are tal_set_option calls (an environment variable must not change which
+    kernels a caller of the C ABI gets): names enumerate, unknown names are errors, and no source of the shipped library
+    reads the environment."""
+    import ctypes as C
+    import glob
+    from tal_asrd_amd import _native as N
+    lib = N.lib()
+    names = []
+    i = 0
+    while True:
+        nm = lib.tal_option_name(i)
+        if not nm:
+            break
+        names.append(nm.decode())
+        i += 1
+    assert "tds_exact_f32" in names and "decode_small_rows" in names and len(names) == len(set(names))
+    assert N.get_option("tds_exact_f32") == 0 and N.get_option("decode_small_rows") == 256
+    N.set_option("tds_exact_f32", 1)
+    assert N.get_option("tds_exact_f32") == 1
+    N.set_option("tds_exact_f32", 0)
+    assert lib.tal_set_option(b"no_such_option", 1) != 0
+    assert b"unknown option" in lib.tal_last_error()
+    assert lib.tal_version() >= 300
+    for src in glob.glob(os.path.join(ROOT, "tal_asrd_amd", "csrc", "*")):
+        assert "getenv" not in open(src).read(), src

@@ -112,3 +112,53 @@ def test_pool_and_vote_fp32_match_numpy():
             continue
         best = max(tot.items(), key=lambda kv: kv[1])
         assert int(gid[k]) == best[0] and abs(float(gw[k]) - best[1]) < 1e-9
+
+
+def test_aligned_to_wder_matches_reference():
+    """The ALIGNED branch (tal/utils/aligned_to_wder_format.py:294-379) against the pickle the reference script itself
+    wrote for the same test_result.pkl (tests/golden/aligned_unit.*, make_golden_episode.py --unit): per episode the
+    references and hypotheses in the script's order (sorted by utterance_start), texts / roles / speaker ids identical --
+    given ids and Counter(...).most_common(1) votes over ids[st_frame:e_frame] alike -- and the embeddings (attention
+    pooling or the plain feature slice, both in the reference's half precision) within one fp16 ulp."""
+    from tal_asrd_amd.wder_format import aligned_to_wder
+    g = golden("aligned_unit")
+    with open(os.path.join(GOLDEN, "aligned_unit.json")) as f:
+        meta = json.load(f)
+    feats = {e: torch.from_numpy(g["feat_" + e]).to(_dev()) for e in meta["episodes"]}
+    ids = {e: torch.from_numpy(g["ids_" + e]).to(_dev()) for e in meta["episodes"]}
+    utterances = []
+    for k, ex in enumerate(meta["examples"]):
+        ref = {"episode": ex["episode"], "utterance": ex["ref_utterance"], "speaker": ex["ref_speaker"], "role": ex["role"],
+               "utterance_start": ex["utterance_start"], "utterance_end": ex["utterance_end"]}
+        hyps = []
+        for h in ex["hyps"]:
+            d = {"utterance": h["utterance"], "speakerId": h["speakerId"]}
+            if h["has_attention"]:
+                d["attention"] = torch.from_numpy(g["attn_%d" % k])
+                d["chunkStart"] = torch.from_numpy(g["cs_%d" % k])
+            hyps.append(d)
+        utterances.append(([ref], hyps))
+    got = aligned_to_wder(utterances, feats, ids, num_ids=6)
+    assert len(got) == len(meta["wder_input"])
+    n_votes = 0
+    for gi, ((refs, hyps), want) in enumerate(zip(got, meta["wder_input"])):
+        assert [[u, s, r] for u, s, r in refs] == want["refs"]
+        assert len(hyps) == len(want["hyps"])
+        for hi, ((u, (emb, spk), r), w) in enumerate(zip(hyps, want["hyps"])):
+            assert (u, int(spk), r) == (w["utterance"], w["speaker"], w["role"]), (gi, hi)
+            n_votes += w["speaker"] != 7
+            ref_emb = g["out_emb_%d_%d" % (gi, hi)]
+            assert tuple(emb.shape) == ref_emb.shape, (gi, hi)
+            np.testing.assert_allclose(emb.float().numpy(), ref_emb, rtol=HALF_ULP, atol=2.0 ** -24)
+    assert n_votes >= 3          # the fixture exercises the majority-vote fallback, not only given ids
+
+
+def test_aligned_vote_outside_the_episode_raises_like_the_reference():
+    """ids[st_frame:e_frame] empty -> the reference's Counter([]).most_common(1)[0] raises IndexError; the counterpart must
+    not hand the scorer a speaker id of -1."""
+    from tal_asrd_amd.wder_format import aligned_to_wder
+    feats = {"e": torch.zeros(100, 128, device=_dev())}
+    ids = {"e": torch.zeros(100, dtype=torch.int32, device=_dev())}
+    ref = {"episode": "e", "utterance": "a b", "speaker": 1, "role": "host", "utterance_start": 50.0, "utterance_end": 55.0}
+    with pytest.raises(IndexError):
+        aligned_to_wder([([ref], [{"utterance": "a b", "speakerId": None}])], feats, ids, num_ids=4)

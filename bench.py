@@ -406,6 +406,26 @@ def main():
         h2d_ms = 1e3 * (time.perf_counter() - t_h)
         del _tmp, host
 
+    # The same path fed from HOST memory as a stream of clips (the reference's loop over episodes, reconcile.py:96-102): the
+    # upload of clip i + 1 runs on a copy stream under the compute of clip i (SDModel.speaker_ids_stream)
+    streamed = None
+    if rank == 0 and args.workload == "clip" and not fake and world == 1:
+        host = clips[0].cpu().pin_memory()
+        n_stream = 4
+        with torch.no_grad():
+            for _ in model.speaker_ids_stream([host] * 2):
+                pass
+            sync()
+            t_s = time.perf_counter()
+            for _ in model.speaker_ids_stream([host] * n_stream):
+                pass
+            sync()
+            dt_s = time.perf_counter() - t_s
+        streamed = {"clips": n_stream, "value": n_stream * clips[0].shape[0] * frames / dt_s, "unit": "frames/s",
+                    "ms_per_clip": 1e3 * dt_s / n_stream,
+                    "what": "%d clips from pinned host memory, upload of the next clip on a copy stream under the compute of the current one" % n_stream}
+        del host
+
     # ------------------------------------------------------------------ timed region
     def timed_pass(with_prof):
         sync()
@@ -554,6 +574,9 @@ def main():
             tot = sum(k["ms_total"] for k in kern.values())
             line["kernel_time_share"] = {k: (v["ms_total"] / tot if tot else 0.0) for k, v in kern.items()}
             line["kernel_ms_per_step"] = {k: v["ms_total"] / args.steps for k, v in kern.items()}
+        if streamed is not None:
+            streamed["fraction_of_resident_value"] = streamed["value"] / line["value"]
+            line["stream_of_clips_from_host"] = streamed
         if h2d_ms is not None:
             line["h2d_ms_per_clip"] = h2d_ms
             line["value_including_h2d"] = total_frames / (elapsed + 1e-3 * h2d_ms * args.segments * args.steps)

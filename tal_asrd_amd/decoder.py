@@ -191,6 +191,25 @@ def _stack_kv(stack, memory):
     return cached[1], cached[2]
 
 
+def stack_kv_private(stack, memory):
+    """The same K / V^T pointer arrays, owned by the caller: (karr, varr, keep-alive list).  The cached form above keeps ONE
+    window per stack; several decode sessions over the same weights (System.transcribe_unaligned_many) each hold their own."""
+    lib = N.lib()
+    B, S, E = memory.shape
+    ks, vts = [], []
+    for layer in stack.layers:
+        k = torch.empty(B, S, E, dtype=torch.float32, device=memory.device)
+        vt = torch.empty(B, E, lib.tal_pad4(S), dtype=torch.float32, device=memory.device)
+        N.check(lib.tal_cross_kv_fwd(C.byref(layer_weights(layer)), N.ptr(memory), B, S, E, N.ptr(k), N.ptr(vt),
+                                     N.stream_handle()), "tal_cross_kv_fwd")
+        ks.append(k)
+        vts.append(vt)
+    n = len(ks)
+    karr = (C.c_void_p * n)(*[k.data_ptr() for k in ks])
+    varr = (C.c_void_p * n)(*[v.data_ptr() for v in vts])
+    return karr, varr, (ks, vts, memory)
+
+
 def _run_stack(model, stack, y_prev, memory, mask, causal, check_tokens=True):
     """embedding -> all decoder layers (one C call) -> hidden [B,U,E]; sets layer.src_attn_weights."""
     lib = N.lib()

@@ -217,12 +217,10 @@ class RangeCheck:
         range_fallbacks += 1
         lib = N.lib()
         B, T, _ = self.x.shape
-        self.desc.flags |= N.TAL_TDS_EXACT_F32
-        try:
-            N.check(lib.tal_tds_fwd(C.byref(self.desc), N.ptr(self.x), B, T, N.ptr(self.y), N.ptr(self.ws), self.nws,
-                                    N.stream_handle()), "tal_tds_fwd (exact fp32 re-run)")
-        finally:
-            self.desc.flags &= ~N.TAL_TDS_EXACT_F32
+        exact = N.TdsDesc.from_buffer_copy(self.desc)       # (a copy: the cached descriptor may be in use by another thread's call)
+        exact.flags |= N.TAL_TDS_EXACT_F32
+        N.check(lib.tal_tds_fwd(C.byref(exact), N.ptr(self.x), B, T, N.ptr(self.y), N.ptr(self.ws), self.nws,
+                                N.stream_handle()), "tal_tds_fwd (exact fp32 re-run)")
         return self.y
 
 

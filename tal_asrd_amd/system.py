@@ -21,6 +21,7 @@ The half-precision casts (`force_half`, system.py:92,285) are accepted and ignor
 path computes in fp32 (BASELINE.json: logits within 1e-3 of the fp32 CPU path).
 """
 import ctypes as C
+import threading
 from types import SimpleNamespace
 
 import numpy as np
@@ -89,7 +90,8 @@ class _GreedySession:
         from . import decoder as D
         mem, mask = window["encoder_out"], window["encoder_padding_mask"]
         D._check_memory(mem, 1, self.ctx.E, "generate_unaligned")
-        self._kv = D._stack_kv(self.model.decoder, mem)            # (K pointer array, V^T pointer array), cached per window
+        # K / V^T of the window for every layer, owned by this session (several sessions share one set of weights)
+        self._kv = D.stack_kv_private(self.model.decoder, mem)
         self.ctx.k_cache = C.cast(self._kv[0], C.c_void_p)
         self.ctx.vt_cache = C.cast(self._kv[1], C.c_void_p)
         self._kpm = D._kpm_u8(mask, 1, mem.shape[1], self.dev)
@@ -140,6 +142,68 @@ class System:
         self.tokenizer = tokenizer if tokenizer is not None else SimpleNamespace(
             eos_token_id=eos_token_id, bos_token_id=bos_token_id, pad_token_id=pad_token_id)
         self.lm = None
+        # the module API keeps per-call results on the modules themselves (layer.src_attn_weights, the cached window K / V^T):
+        # sections that go through it are serialised; the per-token C call of a decode session needs no lock
+        self._lock = threading.RLock()
+
+    # ------------------------------------------------------------------ several episodes in flight
+    @torch.no_grad()
+    def transcribe_unaligned_many(self, episodes, streams=4, **kw):
+        """`transcribe_unaligned` over a list of episodes with up to `streams` decode sessions in flight -- the loop the
+        reference runs this path in (tal/asr/system.py:625-742 per test item, one after the other): each session is the
+        ordinary sliding-window decode on its own HIP stream with its own context (prefix buffer, workspace, window K / V^T,
+        pinned result word); they share the weights.  One host thread per session: the per-token C call runs without the
+        interpreter lock, so the launch work of the sessions overlaps, and a decode step (a chain of ~35 small dependent
+        kernels on a few dozen CUs) of one session runs beside the others' on the chip.  An episode's waveform is uploaded
+        on its session's stream (pinned host memory: the copy runs under the other sessions' compute).
+
+        episodes: list of (audio [1, L] float tensor -- host (pinned or not) or device --, audio_lens LongTensor [1]).
+        Returns [(utterance dicts, generated, alignments)] in episode order, identical to the solo runs."""
+        if not episodes:
+            return []
+        dev = next(self.model.parameters()).device
+        # everything the sessions share is built once, on the caller's stream, before any of them starts
+        first_audio = episodes[0][0]
+        with self._lock:
+            warm = first_audio[:, :min(first_audio.shape[1], 16000 * 40)].to(dev).float()
+            self.model.encode(warm, torch.tensor([warm.shape[1]]))
+            from . import decoder as D
+            D._stack_structs(self.model.decoder)
+            if self.model.embed_size:
+                D._proj_t(self.model)
+        torch.cuda.synchronize(dev)
+        results = [None] * len(episodes)
+        errors = []
+        nxt = [0]
+        take = threading.Lock()
+
+        def worker():
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.device(dev), torch.cuda.stream(stream):
+                while True:
+                    with take:
+                        i = nxt[0]
+                        nxt[0] += 1
+                    if i >= len(episodes) or errors:
+                        return
+                    try:
+                        audio, lens = episodes[i]
+                        x = audio.to(dev, non_blocking=True)
+                        results[i] = self.transcribe_unaligned(x, lens, **kw)
+                        stream.synchronize()
+                    except BaseException as e:      # noqa: B902 -- reported to the caller below
+                        errors.append((i, e))
+                        return
+
+        threads = [threading.Thread(target=worker, daemon=True) for _ in range(max(1, min(int(streams), len(episodes))))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            i, e = errors[0]
+            raise RuntimeError("transcribe_unaligned_many: episode %d failed: %r" % (i, e)) from e
+        return results
 
     # ------------------------------------------------------------------ episode -> utterance dicts
     @torch.no_grad()
@@ -257,7 +321,8 @@ class System:
             raise ValueError("generate_unaligned handles one episode at a time (system.py:331,411 call .item())")
         dev = audio_x.device
         max_positions = model.max_positions if max_positions is None else max_positions
-        encoder_out = model.encode(audio_x.float(), audio_lens)
+        with self._lock:
+            encoder_out = model.encode(audio_x.float(), audio_lens)
         enc, mask = encoder_out["encoder_out"], encoder_out["encoder_padding_mask"]
         encoder_len = int((~mask).sum(dim=-1).cpu().item())
         eos = self.tokenizer.eos_token_id
@@ -306,13 +371,14 @@ class System:
                 # first step through the module API: validates the priming tokens (nn.Embedding raises on out-of-range
                 # ids) and the logits (system.py:363-364)
                 y = gen_dev[history_start:n_gen].view(1, -1)
-                logits = asr_decode(model, y, window, causal=False, last_only=True, check_tokens=True)  # [1, V]
+                with self._lock:     # (the module API leaves its attention weights on the decoder module)
+                    logits = asr_decode(model, y, window, causal=False, last_only=True, check_tokens=True)  # [1, V]
+                    all_w = model.decoder.src_attn_weights_all                              # [n_layers, B, U, S]
                 if bool(torch.isnan(logits).any()):
                     raise Exception("Logits contain nans!")
                 # token = argmax(log_softmax(logits)) and the attention of the new token averaged over layers (heads
                 # are already averaged by the softmax kernel): one launch, one D2H copy (system.py:366-399 does the
                 # same arithmetic with a log_softmax, an argmax, a .cpu() per quantity and a numpy mean)
-                all_w = model.decoder.src_attn_weights_all                                  # [n_layers, B, U, S]
                 S_w = all_w.shape[-1]
                 picked = torch.empty(1 + S_w, dtype=torch.float32, device=dev)
                 N.check(N.lib().tal_greedy_pick_fwd(N.ptr(logits), logits.shape[-1], N.ptr(all_w[0, 0, -1]), all_w.shape[0],

@@ -107,3 +107,31 @@ def test_episode_wder_identical(episode):
     owder, ower, _, dists, ns = W.corpus_wder(strip_roles(out))
     assert (owder, ower) == (float(g["wder_word"]), float(g["wer_word"]))
     assert dists == g["asr_dist"].tolist() and ns == g["n_words"].tolist()
+
+
+def test_sessions_in_flight_reproduce_their_solo_runs(asr_weights):
+    """System.transcribe_unaligned_many: several decode sessions on their own HIP streams, sharing one set of weights, driven
+    by one host thread each.  Every episode's token stream, window starts and attention rows equal its solo run exactly
+    (the sessions share nothing but read-only weights), whatever the number of sessions in flight."""
+    from tal_asrd_amd import ASRModel, synth
+    from tal_asrd_amd.system import System
+    from tal_asrd_amd.tokenizer import SynthTokenizer
+    dev = torch.device("cuda:0")
+    asr = _load(ASRModel("2x", num_speakers=6008, vocab_size=10000, use_speaker_head=True), asr_weights, dev)
+    system = System(asr, tokenizer=SynthTokenizer(10000))
+    eps = []
+    for k, seconds in enumerate((95, 140, 60, 120, 45)):
+        L = seconds * 16000
+        a = synth.synth_audio_batch(1, L, 2469 + k).astype(np.float16).astype(np.float32)
+        eps.append((torch.from_numpy(a).pin_memory(), torch.tensor([L])))
+    solo = [system.transcribe_unaligned(a.to(dev), lens) for a, lens in eps]
+    for streams in (2, 5):
+        many = system.transcribe_unaligned_many(eps, streams=streams)
+        assert len(many) == len(solo)
+        for (u1, g1, al1), (u2, g2, al2) in zip(solo, many):
+            assert torch.equal(g1.cpu(), g2.cpu())
+            assert [int(c[0]) for c, _ in al1] == [int(c[0]) for c, _ in al2]
+            for (_, a1), (_, a2) in zip(al1, al2):
+                assert torch.equal(a1, a2)
+            assert [u["utterance"] for u in u1] == [u["utterance"] for u in u2]
+    assert sum(g.shape[1] for _, g, _ in solo) > 300          # the episodes do generate

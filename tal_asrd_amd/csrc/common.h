@@ -105,6 +105,7 @@ enum Option {
     OPT_GEMM_NO_SPLITK4,          // short problems (M <= 512) on the register-staged tile instead of the split-K-in-workgroup kernel
     OPT_GEMM_NO_GLDS,             // large problems on the register-staged kernel instead of the LDS-DMA kernel
     OPT_GEMM_NO_SPLITK_TAIL,      // no K slices for the tiles of the last partial scheduling round
+    OPT_GEMM_NO_W64,              // fp16x3 layers on the 128 x 160 kernel (2 workgroups per CU) instead of the 256 x 160 one (1 wave per SIMD)
     OPT_LOGMEL_NO_FOLD,           // plans built afterwards use the direct 400-term DFT (no symmetric-window folding)
     OPT_DECODE_NO_SMALL,          // decoder layers on the batched-GEMM path even for a decode step
     OPT_DECODE_SMALL_ROWS,        // largest prefix (rows) the latency-oriented decoder layer takes (default 256)
@@ -161,6 +162,8 @@ struct GemmArgs {
 };
 // mode 0: acc+b | 1: relu(acc+b) | 2: res + alpha*(acc+b) | 3: alpha*(acc+b) | 4: row arg-max partials of acc+b
 int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s);
+// fp16x3 layer on 256 x 160 tiles, one wave per SIMD (gemm_w64.hip); splitk: grid = [whole tiles | K slices of the tail tiles]
+void launch_gemm_w64(const GemmArgs& g, int mode, bool splitk, dim3 grid, hipStream_t s);
 int gemm_mode4_partials(int64_t M, int N);
 
 // internal launchers shared between translation units

@@ -191,6 +191,64 @@ def test_linear_f16x3_pair_matches_fp64(M, C, K):
     assert float(np.abs(hdec - h.cpu().numpy()).max()) < 2e-5 * max(1.0, K ** 0.5 / 8)
 
 
+@pytest.mark.parametrize("M,C", [(256 * 40 + 3, 1440), (256 * 71, 800)])
+def test_linear_f16x3_256_row_kernel_equals_128_row_kernel(M, C):
+    """The one-wave-per-SIMD kernel (csrc/gemm_w64.hip, 256 x 160 tiles) keeps the 128 x 160 kernel's arithmetic order per
+    accumulator: with the K-sliced tail switched off the two produce BIT-IDENTICAL outputs -- fp32 and split form, relu layer
+    and split-residual layer under the range guard -- and with their (differently cut) tails they agree to fp32 rounding."""
+    import ctypes as CT
+    from tal_asrd_amd import ops, _native as N_
+    lib = N_.lib()
+    g = torch.Generator().manual_seed(M + C)
+    K = C
+    x = torch.randn(M, K, generator=g).to(dev())
+    w0 = (torch.randn(C, K, generator=g) / K ** 0.5).to(dev())
+    b0 = torch.randn(C, generator=g).to(dev())
+    xs, w0s = ops.split_f16x3(x), ops.split_f16x3(w0)
+    nws = lib.tal_linear_workspace_bytes(M, C, K)
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev())
+    flag = torch.zeros(16, dtype=torch.int32, device=dev())
+
+    def run(mode, out_split, guarded):
+        y = torch.zeros(M * C * 4, dtype=torch.uint8, device=dev())
+        if guarded:
+            N_.check(lib.tal_linear_f16x3_guarded_fwd(N_.ptr(xs), N_.ptr(w0s), N_.ptr(b0), N_.ptr(xs) if mode == 2 else None, 1 if mode == 2 else 0,
+                                                      0.3, mode, M, C, K, N_.ptr(y), out_split, N_.ptr(flag), N_.ptr(ws), nws, N_.stream_handle()),
+                     "tal_linear_f16x3_guarded_fwd")
+        else:
+            N_.check(lib.tal_linear_f16x3_fwd(N_.ptr(xs), N_.ptr(w0s), N_.ptr(b0), N_.ptr(x) if mode == 2 else None, 0.3, mode, M, C, K, N_.ptr(y),
+                                              out_split, N_.ptr(ws), nws, N_.stream_handle()), "tal_linear_f16x3_fwd")
+        torch.cuda.synchronize()
+        return y
+
+    def decode(y, out_split):
+        if not out_split:
+            return y.view(torch.float32).reshape(M, C)
+        h = y.view(torch.float16).reshape(M, C // 32, 64).float()
+        return (h[:, :, :32] + h[:, :, 32:] / 2048.0).reshape(M, C)
+
+    cases = [(1, 0, False), (2, 0, False), (1, 1, True), (2, 1, True), (2, 0, True)]
+    try:
+        N_.set_option("gemm_no_splitk_tail", 1)
+        for mode, out_split, guarded in cases:
+            N_.set_option("gemm_no_w64", 0)
+            a = run(mode, out_split, guarded)
+            N_.set_option("gemm_no_w64", 1)
+            b = run(mode, out_split, guarded)
+            assert torch.equal(a, b), (mode, out_split, guarded)
+        N_.set_option("gemm_no_splitk_tail", 0)
+        for mode, out_split, guarded in cases:
+            N_.set_option("gemm_no_w64", 0)
+            a = decode(run(mode, out_split, guarded), out_split)
+            N_.set_option("gemm_no_w64", 1)
+            b = decode(run(mode, out_split, guarded), out_split)
+            assert float((a - b).abs().max()) < 2e-5, (mode, out_split, guarded)
+    finally:
+        N_.set_option("gemm_no_w64", 0)
+        N_.set_option("gemm_no_splitk_tail", 0)
+    assert int(flag[0]) == 0
+
+
 def test_linear_identity_asymmetric():
     """A = I against an asymmetric W catches a transposed C write."""
     from tal_asrd_amd import ops

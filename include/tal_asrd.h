@@ -211,6 +211,21 @@ size_t tal_tds_status_offset(const tal_tds_desc* d, int B, int64_t T);
 int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t T, float* y,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* Time-tiled form of the same call for ONE item (SURVEY.md section 8b `halo_mode`): the input is cut into tiles of
+ * `out_tile` output frames; each tile runs as its own tal_tds_fwd over the slice of x that carries its receptive-field halo
+ * (tal_tds_halo: output frame t reads the input frames [stride t - left, stride t + right]; 640 / 780 / 8 for the 2 / 3 / 6
+ * block stack) and reproduces its frames as the whole sequence would -- slices start at multiples of the stride, and at a
+ * true end of the sequence the blocks' zero padding is the same in the slice.  For items beyond the 2 GiB-per-item limit
+ * of the fp16x3 kernels' 32-bit offsets (~3.7 h of audio), which would otherwise take the generic kernels, and for
+ * bounding the workspace.  The fp16-range status word of the whole call (OR over the tiles) sits at
+ * tal_tds_tiled_status_offset() bytes of the workspace; a caller that finds it raised re-runs with TAL_TDS_EXACT_F32. */
+int tal_tds_halo(const tal_tds_desc* d, int64_t* left, int64_t* right, int64_t* stride);
+size_t tal_tds_tiled_workspace_bytes(const tal_tds_desc* d, int64_t T, int64_t out_tile);
+size_t tal_tds_tiled_status_offset(const tal_tds_desc* d, int64_t T, int64_t out_tile);
+/* x [1, T, channels[0]] -> y [1, T', channels[n_stages]] */
+int tal_tds_tiled_fwd(const tal_tds_desc* d, const float* x, int64_t T, float* y, int64_t out_tile,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ *
  * Diarization head: SDModel.decode + reconcile.get_speaker_ids,
  * tal/asr/models.py:473-481, tal/baseline/reconcile.py:76-85.

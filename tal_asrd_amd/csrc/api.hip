@@ -506,6 +506,124 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
     return TAL_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Time-tiled encoder (SURVEY section 8b `halo_mode`): one long item as tiles with the receptive-field halo
+// ---------------------------------------------------------------------------------------
+// Output frame t of the stack reads the input frames [stride t - left, stride t + right]: per stage (from the last one
+// down) `depth` TDSBlocks of +-10 frames at that resolution, below them the stride-2 k = 21 conv (frame u reads [2 u, 2 u + 20]).
+extern "C" int tal_tds_halo(const tal_tds_desc* d, int64_t* left, int64_t* right, int64_t* stride) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    int64_t lo = 0, hi = 0, st = 1;
+    for (int i = d->n_stages - 1; i >= 0; --i) {
+        lo -= (int64_t)d->depths[i] * 10;
+        hi += (int64_t)d->depths[i] * 10;
+        lo = 2 * lo;
+        hi = 2 * hi + 20;
+        st *= 2;
+    }
+    if (left) *left = -lo;
+    if (right) *right = hi;
+    if (stride) *stride = st;
+    return TAL_OK;
+}
+
+namespace {
+struct TilePlan { int64_t in_start, in_stop, out_start, out_stop, skip; };
+// tile k of `out_tile` output frames: the slice starts at a multiple of the total stride (every stage's index 0 of the slice
+// is then a stage index of the whole sequence) and carries the halo; at a true end of the sequence there is nothing to carry
+// -- the zero padding of the block convs is the same in the slice
+TilePlan plan_tile(int64_t T, int64_t t_out, int64_t out_tile, int64_t k, int64_t left, int64_t right, int64_t stride) {
+    TilePlan p;
+    p.out_start = k * out_tile;
+    p.out_stop = p.out_start + out_tile < t_out ? p.out_start + out_tile : t_out;
+    const int64_t a = stride * (p.out_start - (left + stride - 1) / stride);
+    p.in_start = a > 0 ? a : 0;
+    const int64_t b = stride * (p.out_stop - 1) + right + 1;
+    p.in_stop = b < T ? b : T;
+    p.skip = p.out_start - p.in_start / stride;
+    return p;
+}
+__global__ void or_status_kernel(const int* __restrict__ tile_flag, int* __restrict__ call_flag) {
+    if (threadIdx.x == 0 && *tile_flag) atomicOr(call_flag, *tile_flag);
+}
+size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
+}  // namespace
+
+// workspace = [slice output | tal_tds_fwd workspace of the longest slice | 64-byte status block of the whole call]
+static int tiled_layout(const tal_tds_desc* d, int64_t T, int64_t out_tile, size_t* slice_out_bytes, size_t* tds_bytes, int64_t* max_slice) {
+    int64_t left, right, stride;
+    int rc = tal_tds_halo(d, &left, &right, &stride);
+    if (rc) return rc;
+    const int64_t t_out = tal_tds_out_len(d, T);
+    TAL_CHECK_ARG(t_out > 0 && out_tile > 0, "tal_tds_tiled: T=%lld too short or out_tile=%lld not positive", (long long)T, (long long)out_tile);
+    int64_t longest = 0;
+    const int64_t n_tiles = cdiv(t_out, out_tile);
+    for (int64_t k = 0; k < n_tiles; ++k) {       // (the first, an interior and the last tile would do; tiles are few)
+        const TilePlan p = plan_tile(T, t_out, out_tile, k, left, right, stride);
+        if (p.in_stop - p.in_start > longest) longest = p.in_stop - p.in_start;
+    }
+    *max_slice = longest;
+    *slice_out_bytes = up256((size_t)tal_tds_out_len(d, longest) * d->channels[d->n_stages] * sizeof(float));
+    *tds_bytes = up256(tal_tds_workspace_bytes(d, 1, longest));
+    return TAL_OK;
+}
+
+extern "C" size_t tal_tds_tiled_status_offset(const tal_tds_desc* d, int64_t T, int64_t out_tile) {
+    size_t a, b;
+    int64_t m;
+    if (!d || tiled_layout(d, T, out_tile, &a, &b, &m)) return 0;
+    return a + b;
+}
+
+extern "C" size_t tal_tds_tiled_workspace_bytes(const tal_tds_desc* d, int64_t T, int64_t out_tile) {
+    const size_t off = tal_tds_tiled_status_offset(d, T, out_tile);
+    return off ? off + 64 : 0;
+}
+
+extern "C" int tal_tds_tiled_fwd(const tal_tds_desc* d, const float* x, int64_t T, float* y, int64_t out_tile, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    TAL_CHECK_ARG(x && y && workspace, "tal_tds_tiled_fwd: null pointer");
+    size_t so, tb;
+    int64_t longest;
+    int rc = tiled_layout(d, T, out_tile, &so, &tb, &longest);
+    if (rc) return rc;
+    if (workspace_bytes < so + tb + 64) {
+        set_error("tal_tds_tiled_fwd: workspace %zu < %zu bytes", workspace_bytes, so + tb + 64);
+        return TAL_ENOMEM;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int64_t left, right, stride;
+    tal_tds_halo(d, &left, &right, &stride);
+    const int64_t t_out = tal_tds_out_len(d, T), n_tiles = cdiv(t_out, out_tile);
+    const int c_in = d->channels[0], c_out = d->channels[d->n_stages];
+    char* base = reinterpret_cast<char*>(workspace);
+    float* slice_out = reinterpret_cast<float*>(base);
+    void* tds_ws = base + so;
+    int* call_flag = reinterpret_cast<int*>(base + so + tb);
+    if (hipMemsetAsync(call_flag, 0, 64, s) != hipSuccess) {
+        set_error("tal_tds_tiled_fwd: cannot clear the status word");
+        return TAL_EHIP;
+    }
+    for (int64_t k = 0; k < n_tiles; ++k) {
+        const TilePlan p = plan_tile(T, t_out, out_tile, k, left, right, stride);
+        const int64_t Ts = p.in_stop - p.in_start;
+        // a tile that is the whole sequence goes straight into y
+        const bool direct = n_tiles == 1;
+        rc = tal_tds_fwd(d, x + p.in_start * c_in, 1, Ts, direct ? y : slice_out, tds_ws, tb, stream);
+        if (rc) return rc;
+        const int* tile_flag = reinterpret_cast<const int*>(reinterpret_cast<char*>(tds_ws) + tal_tds_status_offset(d, 1, Ts));
+        hipLaunchKernelGGL(or_status_kernel, dim3(1), dim3(64), 0, s, tile_flag, call_flag);
+        TAL_CHECK_LAUNCH("tal_tds_tiled_fwd(status)");
+        if (!direct && hipMemcpyAsync(y + p.out_start * c_out, slice_out + p.skip * c_out, (size_t)(p.out_stop - p.out_start) * c_out * sizeof(float),
+                                      hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            set_error("tal_tds_tiled_fwd: copy of tile %lld failed", (long long)k);
+            return TAL_EHIP;
+        }
+    }
+    return TAL_OK;
+}
+
 extern "C" int tal_split_f16x3_fwd(const float* x, void* out, int64_t rows, int K, void* stream) {
     return launch_split_f16x3(x, out, rows, K, (hipStream_t)stream);
 }

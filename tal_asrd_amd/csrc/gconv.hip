@@ -358,6 +358,10 @@ typedef _Float16 f16x8a8 __attribute__((ext_vector_type(8), aligned(8)));
 #ifndef GC_LB18
 #define GC_LB18 2
 #endif
+// how many K chunks ahead of their MFMAs the operand fragments are read from LDS
+#ifndef GC_PF
+#define GC_PF 2
+#endif
 #define GC_LB(CIG, STRIDE) (((CIG) > 16 && (STRIDE) == 1) ? GC_LB18 : 2)
 typedef _Float16 f16x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -416,10 +420,21 @@ static bool gconv_mfma_desc(int cig, int cog, int stride, int groups, GcPackDesc
     return false;
 }
 
+// `p2` = p + 4 halves through a pointer the compiler cannot relate to `p` (8-byte-aligned pitches only): the fragment is then
+// read as TWO ds_read_b64 (2 LDS cycles each).  Left to itself hipcc merges the pair into one ds_read2_b64, which the LDS
+// serves at half the rate (8-16 cycles per wave instruction, MI355X_MICROARCH.md section LDS) -- with 20- or 12-halves rows the
+// LDS array was ~70 % busy at ~40 % matrix-pipe utilisation (profiles/r2_pmc_inst_all_kernels.txt, SQ_LDS_IDX_ACTIVE).
 template <int P>
-__device__ __forceinline__ f16x8 gconv_frag(const _Float16* p) {
+__device__ __forceinline__ f16x8 gconv_frag(const _Float16* p, const _Float16* p2) {
     if (P % 8 == 0) return *reinterpret_cast<const f16x8*>(p);
+#ifdef GC_MERGED_READS      // (layout ablation build, scripts/build_ablation.sh: one 8-byte-aligned 16-byte read = ds_read2_b64)
     if (P % 4 == 0) return *reinterpret_cast<const f16x8a8*>(p);
+#endif
+    if (P % 4 == 0) {
+        typedef _Float16 f16x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+        const f16x4a8 a = *reinterpret_cast<const f16x4a8*>(p), b = *reinterpret_cast<const f16x4a8*>(p2);
+        return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    }
     return *reinterpret_cast<const f16x8u*>(p);
 }
 
@@ -585,13 +600,27 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
         // fragment of K chunk c for output column (16 tb + col): segment base + (16 tb + col) * pitch + 8 kg + 32 ks
         const _Float16* hs = s_hi + gl * GS + 8 * kg;
         const _Float16* ls = s_lo + gl * GS + 8 * kg;
+        int four = 4;                        // (opaque to the compiler: hs2 / ls2 become separate base registers, still LDS pointers)
+        asm volatile("" : "+v"(four));
+        const _Float16* hs2 = hs + four;     // second halves of the fragments (gconv_frag)
+        const _Float16* ls2 = ls + four;
         int boff0 = (tbeg * 16 + col) * P0, boff1 = SL0 + (tbeg * 16 + col) * P1;
         auto frag_off = [&](int c, int b0, int b1) { return c < NK0 ? b0 + 32 * c : b1 + 32 * (c - NK0); };
         auto frag = [&](const _Float16* base, int c, int b0, int b1) {
-            return c < NK0 ? gconv_frag<P0>(base + frag_off(c, b0, b1)) : gconv_frag<P1>(base + frag_off(c, b0, b1));
+            const _Float16* base2 = base == hs ? hs2 : ls2;
+            return c < NK0 ? gconv_frag<P0>(base + frag_off(c, b0, b1), base2 + frag_off(c, b0, b1))
+                           : gconv_frag<P1>(base + frag_off(c, b0, b1), base2 + frag_off(c, b0, b1));
         };
-        f16x8 c0h = frag(hs, 0, boff0, boff1), c0l = frag(ls, 0, boff0, boff1);
-        f16x8 c1h = frag(hs, 1, boff0, boff1), c1l = frag(ls, 1, boff0, boff1);
+        // operand fragments are read PF K chunks ahead of their MFMAs (a ring of PF + 1 register slots; the first PF chunks of the
+        // next block are read under the last MFMAs of the current one and carried across the epilogue)
+        constexpr int PF = GC_PF, RING = PF + 1;
+        static_assert(PF >= 1 && PF < NKS, "prefetch depth");
+        f16x8 ch[PF], cl[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            ch[q] = frag(hs, q, boff0, boff1);
+            cl[q] = frag(ls, q, boff0, boff1);
+        }
         // TDSBlock residual: x of block tb is fetched XD blocks ahead; the block loop is unrolled by XD + 1 so the ring of
         // in-flight registers is indexed statically.  Branch-free: every lane loads 16 bytes; a lane with two valid
         // channels loads from two floats earlier and keeps the upper half, a lane with none re-reads the group's first
@@ -629,26 +658,34 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
                 f32x4 acc = bv, ax1 = {0.f, 0.f, 0.f, 0.f}, ax2 = {0.f, 0.f, 0.f, 0.f};
                 const bool more = tb + 1 < tend;
                 const int nb0 = more ? boff0 + 16 * P0 : boff0, nb1 = more ? boff1 + 16 * P1 : boff1;
-                f16x8 bh[3], bl[3];
-                bh[0] = c0h; bl[0] = c0l; bh[1] = c1h; bl[1] = c1l;
+                f16x8 bh[RING], bl[RING];
+#pragma unroll
+                for (int q = 0; q < PF; ++q) {
+                    bh[q] = ch[q];
+                    bl[q] = cl[q];
+                }
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    // fragments of K chunk ks + 2 (of the next block at the end) are read before the MFMAs of chunk ks
-                    const int pk = ks + 2;
+                    // fragments of K chunk ks + PF (of the next block at the end) are read before the MFMAs of chunk ks
+                    const int pk = ks + PF;
                     if (pk < NKS) {
-                        bh[pk % 3] = frag(hs, pk, boff0, boff1);
-                        bl[pk % 3] = frag(ls, pk, boff0, boff1);
+                        bh[pk % RING] = frag(hs, pk, boff0, boff1);
+                        bl[pk % RING] = frag(ls, pk, boff0, boff1);
                     } else {
-                        bh[pk % 3] = frag(hs, pk - NKS, nb0, nb1);
-                        bl[pk % 3] = frag(ls, pk - NKS, nb0, nb1);
+                        bh[pk % RING] = frag(hs, pk - NKS, nb0, nb1);
+                        bl[pk % RING] = frag(ls, pk - NKS, nb0, nb1);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], bh[ks % 3], acc, 0, 0, 0);
-                    ax1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], bl[ks % 3], ax1, 0, 0, 0);
-                    ax2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks], bh[ks % 3], ax2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], bh[ks % RING], acc, 0, 0, 0);
+                    ax1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], bl[ks % RING], ax1, 0, 0, 0);
+                    ax2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks], bh[ks % RING], ax2, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                c0h = bh[NKS % 3]; c0l = bl[NKS % 3]; c1h = bh[(NKS + 1) % 3]; c1l = bl[(NKS + 1) % 3];
+#pragma unroll
+                for (int q = 0; q < PF; ++q) {
+                    ch[q] = bh[(NKS + q) % RING];
+                    cl[q] = bl[(NKS + q) % RING];
+                }
                 boff0 = nb0;
                 boff1 = nb1;
                 // ---- epilogue (every vector instruction here is time taken from the matrix pipe: kept to ~40) ----

@@ -300,7 +300,8 @@ class TDS(nn.Module):
         if first == last:
             return x
         if self._needs_tiles(x, first, last):
-            return tiling.encode_tiled(self, x, self.tile_frames)
+            # one item beyond the kernels' per-item limit: tile by tile inside the C call (tal_tds_tiled_fwd)
+            return ops.tds_forward_tiled(self._descriptor(first, last), x, self.sizes[last], self.tile_frames)
         return ops.tds_forward(self._descriptor(first, last), x, self.sizes[last])
 
     def forward_then(self, x, tail):

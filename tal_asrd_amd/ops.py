@@ -250,6 +250,36 @@ def tds_forward(desc, x, c_out, check_range=True, defer=False):
     return y
 
 
+def tds_forward_tiled(desc, x, c_out, out_tile, check_range=True):
+    """x [1, T, C0] -> [1, T', C_last] through tal_tds_tiled_fwd: tiles of `out_tile` output frames, each with its
+    receptive-field halo (include/tal_asrd.h); same range guard as tds_forward."""
+    lib = N.lib()
+    x = _f32c(x, "tds_forward_tiled")
+    if x.dim() != 3 or x.shape[0] != 1:
+        raise N.NativeError("tds_forward_tiled: x must be [1, T, C]")
+    T = x.shape[1]
+    t_out = lib.tal_tds_out_len(C.byref(desc), T)
+    if t_out <= 0:
+        raise N.NativeError("tds_forward_tiled: %d frames are too few for the stride-2 k=21 stages" % T)
+    y = torch.empty(1, t_out, c_out, dtype=torch.float32, device=x.device)
+    nws = lib.tal_tds_tiled_workspace_bytes(C.byref(desc), T, int(out_tile))
+    ws = _ws(nws, x.device)
+
+    def run(d):
+        N.check(lib.tal_tds_tiled_fwd(C.byref(d), N.ptr(x), T, N.ptr(y), int(out_tile), N.ptr(ws), nws, N.stream_handle()),
+                "tal_tds_tiled_fwd")
+    run(desc)
+    if check_range and not (desc.flags & N.TAL_TDS_EXACT_F32):
+        off = lib.tal_tds_tiled_status_offset(C.byref(desc), T, int(out_tile))
+        if int(ws[off:off + 4].view(torch.int32)[0]) != 0:
+            global range_fallbacks
+            range_fallbacks += 1
+            exact = N.TdsDesc.from_buffer_copy(desc)
+            exact.flags |= N.TAL_TDS_EXACT_F32
+            run(exact)
+    return y
+
+
 # ------------------------------------------------------------------ diarization head
 def sd_head(x, w_embed, b_embed, w_logit, b_logit, want_logits=True, want_ids=True):
     """x [..., C] -> (feat [..., E], logits [..., S] | None, ids [...] int32 | None)."""

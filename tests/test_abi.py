@@ -150,3 +150,30 @@ def test_options_are_explicit_calls_not_environment():
     assert lib.tal_version() >= 300
     for src in glob.glob(os.path.join(ROOT, "tal_asrd_amd", "csrc", "*")):
         assert "getenv" not in open(src).read(), src
+
+
+def test_tiled_entry_points_agree_with_the_python_plan():
+    """tal_tds_halo (host arithmetic of tal_tds_tiled_fwd) against tiling.receptive_halo: [640, 780] frames at stride 8 for
+    the reference's 2 / 3 / 6 block stack (output frame c reads mel frames [8c - 640, 8c + 780])."""
+    import ctypes as C
+    from tal_asrd_amd import _native as N, tiling
+    lib = N.lib()
+    for depths in ((2, 3, 6), (1, 1, 2), (0, 4, 1), (3,)):
+        d = N.TdsDesc()
+        d.n_stages, d.groups = len(depths), 8
+        for i in range(len(depths) + 1):
+            d.channels[i] = 8 * (i + 1)
+        for i, v in enumerate(depths):
+            d.depths[i] = v
+        left, right, stride = C.c_int64(), C.c_int64(), C.c_int64()
+        assert lib.tal_tds_halo(C.byref(d), C.byref(left), C.byref(right), C.byref(stride)) == 0
+        assert (left.value, right.value, stride.value) == tiling.receptive_halo(depths), depths
+        if depths == (2, 3, 6):
+            assert (left.value, right.value, stride.value) == (640, 780, 8)
+        # the tiled workspace holds the longest slice's own workspace, its output and the status block
+        T, tile = 30001, 512
+        plan = tiling.plan_tiles(T, tile, depths)
+        longest = max(t.in_stop - t.in_start for t in plan)
+        need = lib.tal_tds_tiled_workspace_bytes(C.byref(d), T, tile)
+        assert need >= lib.tal_tds_workspace_bytes(C.byref(d), 1, longest) + 64
+        assert lib.tal_tds_tiled_status_offset(C.byref(d), T, tile) == need - 64

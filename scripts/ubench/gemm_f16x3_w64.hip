@@ -8,6 +8,7 @@
 //   hipcc --offload-arch=gfx950 -O3 scripts/ubench/gemm_f16x3_w64.hip -o scripts/ubench/gemm_f16x3_w64
 //   -DPATTERN=n   where the 13 LDS-DMA loads of a K step sit among its MFMAs (dma_piece)
 //   -DTOPBAR      barrier at the top of the K step (no cross-step fragment prefetch)
+//   -DPERSIST     256 workgroups walk the tiles; a tile's first operands are requested before the previous tile's epilogue
 //   -DABL=mask    1 = no operand loads in the loop, 8 = fragments from registers (timing only)
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -93,21 +94,11 @@ struct Frags {
 };
 
 __global__ __launch_bounds__(256, 1) void gemm_w64_kernel(const float* __restrict__ As, const float* __restrict__ Ws, float* __restrict__ C,
-                                                          int64_t M, int N, int K, int tiles_n, long long* clk) {
+                                                          int64_t M, int N, int K, int tiles_n, long long* clk, unsigned ntiles) {
     __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF_FLOATS];      // 159,744 B
-    const unsigned tile = blockIdx.x;
-    const int64_t m0 = (int64_t)(tile / (unsigned)tiles_n) * BM;
-    const int n0 = (int)(tile % (unsigned)tiles_n) * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane >> 3, srccol = ((lane & 7) ^ (((w & 1) * 4 + (lane >> 4)) & 7)) * 4;
-    const int a_rows = (int)((M - m0) < BM ? (M - m0) : BM) - 1;
-    const int b_rows = ((N - n0) < BN ? (N - n0) : BN) - 1;
-    auto uptr = [](const float* p) {
-        const uint64_t v = reinterpret_cast<uint64_t>(p);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-        return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
-    };
     // buffer descriptors as four SGPR dwords: base, base high (stride 0), num_records, flags
     auto make_rsrc = [](const float* p) {
         const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -118,17 +109,27 @@ __global__ __launch_bounds__(256, 1) void gemm_w64_kernel(const float* __restric
         r[3] = 0x00020000u;
         return r;
     };
-    const u32x4 rs_a = make_rsrc(As + m0 * K), rs_w = make_rsrc(Ws + (int64_t)n0 * K);
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds) + (unsigned)w * 1024u;
+    // per-tile state (PERSIST: a workgroup walks the tiles blockIdx.x, + gridDim.x, ...)
+    int64_t m0;
+    int n0;
+    u32x4 rs_a, rs_w;
     int voff[PER_WAVE];
+    auto setup = [&](unsigned tile) {
+        m0 = (int64_t)(tile / (unsigned)tiles_n) * BM;
+        n0 = (int)(tile % (unsigned)tiles_n) * BN;
+        const int a_rows = (int)((M - m0) < BM ? (M - m0) : BM) - 1;
+        const int b_rows = ((N - n0) < BN ? (N - n0) : BN) - 1;
+        rs_a = make_rsrc(As + m0 * K);
+        rs_w = make_rsrc(Ws + (int64_t)n0 * K);
 #pragma unroll
-    for (int t = 0; t < PER_WAVE; ++t) {
-        const int row = 8 * (w + 4 * t) + sub;
-        voff[t] = t < A_T ? (min(row, a_rows) * K + srccol) * 4 : (min(row - BM, b_rows) * K + srccol) * 4;
-    }
-    // LDS-DMA in inline asm: hipcc would otherwise make every ds_read wait for ALL LDS-DMA loads in flight (vmcnt(0): it
-    // cannot tell the three buffers apart), which serialises the pipeline.  M0 (LDS destination of the wave's 1 KB piece) is
-    // written in the same statement; completion is counted by hand (s_waitcnt vmcnt(13) before the step's barrier).
+        for (int t = 0; t < PER_WAVE; ++t) {
+            const int row = 8 * (w + 4 * t) + sub;
+            voff[t] = t < A_T ? (min(row, a_rows) * K + srccol) * 4 : (min(row - BM, b_rows) * K + srccol) * 4;
+        }
+    };
+    unsigned tile = blockIdx.x;
+    setup(tile);
     // `nrec` = num_records of the descriptor for this tile: 0 for a tile index past the end -- every lane is then out of
     // range and the load is dropped (the scalar offset is not part of the range check, so it cannot carry the condition),
     // but it still counts in vmcnt: the loop needs no tail variants.
@@ -139,12 +140,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w64_kernel(const float* __restric
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff[t]), "s"(rs), "s"(kofs) : "memory");
     };
     f32x16 hh[2][NSUB], xx[2][NSUB];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int j = 0; j < NSUB; ++j)
+            for (int j = 0; j < NSUB; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) hh[b][j][e] = xx[b][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) hh[b][j][e] = xx[b][j][e] = 0.f;
+    };
+    zero_acc();
 
     // fragment addresses: row (lane & 31) of a 32-row block; logical 16-byte slot x | fhalf (x = 2 gk for the hi halves,
     // 4 + 2 gk for the lo halves) sits at physical slot (x | fhalf) ^ fsw = x ^ (fhalf ^ fsw)
@@ -179,13 +183,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w64_kernel(const float* __restric
     };
     // prologue: tiles 0 and 1 in flight, tile 0 landed, first fragments read
     constexpr unsigned NREC = 0x7fffffffu;
+    auto issue_first_two = [&]() {
 #pragma unroll
-    for (int t = 0; t < PER_WAVE; ++t) dma(t, NREC, 0, 0);
-    {
+        for (int t = 0; t < PER_WAVE; ++t) dma(t, NREC, 0, 0);
         const unsigned nrec = nk > 1 ? NREC : 0u;
 #pragma unroll
         for (int t = 0; t < PER_WAVE; ++t) dma(t, nrec, BUF_FLOATS, BK * 4);
-    }
+    };
+    issue_first_two();
+#ifdef PERSIST
+  for (;;) {
+#endif
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
     __builtin_amdgcn_s_barrier();
 #ifndef TOPBAR
@@ -254,19 +262,38 @@ __global__ __launch_bounds__(256, 1) void gemm_w64_kernel(const float* __restric
         clk[2 * blockIdx.x] = (long long)(clock64() - c0);
         clk[2 * blockIdx.x + 1] = (long long)(wall_clock64() - w0);
     }
+    const int64_t em0 = m0;
+    const int en0 = n0;
+#ifdef PERSIST
+    // the next tile's first two K tiles are requested BEFORE this tile's epilogue: with one workgroup per CU nothing else hides
+    // the first operand round trip of a tile
+    const unsigned next = tile + gridDim.x;
+    const bool more = next < ntiles;
+    __builtin_amdgcn_s_barrier();              // every wave is done with the operand buffers
+    if (more) {
+        setup(next);
+        issue_first_two();
+    }
+#endif
     const int colb = lane & 31, rowb = 4 * (lane >> 5);
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int j = 0; j < NSUB; ++j) {
-            const int col = n0 + j * 32 + colb;
+            const int col = en0 + j * 32 + colb;
             if (col >= N) continue;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int64_t row = m0 + w * 64 + b * 32 + rowb + (e & 3) + 8 * (e >> 2);
+                const int64_t row = em0 + w * 64 + b * 32 + rowb + (e & 3) + 8 * (e >> 2);
                 if (row < M) C[row * N + col] = hh[b][j][e] + xx[b][j][e] * (1.0f / 2048.0f);
             }
         }
+#ifdef PERSIST
+    if (!more) break;
+    tile = next;
+    zero_acc();
+  }
+#endif
 }
 
 static int g_lo_mask = 0;
@@ -305,7 +332,12 @@ static void run(int64_t M, int N, int K, bool check) {
     for (int rep = 0; rep < reps; ++rep) {
         if (filler) (void)hipMemsetAsync(fbuf, rep, filler, 0);
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL(gemm_w64_kernel, dim3(grid), dim3(256), 0, 0, (const float*)as, (const float*)ws, c, M, N, K, tiles_n, clk);
+#ifdef PERSIST
+        const unsigned launch_grid = grid < 256 ? grid : 256;
+#else
+        const unsigned launch_grid = grid;
+#endif
+        hipLaunchKernelGGL(gemm_w64_kernel, dim3(launch_grid), dim3(256), 0, 0, (const float*)as, (const float*)ws, c, M, N, K, tiles_n, clk, grid);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms;

@@ -403,26 +403,43 @@ class SDModel(nn.Module):
         dev = self.spk_embed_proj.weight.device
         copy_stream = torch.cuda.Stream(device=dev)
         compute = torch.cuda.current_stream(dev)
+        # two device buffers, allocated once per clip length (a fresh allocation per clip would be a hipMalloc, i.e. a device
+        # synchronisation, in the middle of the stream): clip i + 1 lands in the buffer clip i - 1 has finished with
+        if not hasattr(self, "_stream_bufs"):
+            self._stream_bufs = {}              # kept between calls: (slot, shape) -> device buffer
+        bufs, free_ev = self._stream_bufs, {}
 
-        def upload(clip):
+        def upload(clip, slot):
+            key = (slot, tuple(clip.shape))
+            if key not in bufs:
+                bufs[key] = torch.empty(clip.shape, dtype=torch.float32, device=dev)
+            if key in free_ev:
+                copy_stream.wait_event(free_ev[key])          # the compute that last read this buffer is done
+            else:
+                copy_stream.wait_stream(compute)              # (first use: the allocation above is ordered on the compute stream)
             with torch.cuda.stream(copy_stream):
-                x = clip.to(dev, non_blocking=True)
+                bufs[key].copy_(clip, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(copy_stream)
-            return x, done
+            return bufs[key], done, key
 
         it = iter(host_clips)
-        try:
-            pending = upload(next(it))
-        except StopIteration:
+        first = next(it, None)
+        if first is None:
             return
+        pending = upload(first, 0)
+        i = 0
         while pending is not None:
-            x, done = pending
+            x, done, key = pending
             nxt = next(it, None)
-            pending = upload(nxt) if nxt is not None else None
+            pending = upload(nxt, (i + 1) & 1) if nxt is not None else None
             compute.wait_event(done)
-            x.record_stream(compute)          # allocated on the copy stream, consumed on the compute stream
-            yield self.speaker_ids(x)
+            out = self.speaker_ids(x)
+            ev = torch.cuda.Event()
+            ev.record(compute)
+            free_ev[key] = ev
+            i += 1
+            yield out
 
 
 class ModRZTXDecoderLayer(nn.Module):

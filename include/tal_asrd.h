@@ -54,7 +54,7 @@ const char* tal_last_error(void);
  *                         (per call: tal_tds_desc.flags & TAL_TDS_EXACT_F32)
  *   tds_fp32_activations  fp16x3 layers, but fp32 activations between the kernels of a stage
  *   gconv_fuse_split, gconv_c1_generic, head_no_astationary, gemm_global_loads, gemm_no_splitk4, gemm_no_glds,
- *   gemm_no_splitk_tail, gemm_no_w64, logmel_no_fold, decode_no_small, decode_no_chain
+ *   gemm_no_splitk_tail, gemm_no_w64, logmel_no_fold, decode_no_small
  *                         kernel-selection switches of the ablation measurements
  *   decode_small_rows     largest prefix the latency-oriented decoder layer takes (default 256)
  * tal_set_option returns TAL_EINVAL for an unknown name; tal_option_name(i) enumerates the names (NULL past the end). */
@@ -353,10 +353,6 @@ typedef struct tal_greedy_ctx {
     float* picked_host_dev;  /* device alias of picked_host; NULL: resolved (hipHostGetDevicePointer) by the first sync 2 / 3 step */
     uint32_t seq;            /* library-owned: sequence value of the latest sync 2 / 3 step (start at 0) */
     uint32_t _pad;
-    uint32_t* chain_flags;   /* 129 device words, ZERO before the first call, never reset: arrival words of the launches that
-                              * chain a layer's dense layers (out-projection -> q-projection; out-projection -> FFN-1 -> FFN-2 ->
-                              * next layer's q|k|v projection): 19 launches per step instead of 35.  NULL: one launch per layer */
-    uint32_t chain_launches[2][8];   /* library-owned (start at 0): chain launches that have covered each 32-row block */
 } tal_greedy_ctx;
 size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H, int FF, int V, int E0, int n_layers);
 /* sync: 0 = enqueue only; 1 = copy {token, attention row} to picked_host and wait for the stream; 2 = the last kernel writes

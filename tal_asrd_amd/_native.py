@@ -44,7 +44,7 @@ class GreedyCtx(C.Structure):
                 ("k_cache", C.c_void_p), ("vt_cache", C.c_void_p), ("mem_kpm", C.c_void_p), ("tokens", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("picked_dev", C.c_void_p),
                 ("picked_host", C.c_void_p), ("tickets", C.c_void_p), ("picked_host_dev", C.c_void_p),
-                ("seq", C.c_uint32), ("_pad", C.c_uint32), ("chain_flags", C.c_void_p), ("chain_launches", (C.c_uint32 * 8) * 2)]
+                ("seq", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/tal_asrd.h declares

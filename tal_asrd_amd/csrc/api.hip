@@ -20,8 +20,8 @@ void set_error(const char* fmt, ...) {
 // ---- behaviour switches (tal_set_option) ---------------------------------------------------
 static const char* const g_opt_names[OPT_COUNT] = {
     "tds_exact_f32", "tds_fp32_activations", "gconv_fuse_split", "gconv_c1_generic", "head_no_astationary", "gemm_global_loads",
-    "gemm_no_splitk4", "gemm_no_glds", "gemm_no_splitk_tail", "gemm_no_w64", "logmel_no_fold", "decode_no_small", "decode_no_chain", "decode_small_rows"};
-static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {256}};
+    "gemm_no_splitk4", "gemm_no_glds", "gemm_no_splitk_tail", "gemm_no_w64", "logmel_no_fold", "decode_no_small", "decode_small_rows"};
+static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {256}};
 int opt(Option o) { return g_opt[o].load(std::memory_order_relaxed); }
 
 // ---- per-launch event timing ------------------------------------------------------------
@@ -172,7 +172,7 @@ static int64_t conv_out_len(int64_t t) { return t < 21 ? 0 : (t - 21) / 2 + 1; }
 
 using namespace tal;
 
-extern "C" int tal_version(void) { return 310; /* 0.3.1: chained decode step (tal_greedy_ctx.chain_flags); 0.3.0: tal_set_option; tal_attn_pool_fwd half_mode, tal_tds_desc flags (0.2) */ }
+extern "C" int tal_version(void) { return 300; /* 0.3.0: tal_set_option; tal_attn_pool_fwd half_mode, tal_tds_desc flags (0.2) */ }
 
 // Host-side helper of the decode loop (no device work): ngram_repeat_mask(row, n).sum() of tal/asr/util.py:5-17 -- the number
 // of positions covered by an n-gram that already occurred earlier in the row; like the reference, n-gram starts run to

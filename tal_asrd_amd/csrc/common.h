@@ -108,7 +108,6 @@ enum Option {
     OPT_GEMM_NO_W64,              // fp16x3 layers on the 128 x 160 kernel (2 workgroups per CU) instead of the 256 x 160 one (1 wave per SIMD)
     OPT_LOGMEL_NO_FOLD,           // plans built afterwards use the direct 400-term DFT (no symmetric-window folding)
     OPT_DECODE_NO_SMALL,          // decoder layers on the batched-GEMM path even for a decode step
-    OPT_DECODE_NO_CHAIN,          // a decode step's dense layers as one launch each (35 launches) instead of chained (19)
     OPT_DECODE_SMALL_ROWS,        // largest prefix (rows) the latency-oriented decoder layer takes (default 256)
     OPT_COUNT
 };
@@ -236,32 +235,6 @@ struct AttnArgs {
     int64_t ldq, q_bs, ldk, k_bs, ldvt, vt_bs, ldc, c_bs;
     int U, S, H, prob_row0;
 };
-
-// A chain of skinny GEMMs inside ONE launch (csrc/decode_small.hip, skinny_chain_kernel): stage s + 1 consumes what stage s
-// wrote, row block by row block -- a consumer workgroup waits until the producers of ITS 32-row block have arrived on a flag
-// word (write-through stores + drained flag on the producer side, relaxed polling + sc1 loads on the consumer side).
-// Stage = one launch_skinny_gemm problem with 4 waves per workgroup (K / ksplit == 512).
-struct ChainStage {
-    SkinnyArgs g;
-    int mode;            // epilogue mode 0..3
-    int wait_slot;       // flag word of the row block to wait on before this stage (-1: none) ...
-    int wait_per_z;      // ... + blockIdx z-slice index when 1 (FFN-2's K quarter q waits for FFN-1's column quarter q)
-    int wait_count;      // arrivals that complete the wait (per launch and row block)
-    int pub_slot;        // flag word this stage's finished tiles arrive on (-1: none) ...
-    int pub_div;         // ... + (column tile / pub_div) when > 0 (FFN-1 publishes per column quarter)
-    int a_coherent;      // the A operand / the residual was written earlier in the SAME launch: sc1 loads
-    int res_coherent;
-};
-constexpr int CHAIN_MAX_STAGES = 4, CHAIN_SLOTS = 8, CHAIN_MAX_ROWBLOCKS = 8;
-struct ChainArgs {
-    ChainStage st[CHAIN_MAX_STAGES];
-    int n;
-    unsigned* flags;                          // [CHAIN_MAX_ROWBLOCKS][CHAIN_SLOTS], zero before the first launch, never reset:
-    unsigned launches[CHAIN_MAX_ROWBLOCKS];   // a row block's words gain wait_count per launch that covers it (host-side count)
-    unsigned* timeout;                        // device word set to a stage code when a wait gives up (may be NULL)
-};
-bool skinny_chain_applicable(const ChainArgs& c);
-int launch_skinny_chain(const ChainArgs& c, hipStream_t s);
 
 bool skinny_gemm_applicable(const SkinnyArgs& g);
 int launch_skinny_gemm(const SkinnyArgs& g, int mode, hipStream_t s);

@@ -175,211 +175,6 @@ int launch_skinny_gemm(const SkinnyArgs& g, int mode, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// A chain of skinny GEMMs in ONE launch (ChainArgs, common.h).  A decode step is 35 dependent launches of ~6 us each, and
-// the host pays ~3.4 us per launch whatever it does (with several sessions in flight that is the limit): the chains
-//   self-attention out-projection + ReZero -> cross-attention q-projection                                    (2 stages)
-//   cross-attention out-projection + ReZero -> FFN-1 -> FFN-2 (K cut in four) -> next layer's q|k|v^T projection (4 stages)
-// take a layer from 8 launches to 4.  Every stage runs the arithmetic of skinny_gemm_kernel<., ., 4> unchanged (same K split
-// over the waves, same summation orders), so results are bit-identical to the separate launches.
-// Hand-off: a producer stores its tile write-through (16-byte sc1 stores), drains them, and one lane adds 1 to the row
-// block's flag word; a consumer's lane 0 polls that word (relaxed, agent scope) until it holds (launches + 1) * count, then
-// the workgroup reads the operand with sc1 loads (its L1 may hold the previous step's bytes at the same addresses).  All
-// workgroups of a row block (<= 128) are resident together and producers have the lower block indices of the row, so a
-// waiting workgroup never keeps its producers from being scheduled.  Waits are bounded (a lost producer raises *timeout).
-template <int N>
-__device__ __forceinline__ void ld_sc1_x4_pair(const float* p0, const float* p1, f32x4 (&a)[N], f32x4 (&b)[N], bool two) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(a[i]) : "v"(p0 + i * 16) : "memory");
-    if (two) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(b[i]) : "v"(p1 + i * 16) : "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]));
-    if (two) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) asm volatile("" : "+v"(b[i]));
-    }
-}
-__device__ __forceinline__ void st_sc1_x4(float* p, const f32x4& v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-
-template <int MT>
-__global__ __launch_bounds__(256) void skinny_chain_kernel(const ChainArgs c) {
-    constexpr int NW = 4;
-    __shared__ __attribute__((aligned(16))) float part[NW * MT * 256 + 4];     // (+ the ticket word: ONE shared object)
-    unsigned* ticket = reinterpret_cast<unsigned*>(part + NW * MT * 256);
-    const int by = blockIdx.y;
-    const int m0 = by * 32;
-    const int lane = threadIdx.x & 63, w = wave_id();
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int t = threadIdx.x;
-    unsigned* flags = c.flags + by * CHAIN_SLOTS;
-    const unsigned epoch = c.launches[by] + 1u;
-    for (int si = 0; si < c.n; ++si) {
-        const ChainStage& st = c.st[si];
-        const SkinnyArgs& g = st.g;
-        const int nx = g.N / 16, KS = g.ksplit > 1 ? g.ksplit : 1;
-        if ((int)blockIdx.x >= nx * KS) continue;                    // (uniform per workgroup)
-        const int bx = (int)blockIdx.x % nx, bz = (int)blockIdx.x / nx;
-        const int n0 = bx * 16;
-        if (st.wait_slot >= 0) {
-            if (t == 0) {
-                const unsigned* word = flags + st.wait_slot + (st.wait_per_z ? bz : 0);
-                const unsigned want = epoch * (unsigned)st.wait_count;
-                unsigned spins = 0;
-                while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 20)) {                      // ~a second: a producer is lost; say so instead of hanging
-                        if (c.timeout) __hip_atomic_store(c.timeout, (unsigned)(si + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-        }
-        __syncthreads();            // the flag has been seen; and every wave is done with `part` of the previous stage
-        // ---- the tile: as skinny_gemm_kernel<mode, MT, 4>; a wave's K share is one batch of 8 chunks
-        const int Kw = g.K / (NW * KS);
-        const int kofs = (bz * NW + w) * Kw;
-        const float* wp = g.W + (int64_t)(n0 + r16) * g.ldw + kofs + 4 * kq;
-        const float* ap[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int row = m0 + (mt < MT ? mt : 0) * 16 + r16;
-            ap[mt] = g.A + (int64_t)(row < g.M ? row : g.M - 1) * g.lda + kofs + 4 * kq;
-        }
-        f32x4 bw[8], av[2][8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) bw[u] = *reinterpret_cast<const f32x4*>(wp + u * 16);
-        if (st.a_coherent) {
-            ld_sc1_x4_pair<8>(ap[0], ap[1], av[0], av[1], MT == 2);
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                av[0][u] = *reinterpret_cast<const f32x4*>(ap[0] + u * 16);
-                if (MT == 2) av[1][u] = *reinterpret_cast<const f32x4*>(ap[1] + u * 16);
-            }
-        }
-        f32x4 acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u].x, bw[u].x, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u].y, bw[u].y, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u].z, bw[u].z, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u].w, bw[u].w, acc[mt], 0, 0, 0);
-            }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) part[((w * MT + mt) * 16 + 4 * kq + i) * 16 + r16] = acc[mt][i];
-        __syncthreads();
-        const int mt = t >> 6, r = (t & 63) >> 2, c4 = t & 3;
-        const int m = m0 + mt * 16 + r;
-        const bool owner = t < MT * 64;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (owner) {
-            v = *reinterpret_cast<const f32x4*>(&part[((0 * MT + mt) * 16 + r) * 16 + 4 * c4]);
-#pragma unroll
-            for (int q = 1; q < NW; ++q) v += *reinterpret_cast<const f32x4*>(&part[((q * MT + mt) * 16 + r) * 16 + 4 * c4]);   // wave order
-        }
-        bool finisher = true;        // false: a K slice that is not the last to arrive (its tile is finished by another workgroup)
-        if (KS > 1) {
-            const unsigned tile = (unsigned)by * nx + bx, ntile = (unsigned)nx * gridDim.y;
-            float* mine = g.sk_part + ((size_t)bz * ntile + tile) * 512 + t * 4;
-            if (owner) { st_agent(mine, v.x); st_agent(mine + 1, v.y); st_agent(mine + 2, v.z); st_agent(mine + 3, v.w); }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t == 0) *ticket = take_ticket(&g.sk_tickets[tile]);
-            __syncthreads();
-            finisher = *ticket == (unsigned)(KS - 1);
-            if (finisher) {
-                if (t == 0) reset_ticket(&g.sk_tickets[tile]);
-                if (owner) {
-                    const float* p0 = g.sk_part + (size_t)tile * 512 + t * 4;
-                    v = {0.f, 0.f, 0.f, 0.f};
-                    for (int q = 0; q < KS; ++q) {                 // split order
-                        const float* pq = p0 + (size_t)q * ntile * 512;
-                        v.x += ld_agent(pq); v.y += ld_agent(pq + 1); v.z += ld_agent(pq + 2); v.w += ld_agent(pq + 3);
-                    }
-                }
-            }
-        }
-        if (finisher && owner && m < g.M) {
-            const int col = n0 + 4 * c4;
-            if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
-            if (st.mode == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (st.mode == 2) {
-                f32x4 rv;
-                if (st.res_coherent) {
-                    f32x4 r1[1], r2[1];
-                    r2[0] = r1[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    ld_sc1_x4_pair<1>(g.res + (int64_t)m * g.ldres + col, nullptr, r1, r2, false);
-                    rv = r1[0];
-                } else
-                    rv = *reinterpret_cast<const f32x4*>(g.res + (int64_t)m * g.ldres + col);
-                v = rv + g.alpha * v;
-            }
-            if (st.mode == 3 && (g.scale_cols == 0 || col < g.scale_cols)) v = g.alpha * v;
-            if (g.Yt && col >= g.vt_begin) {
-                const int b = m / g.U, u = m - b * g.U;
-                float* yt = g.Yt + (int64_t)b * g.vt_bs + (int64_t)(col - g.vt_begin) * g.ldt + u;
-                yt[0] = v.x;
-                yt[g.ldt] = v.y;
-                yt[2 * g.ldt] = v.z;
-                yt[3 * g.ldt] = v.w;
-            } else if (st.pub_slot >= 0)
-                st_sc1_x4(g.Y + (int64_t)m * g.ldy + col, v);
-            else
-                *reinterpret_cast<f32x4*>(g.Y + (int64_t)m * g.ldy + col) = v;
-        }
-        if (st.pub_slot >= 0 && finisher) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains its write-through stores
-            __syncthreads();
-            if (t == 0) __hip_atomic_fetch_add(flags + st.pub_slot + (st.pub_div > 0 ? bx / st.pub_div : 0), 1u, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-bool skinny_chain_applicable(const ChainArgs& c) {
-    if (c.n < 1 || c.n > CHAIN_MAX_STAGES || !c.flags) return false;
-    const int M = c.st[0].g.M;
-    if (M < 1 || (M + 31) / 32 > CHAIN_MAX_ROWBLOCKS) return false;
-    for (int i = 0; i < c.n; ++i) {
-        const SkinnyArgs& g = c.st[i].g;
-        const int ks = g.ksplit > 1 ? g.ksplit : 1;
-        if (!skinny_gemm_applicable(g) || g.M != M || g.K != 512 * ks || (g.N / 16) * ks > 128) return false;
-        if (c.st[i].wait_slot >= CHAIN_SLOTS || c.st[i].pub_slot >= CHAIN_SLOTS) return false;
-    }
-    return true;
-}
-
-int launch_skinny_chain(const ChainArgs& c, hipStream_t s) {
-    TAL_CHECK_ARG(skinny_chain_applicable(c), "skinny chain: shapes not supported");
-    int gx = 0;
-    double work = 0.0;
-    for (int i = 0; i < c.n; ++i) {
-        const SkinnyArgs& g = c.st[i].g;
-        const int n = (g.N / 16) * (g.ksplit > 1 ? g.ksplit : 1);
-        gx = n > gx ? n : gx;
-        work += 2.0 * g.M * (double)g.N * g.K;
-    }
-    const int M = c.st[0].g.M;
-    const dim3 grid((unsigned)gx, (unsigned)((M + 31) / 32));
-    ProfScope prof(PROF_GEMM, work, s);
-    if (M <= 16) hipLaunchKernelGGL((skinny_chain_kernel<1>), grid, dim3(256), 0, s, c);
-    else hipLaunchKernelGGL((skinny_chain_kernel<2>), grid, dim3(256), 0, s, c);
-    TAL_CHECK_LAUNCH("skinny chain");
-    return TAL_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // 8 waves per workgroup.  Scores: wave w takes key blocks w, w + 8, ... three at a time (all 3 x HD/16 fragment loads in
 // flight before the first MFMA).  P.V: one 16-feature block per wave (HD = 128), the V^T fragments of the next 8 key
 // steps in flight while the current 8 are multiplied.

@@ -747,98 +747,6 @@ static int decoder_layer_small(const tal_decoder_layer_w* w, const float* tgt, i
     return launch_skinny_gemm(f2, 2, s);
 }
 
-// ---- the same stack with the dense layers of a layer chained inside two launches (skinny_chain_kernel): per layer
-//   [q|k|v^T projection]   self-attention   {out-projection + ReZero -> cross q-projection}   cross-attention
-//   {out-projection + ReZero -> FFN-1 -> FFN-2 -> the NEXT layer's q|k|v^T projection}
-// = 4 launches instead of 8 (19 instead of 35 for the 4-layer step with its embedding and pick); every stage keeps the
-// arithmetic of its separate launch, so the step's results are bit-identical.  flags: 2 x 64 words (one set per chain kind),
-// zero before the first call, never reset; launches[kind][row block]: how many chain launches have covered the row block.
-static bool chained_stack_applicable(int U, int S, int E, int H, int FF) {
-    return E == 512 && FF == 2048 && U >= 1 && (U + 31) / 32 <= CHAIN_MAX_ROWBLOCKS && small_layer_applicable(1, U, S, E, H, FF, true);
-}
-
-static int decoder_stack_small_chained(const tal_decoder_layer_w* layers, int L, const float* h0, int U, int S, int E, int H, int FF,
-                                       const uint8_t* mem_kpm, const float* const* k_cache, const float* const* vt_cache, float* h1,
-                                       float* probs, const LayerWs& ws, hipStream_t s, const DecodeScratch& sk, unsigned* flags,
-                                       uint32_t (*launches)[CHAIN_MAX_ROWBLOCKS]) {
-    const int M = U, hd = E / H, nrb = (U + 31) / 32;
-    const int64_t U4 = pad4(U), S4 = pad4(S);
-    const float qscale = 1.0f / sqrtf((float)hd);
-    auto qkv_args = [&](const tal_decoder_layer_w* w, const float* tgt) {
-        SkinnyArgs g = skinny(tgt, E, w->sa_in_w, w->sa_in_b, nullptr, ws.mha.q, 3 * E, M, 3 * E, E, qscale);
-        g.scale_cols = E;
-        g.Yt = ws.mha.vt; g.vt_begin = 2 * E; g.U = U; g.ldt = U4; g.vt_bs = (int64_t)E * U4;
-        return g;
-    };
-    auto stamp = [&](ChainArgs& c, int kind) {
-        c.flags = flags + kind * CHAIN_MAX_ROWBLOCKS * CHAIN_SLOTS;
-        c.timeout = flags + 2 * CHAIN_MAX_ROWBLOCKS * CHAIN_SLOTS;
-        for (int rb = 0; rb < CHAIN_MAX_ROWBLOCKS; ++rb) c.launches[rb] = launches[kind][rb];
-        for (int rb = 0; rb < nrb; ++rb) ++launches[kind][rb];
-    };
-    int rc = launch_skinny_gemm(qkv_args(&layers[0], h0), 3, s);
-    if (rc) return rc;
-    const float* tgt = h0;
-    for (int l = 0; l < L; ++l) {
-        const tal_decoder_layer_w* w = &layers[l];
-        TAL_CHECK_ARG(k_cache[l] && vt_cache[l], "tal_greedy_step_fwd: layer %d has no cached K / V^T", l);
-        AttnArgs a = {};
-        a.q = ws.mha.q; a.ldq = 3 * E; a.q_bs = (int64_t)U * 3 * E;
-        a.k = ws.mha.q + E; a.ldk = 3 * E; a.k_bs = (int64_t)U * 3 * E;
-        a.vt = ws.mha.vt; a.ldvt = U4; a.vt_bs = (int64_t)E * U4;
-        a.ctx = ws.mha.ctx; a.ldc = E; a.c_bs = (int64_t)U * E;
-        a.U = U; a.S = U; a.H = H;
-        rc = launch_attn_small(a, 1, hd, s);
-        if (rc) return rc;
-        {   // out-projection + ReZero -> x1; cross q-projection of x1
-            ChainArgs c = {};
-            c.n = 2;
-            c.st[0].g = skinny(ws.mha.ctx, E, w->sa_out_w, w->sa_out_b, tgt, ws.x1, E, M, E, E, w->resweight);
-            c.st[0].mode = 2; c.st[0].wait_slot = -1; c.st[0].pub_slot = 0;
-            c.st[1].g = skinny(ws.x1, E, w->ca_in_w, w->ca_in_b, nullptr, ws.mha.q, E, M, E, E, qscale);
-            c.st[1].mode = 3; c.st[1].wait_slot = 0; c.st[1].wait_count = E / 16; c.st[1].pub_slot = -1; c.st[1].a_coherent = 1;
-            stamp(c, 0);
-            rc = launch_skinny_chain(c, s);
-            if (rc) return rc;
-        }
-        AttnArgs x = {};
-        x.q = ws.mha.q; x.ldq = E; x.q_bs = (int64_t)U * E;
-        x.k = k_cache[l]; x.ldk = E; x.k_bs = (int64_t)S * E;
-        x.vt = vt_cache[l]; x.ldvt = S4; x.vt_bs = (int64_t)E * S4;
-        x.vbias = w->ca_in_b + 2 * E;
-        x.kpm = mem_kpm;
-        x.ctx = ws.mha.ctx; x.ldc = E; x.c_bs = (int64_t)U * E;
-        x.U = U; x.S = S; x.H = H;
-        x.probs = probs + (size_t)l * H * S; x.prob_row0 = U - 1;
-        if (S > 64 && attn_split_tickets(1, U, H) <= 64) rc = launch_attn_split(x, 1, hd, sk.part, sk.tickets, s);
-        else rc = launch_attn_small(x, 1, hd, s);
-        if (rc) return rc;
-        {   // out-projection + ReZero -> x2; FFN-1; FFN-2 (+ ReZero) -> h1; the next layer's q | k | v^T projection of h1
-            ChainArgs c = {};
-            c.n = l + 1 < L ? 4 : 3;
-            c.st[0].g = skinny(ws.mha.ctx, E, w->ca_out_w, w->ca_out_b, ws.x1, ws.x2, E, M, E, E, w->resweight_src);
-            c.st[0].mode = 2; c.st[0].wait_slot = -1; c.st[0].pub_slot = 0;
-            c.st[1].g = skinny(ws.x2, E, w->lin1_w, w->lin1_b, nullptr, ws.ff, FF, M, FF, E, 0.f);
-            c.st[1].mode = 1; c.st[1].wait_slot = 0; c.st[1].wait_count = E / 16; c.st[1].a_coherent = 1;
-            c.st[1].pub_slot = 1; c.st[1].pub_div = (FF / 4) / 16;              // column quarter = the K slice of FFN-2 that reads it
-            c.st[2].g = skinny(ws.ff, FF, w->lin2_w, w->lin2_b, ws.x2, h1, E, M, E, FF, w->resweight);
-            c.st[2].g.ksplit = 4; c.st[2].g.sk_part = sk.part; c.st[2].g.sk_tickets = sk.tickets + 64;
-            c.st[2].mode = 2; c.st[2].wait_slot = 1; c.st[2].wait_per_z = 1; c.st[2].wait_count = (FF / 4) / 16;
-            c.st[2].a_coherent = 1; c.st[2].res_coherent = 1;
-            c.st[2].pub_slot = 5;       // (also in the last layer, where nobody waits: every word gains its count on EVERY launch)
-            if (c.n == 4) {
-                c.st[3].g = qkv_args(&layers[l + 1], h1);
-                c.st[3].mode = 3; c.st[3].wait_slot = 5; c.st[3].wait_count = E / 16; c.st[3].a_coherent = 1; c.st[3].pub_slot = -1;
-            }
-            stamp(c, 1);
-            rc = launch_skinny_chain(c, s);
-            if (rc) return rc;
-        }
-        tgt = h1;
-    }
-    return TAL_OK;
-}
-
 }  // namespace tal
 
 using namespace tal;
@@ -1076,16 +984,7 @@ extern "C" int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int
     if (rc) return rc;
     const bool small = small_layer_applicable(1, U, S, E, H, FF, true);
     const float* cur = h0;
-    // the chained form needs the key-split scratch to hold FFN-2's partial tiles (tickets 64 .. 254: 32 column tiles x row blocks)
-    const bool chained = c->chain_flags && c->tickets && !opt(OPT_DECODE_NO_CHAIN) && chained_stack_applicable(U, S, E, H, FF) &&
-                         (E / 16) * ((U + 31) / 32) <= TAL_GREEDY_TICKETS - 64;
-    if (chained) {
-        rc = decoder_stack_small_chained(c->layers, L, h0, U, S, E, H, FF, c->mem_kpm, c->k_cache, c->vt_cache, h1, probs, ws, s, sk,
-                                         c->chain_flags, c->chain_launches);
-        if (rc) return rc;
-        cur = h1;
-    }
-    for (int l = chained ? L : 0; l < L; ++l) {
+    for (int l = 0; l < L; ++l) {
         TAL_CHECK_ARG(c->k_cache[l] && c->vt_cache[l], "tal_greedy_step_fwd: layer %d has no cached K / V^T", l);
         if (small)
             rc = decoder_layer_small(&c->layers[l], cur, 1, U, S, E, H, FF, nullptr, c->mem_kpm, c->k_cache[l], c->vt_cache[l], h1,

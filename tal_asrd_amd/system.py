@@ -76,9 +76,6 @@ class _GreedySession:
         self._stream = N.stream_handle()          # the stream current at construction carries every step
         self._tickets = torch.zeros(256, dtype=torch.int32, device=emb.device)   # arrival tickets, self-resetting
         c.tickets = self._tickets.data_ptr()
-        # arrival words of the chained dense-layer launches (19 launches per step instead of 35); zero once, never reset
-        self._chain_flags = torch.zeros(129, dtype=torch.int32, device=emb.device)
-        c.chain_flags = self._chain_flags.data_ptr()
         self.S = -1
         self.ws = None
         self._ctx_ref = C.byref(self.ctx)

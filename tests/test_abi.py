@@ -48,7 +48,7 @@ def test_struct_layout_matches_header():
     expect += 8                              # flags + pad
     assert C.sizeof(_native.TdsDesc) == expect
     assert _native.TdsDesc.flags.offset == expect - 8
-    assert C.sizeof(_native.GreedyCtx) == 8 + 8 * 4 + 8 * 8 + 8 + 8 + 3 * 8 + 8 + 8 + 8 + 64    # pointer, 8 ints, 8 pointers, workspace + size, 3 pointers, device alias, seq + pad, chain flags + launch counts
+    assert C.sizeof(_native.GreedyCtx) == 8 + 8 * 4 + 8 * 8 + 8 + 8 + 3 * 8 + 8 + 8    # pointer, 8 ints, 8 pointers, workspace + size, 3 pointers, device alias, seq + pad
 
 
 def test_error_path_no_gpu_needed():
@@ -147,7 +147,7 @@ def test_options_are_explicit_calls_not_environment():
     N.set_option("tds_exact_f32", 0)
     assert lib.tal_set_option(b"no_such_option", 1) != 0
     assert b"unknown option" in lib.tal_last_error()
-    assert lib.tal_version() >= 310
+    assert lib.tal_version() >= 300
     for src in glob.glob(os.path.join(ROOT, "tal_asrd_amd", "csrc", "*")):
         assert "getenv" not in open(src).read(), src
 

@@ -57,6 +57,10 @@ const char* tal_last_error(void);
  *   gemm_no_splitk_tail, gemm_no_w64, logmel_no_fold, decode_no_small
  *                         kernel-selection switches of the ablation measurements
  *   decode_small_rows     largest prefix the latency-oriented decoder layer takes (default 256)
+ *   gemm_s64_below        fp16x3 relu / residual layers run on 64 x 80 tiles without K slices while those tiles number
+ *                         at most this many per CU (default 2; 0: never)
+ *   gconv_short_below     grouped convs use 64-step tiles while the long tiles would give a CU fewer workgroups than
+ *                         this (default 4; 0: always the long tiles).  Results do not depend on it.
  * tal_set_option returns TAL_EINVAL for an unknown name; tal_option_name(i) enumerates the names (NULL past the end). */
 int tal_set_option(const char* name, int value);
 int tal_get_option(const char* name, int* value);

@@ -109,9 +109,12 @@ enum Option {
     OPT_LOGMEL_NO_FOLD,           // plans built afterwards use the direct 400-term DFT (no symmetric-window folding)
     OPT_DECODE_NO_SMALL,          // decoder layers on the batched-GEMM path even for a decode step
     OPT_DECODE_SMALL_ROWS,        // largest prefix (rows) the latency-oriented decoder layer takes (default 256)
+    OPT_GEMM_S64_BELOW,           // fp16x3 relu / residual layers take 64 x 80 tiles while those number at most this many per CU (default 2; 0: never)
+    OPT_GCONV_SHORT_BELOW,        // grouped convs take 64-step tiles while the long tiles give a CU fewer workgroups than this (default 4)
     OPT_COUNT
 };
 int opt(Option o);
+int device_cus();      // compute units of the current device
 
 // wave-uniform wave index inside the workgroup, provably uniform to the compiler
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
@@ -164,6 +167,9 @@ struct GemmArgs {
 int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s);
 // fp16x3 layer on 256 x 160 tiles, one wave per SIMD (gemm_w64.hip); splitk: grid = [whole tiles | K slices of the tail tiles]
 void launch_gemm_w64(const GemmArgs& g, int mode, bool splitk, dim3 grid, hipStream_t s);
+// fp16x3 relu / residual layer on 64 x 80 tiles for short inputs (gemm_s64.hip): whole tiles only, no K slices
+bool gemm_s64_ok(const GemmArgs& g, int mode);
+void launch_gemm_s64(GemmArgs g, int mode, hipStream_t s);
 int gemm_mode4_partials(int64_t M, int N);
 
 // internal launchers shared between translation units

@@ -884,6 +884,14 @@ static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias
     return TAL_OK;
 }
 
+// Short inputs: tiles of 64 output steps instead of 256 (128 for stride 2) when the long tiles would not give every CU
+// gconv_short_below workgroups (option "gconv_short_below", default 4: two rounds of two resident workgroups) -- a wave then
+// walks 4 blocks of 16 steps instead of 16 behind its slab fill, on 4x the workgroups.  Same arithmetic per output: results
+// do not depend on the tile length.
+static bool gconv_short_tiles(int64_t T_out, int tt_long, int group_blocks, int B) {
+    return cdiv(T_out, tt_long) * group_blocks * B < (int64_t)opt(OPT_GCONV_SHORT_BELOW) * device_cus();
+}
+
 // the slab loads address one batch item ([T, C] floats) through a buffer descriptor with 32-bit byte offsets
 bool gconv_f16x3_fits(int64_t T, int C) { return T * C * 4 + (int64_t)300 * C * 4 < ((int64_t)1 << 31); }
 
@@ -915,6 +923,11 @@ int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias
     TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && C % 4 == 0, "tal_gconv_res_f16x3_fwd: x must be 16-byte aligned");
     TAL_CHECK_ARG(gconv_f16x3_fits(T, C), "tal_gconv_res_f16x3_fwd: one batch item must stay below 2 GiB (T=%lld, C=%d)", (long long)T, C);
     const int cg = C / groups;
+    if (gconv_short_tiles(T, 256, groups / (cg == 18 ? 2 : 4), B)) {
+        if (cg == 10) return launch_mfma_spec<10, 10, 1, true, 4, 64>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
+        if (cg == 14) return launch_mfma_spec<14, 14, 1, true, 4, 64>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
+        return launch_mfma_spec<18, 18, 1, true, 2, 64>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
+    }
     if (cg == 10) return launch_mfma_spec<10, 10, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
     if (cg == 14) return launch_mfma_spec<14, 14, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
     return launch_mfma_spec<18, 18, 1, true, 2, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
@@ -929,6 +942,10 @@ int launch_gconv_s2_f16x3(const float* x, const void* w_frag, const float* bias,
     TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && C_in % 4 == 0, "tal_gconv_s2_f16x3_fwd: x must be 16-byte aligned");
     TAL_CHECK_ARG(gconv_f16x3_fits(T_in, C_in), "tal_gconv_s2_f16x3_fwd: one batch item must stay below 2 GiB (T=%lld, C=%d)", (long long)T_in, C_in);
     const int64_t T_out = (T_in - KS) / 2 + 1;
+    if (gconv_short_tiles(T_out, 128, groups / (C_in / groups == 10 ? 4 : 2), B)) {
+        if (C_in / groups == 10) return launch_mfma_spec<10, 14, 2, false, 4, 64>(x, w_frag, bias, 0.f, y, y_split, B, T_in, T_out, C_in, C_out, groups, s, range_flag, x_split);
+        return launch_mfma_spec<14, 18, 2, false, 2, 64>(x, w_frag, bias, 0.f, y, y_split, B, T_in, T_out, C_in, C_out, groups, s, range_flag, x_split);
+    }
     if (C_in / groups == 10) return launch_mfma_spec<10, 14, 2, false, 4, 128>(x, w_frag, bias, 0.f, y, y_split, B, T_in, T_out, C_in, C_out, groups, s, range_flag, x_split);
     return launch_mfma_spec<14, 18, 2, false, 2, 128>(x, w_frag, bias, 0.f, y, y_split, B, T_in, T_out, C_in, C_out, groups, s, range_flag, x_split);
 }

@@ -590,16 +590,6 @@ static void launch_fixup(const GemmArgs& g, int mode, dim3 grid, hipStream_t s) 
     }
 }
 
-static int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
 
 constexpr int SPLITK_MAX_SLICES = 1024;  // tail tiles x slices (84 MB of scratch)
 size_t gemm_splitk_ws_bytes() { return (size_t)SPLITK_MAX_SLICES * 128 * 160 * sizeof(float); }
@@ -668,6 +658,16 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
     TAL_CHECK_ARG(!g.res_split || (g.f16x3 && mode == 2 && g.N % 160 == 0 && g.ldres % 32 == 0 && g.ldy < (1 << 21) && g.ldres < (1 << 21) &&
                                   (reinterpret_cast<uintptr_t>(g.res) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.Y) & 15) == 0),
                   "gemm: a split-form residual needs the fp16x3 form, mode 2, N %% 160 == 0");
+    // short inputs: 64 x 80 tiles, whole tiles only (gemm_s64.hip), while they fit one round of two workgroups per CU (measured
+    // against the K-sliced launches below: ahead up to 470 / 336 / 432 tiles at N = K = 800 / 1120 / 1440, behind from 590 / 658 / 846,
+    // profiles/r3_gemm_short_inputs.txt)
+    if (g.f16x3 && nbatch == 1 && cdiv(g.M, 64) * (g.N / 80) <= (int64_t)opt(OPT_GEMM_S64_BELOW) * device_cus() &&
+        gemm_s64_ok(g, mode)) {
+        ProfScope prof(PROF_GEMM, 2.0 * (double)g.M * (double)g.N * (double)g.K, s);
+        launch_gemm_s64(g, mode, s);
+        TAL_CHECK_LAUNCH("gemm (64 x 80 tiles)");
+        return TAL_OK;
+    }
     // fp16x3 launches with at least one full round of 256 x 160 tiles (one workgroup per CU) take the one-wave-per-SIMD
     // kernel (gemm_w64.hip); the tiles of its last partial round are cut along K like the 128 x 160 kernel's
     if (g.f16x3 && nbatch == 1 && !opt(OPT_GEMM_NO_W64) && !opt(OPT_GEMM_NO_GLDS) &&

@@ -1,0 +1,270 @@
+// The fp16x3 dense layer for SHORT inputs (a few hundred to a few thousand rows): workgroup tile 64 rows x 80 columns x 32 k,
+// 4 waves x (16 rows x 80 columns) of v_mfma_f32_16x16x32_f16.  The TDS block's 1x1 Conv1d pair (tal/asr/models.py:312-318,
+// 330) on clips of seconds to minutes.
+//
+// Why: a 30-second clip has 1,501 / 751 / 376 rows in the three stages.  On 128 x 160 tiles that is 60 / 42 / 27 tiles for
+// 256 CUs, so launch_gemm cut every tile along K into 4-6 slices and ran a fix-up kernel behind each layer (13-16 us +
+// 7-9 us per layer, 22 layers: 60 % of the clip, profiles/r2_clip_30s_kernel_sequence.txt).  Here the same layer is
+// 240 / 168 / 108 whole tiles: no slices, no scratch traffic, no second launch, and the summation order does not depend on
+// the launch geometry.  A tile streams (64 + 80) x K x 4 bytes from L2 -- 461 KB at K = 800, 3.4 us at the 64 B/clk a CU
+// gets from its L2 -- beside 15 MFMAs of 16 cycles per K step (240 cycles against 288 for the operands): the kernel is
+// bound by the L2 -> LDS path by design, which is the price of 240 tiles instead of 60.
+//
+// Structure:
+//   * operands go L2 -> LDS by LDS-DMA (inline asm, counted vmcnt: see gemm_w64.hip for why not the builtin), FOUR buffers
+//     of 18 KB: tiles kt + 2 .. kt + 4 are in flight while tile kt is multiplied (a tile's MFMAs are 0.1 us, an L2 round
+//     trip is several times that);
+//   * the fragments of tile kt + 1 are read from LDS into a second register set while tile kt is multiplied from the
+//     first (12 ds_read_b128 per wave and K step): with one wave per SIMD nothing else hides an LDS round trip;
+//   * ONE barrier per K step; same operand geometry and source-side XOR swizzle as gemm_glds_kernel;
+//   * MFMA operand A = 16 W rows (output columns), B = 16 X rows: a lane ends up with 4 consecutive output columns of one
+//     row -- the epilogue (bias, ReLU / ReZero residual, hi / lo split, range guard) runs on registers and stores 8 or 16
+//     bytes per lane and column block, no LDS staging.
+// Arithmetic per output: hi*hi in one fp32 accumulator (started from the bias), hi*lo + lo*hi in a second one, combined as
+// acc + 2^-11 accx like the long-input kernels; K order inside an MFMA differs from the 32x32x16 form, so results agree
+// with those kernels to fp32 rounding, not bitwise.
+#include <type_traits>
+
+#include "gemm_common.h"
+
+namespace tal {
+
+namespace {
+
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+
+constexpr int S_BM = 64, S_BN = 80, S_NJ = S_BN / 16, S_ROWS = S_BM + S_BN, S_NBUF = 4;
+constexpr int S_CHUNKS = S_ROWS / 8;            // 18 wave-loads of 1 KB (8 rows x 128 B) per K step
+constexpr int S_PER_WAVE = 5;                   // chunk i = w + 4 t; i >= 18 (t = 4 of waves 2, 3) lands in a dummy 2 KB behind the buffers
+                                                // (every wave issues the same number of loads: one vmcnt schedule for all)
+constexpr int S_AT = S_BM / 8 / 4;              // t < 2: X rows
+constexpr int S_BUF_FLOATS = S_ROWS * 32;
+
+struct SFrags {
+    f16x8 xh, xl;                // 16 X rows of this wave
+    f16x8 wh[S_NJ], wl[S_NJ];    // 5 blocks of 16 W rows
+};
+
+}  // namespace
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_s64_kernel(const GemmArgs g) {
+    static_assert(MODE == 1 || MODE == 2, "relu or residual layer");
+    constexpr int NJ = S_NJ, BM = S_BM, BN = S_BN, PER_WAVE = S_PER_WAVE, BUF = S_BUF_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[S_NBUF * S_BUF_FLOATS + 512];      // 75,776 B: two workgroups per CU
+
+    const unsigned logical = logical_tile();
+    const unsigned tile_m = g.tiles_n == 1 ? logical : __umulhi(logical, g.tiles_n_magic);
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = (int)(logical - tile_m * (unsigned)g.tiles_n) * BN;
+    const int64_t M = g.M;
+    const int K = g.K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = wave_id();
+
+    // operand loads: chunk = 8 rows x 128 B; slot s of LDS row r holds the row's logical 16-byte column s ^ ((r >> 1) & 7)
+    const int sub = lane >> 3, srccol = ((lane & 7) ^ (((w & 1) * 4 + (lane >> 4)) & 7)) * 4;
+    const int a_rows = (int)((M - m0) < BM ? (M - m0) : BM) - 1;
+    auto make_rsrc = [](const float* p, unsigned nrec) {
+        const uint64_t v = reinterpret_cast<uint64_t>(p);
+        u32x4s r;
+        r[0] = __builtin_amdgcn_readfirstlane((uint32_t)v);
+        r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        r[2] = nrec;
+        r[3] = 0x00020000u;
+        return r;
+    };
+    constexpr unsigned NREC = 0x7fffffffu;
+    const u32x4s rs_a = make_rsrc(g.A + m0 * g.lda, NREC), rs_w = make_rsrc(g.W + (int64_t)n0 * g.ldw, NREC);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds) + (unsigned)w * 1024u;
+    int voff[PER_WAVE];
+#pragma unroll
+    for (int t = 0; t < PER_WAVE; ++t) {
+        const int row = 8 * (w + 4 * t) + sub;
+        voff[t] = t < S_AT ? (int)((min(row, a_rows) * g.lda + srccol) * 4) : (int)((min(row - BM, BN - 1) * g.ldw + srccol) * 4);
+    }
+    const bool last_chunk = w + 16 < S_CHUNKS;          // wave-uniform: chunk w + 16 exists
+    auto dma = [&](int t, unsigned nrec, int bufoff, int kofs) {
+        const unsigned dst = (t < 4 || last_chunk) ? lds_base + (unsigned)(bufoff * 4 + t * 4096) : lds_base + (unsigned)(S_NBUF * BUF * 4 - 2048);
+        u32x4s rs = t < S_AT ? rs_a : rs_w;
+        rs[2] = nrec;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff[t]), "s"(rs), "s"(kofs) : "memory");
+    };
+
+    const int nk = K / BK;
+    // prologue: tiles 0..3 requested first of all
+#pragma unroll
+    for (int b = 0; b < S_NBUF; ++b) {
+        const unsigned nrec = b < nk ? NREC : 0u;
+#pragma unroll
+        for (int t = 0; t < PER_WAVE; ++t) dma(t, nrec, b * BUF, b * (BK * 4));
+    }
+
+    // a lane's outputs: row m0 + 16 w + (lane & 15), columns n0 + 16 j + 4 (lane >> 4) + {0..3}
+    const int col = lane & 15, q4 = lane >> 4;
+    f32x4 acc[NJ], accx[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        acc[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n0 + 16 * j + 4 * q4) : z;
+        accx[j] = z;
+    }
+    // the residual of this lane's outputs is requested before the K loop (MODE 2): 20 registers against an exposed round trip
+    const int64_t row = m0 + 16 * w + col;
+    const bool row_ok = row < M;
+    const int64_t rrow = row_ok ? row : M - 1;
+    u32x2s rh[NJ], rl[NJ];
+    f32x4 rf[NJ];
+    if (MODE == 2) {
+        if (g.res_split) {
+            const char* rp = reinterpret_cast<const char*>(g.res + rrow * g.ldres);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = n0 + 16 * j + 4 * q4;
+                rh[j] = *reinterpret_cast<const u32x2s*>(rp + (c >> 5) * 128 + (c & 31) * 2);
+                rl[j] = *reinterpret_cast<const u32x2s*>(rp + (c >> 5) * 128 + (c & 31) * 2 + 64);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rf[j] = *reinterpret_cast<const f32x4*>(g.res + rrow * g.ldres + n0 + 16 * j + 4 * q4);
+        }
+    }
+
+    // fragment addresses: row (lane & 15) of a 16-row block, logical 16-byte slot q4 (hi halves) / 4 + q4 (lo halves)
+    const int fsw = (col >> 1) & 7;
+    const int x_lane = (16 * w + col) * 32, w_lane = (BM + col) * 32;
+    const int sh = ((q4) ^ fsw) * 4, sl = ((4 + q4) ^ fsw) * 4;
+    SFrags f[2];
+    auto read_frags = [&](SFrags& d, int bufoff) {
+        d.xh = *reinterpret_cast<const f16x8*>(lds + bufoff + x_lane + sh);
+        d.xl = *reinterpret_cast<const f16x8*>(lds + bufoff + x_lane + sl);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            d.wh[j] = *reinterpret_cast<const f16x8*>(lds + bufoff + w_lane + j * 16 * 32 + sh);
+            d.wl[j] = *reinterpret_cast<const f16x8*>(lds + bufoff + w_lane + j * 16 * 32 + sl);
+        }
+    };
+
+    // The bias and residual registers are consumed HERE as far as hipcc can tell: its wait for them (it counts only the loads
+    // it can see, so it is a vmcnt(0)) lands in front of the K loop instead of inside it -- one round trip for the first four
+    // tiles, the bias and the residual together.
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        asm volatile("" : "+v"(acc[j]));
+        if (MODE == 2) {
+            if (g.res_split) asm volatile("" : "+v"(rh[j]), "+v"(rl[j]));
+            else asm volatile("" : "+v"(rf[j]));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(f[0], 0);
+    // step on tile kt (fragment set B & 1): tile kt + 1 (LDS buffer (B + 1) % 4) goes into the other set, tile kt + 4 is
+    // requested into buffer B -- every wave has read tile kt out of it before it arrived at this step's barrier
+    auto step = [&](auto bc, int kt) {
+        constexpr int B = decltype(bc)::value, cur = B & 1, nxt = cur ^ 1;
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PER_WAVE) : "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(f[nxt], ((B + 1) % S_NBUF) * BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const unsigned nrec = kt + 4 < nk ? NREC : 0u;
+            const int kofs = (kt + 4) * (BK * 4);
+#pragma unroll
+            for (int t = 0; t < PER_WAVE; ++t) dma(t, nrec, B * BUF, kofs);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[cur].wh[j], f[cur].xh, acc[j], 0, 0, 0);
+            accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[cur].wh[j], f[cur].xl, accx[j], 0, 0, 0);
+            accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[cur].wl[j], f[cur].xh, accx[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int kt = 0;
+    for (; kt + 4 <= nk; kt += 4) {
+        step(std::integral_constant<int, 0>(), kt);
+        step(std::integral_constant<int, 1>(), kt + 1);
+        step(std::integral_constant<int, 2>(), kt + 2);
+        step(std::integral_constant<int, 3>(), kt + 3);
+    }
+    if (kt < nk) step(std::integral_constant<int, 0>(), kt);
+    if (kt + 1 < nk) step(std::integral_constant<int, 1>(), kt + 1);
+    if (kt + 2 < nk) step(std::integral_constant<int, 2>(), kt + 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (dropped loads included; the residual registers are older than every LDS-DMA)
+
+    // ---- epilogue on registers ----
+    const float alpha = g.alpha, s1 = 1.0f / 2048.0f;
+    float amax = 0.f;
+    char* yrow = reinterpret_cast<char*>(g.Y + rrow * g.ldy);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(accx[j][e], s1, acc[j][e]);
+        if (MODE == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(v[e], 0.f);
+        } else {
+            f32x4 r;
+            if (g.res_split) {
+                const f16x4 h4 = __builtin_bit_cast(f16x4, rh[j]), l4 = __builtin_bit_cast(f16x4, rl[j]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf((float)l4[e], s1, (float)h4[e]);
+            } else
+                r = rf[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(alpha, v[e], r[e]);
+        }
+        const int c = n0 + 16 * j + 4 * q4;
+        if (g.out_split) {
+            amax = amax4(amax, v);
+            f16x4 hi, lo;
+            if (g.range_flag) {
+                f16x2p h01, l01, h23, l23;
+                split_f16x3_pair(v[0], v[1], h01, l01);
+                split_f16x3_pair(v[2], v[3], h23, l23);
+                hi = f16x4{h01[0], h01[1], h23[0], h23[1]};
+                lo = f16x4{l01[0], l01[1], l23[0], l23[1]};
+            } else {          // unguarded call: clamped halves
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 h, l;
+                    split_f16x3(v[e], h, l);
+                    hi[e] = h;
+                    lo[e] = l;
+                }
+            }
+            if (row_ok) {
+                char* yp = yrow + (c >> 5) * 128 + (c & 31) * 2;
+                *reinterpret_cast<f16x4*>(yp) = hi;
+                *reinterpret_cast<f16x4*>(yp + 64) = lo;
+            }
+        } else if (row_ok)
+            *reinterpret_cast<f32x4*>(yrow + c * 4) = v;
+    }
+    if (g.out_split && g.range_flag) note_range(row_ok ? amax : 0.f, g.range_flag);
+}
+
+// M, N, K, leading dimensions and pointers as launch_gemm checked them for the fp16x3 form; N % 80 == 0
+bool gemm_s64_ok(const GemmArgs& g, int mode) {
+    if (!(mode == 1 || mode == 2) || !g.f16x3 || g.N % S_BN != 0 || g.K % BK != 0) return false;
+    if (((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W) | reinterpret_cast<uintptr_t>(g.Y)) & 15) != 0) return false;
+    if (g.bias && (reinterpret_cast<uintptr_t>(g.bias) & 15) != 0) return false;
+    if (g.ldy % 4 != 0 || g.lda >= (1 << 21) || g.ldw >= (1 << 21)) return false;
+    if (mode == 2 && (!g.res || (reinterpret_cast<uintptr_t>(g.res) & 15) != 0 || g.ldres % 4 != 0)) return false;
+    if ((g.out_split && g.N % 32 != 0) || (mode == 2 && g.res_split && g.ldres % 32 != 0)) return false;
+    return true;
+}
+
+void launch_gemm_s64(GemmArgs g, int mode, hipStream_t s) {
+    g.tiles_n = g.N / S_BN;
+    g.tiles_n_magic = g.tiles_n > 1 ? (unsigned)((1ull << 32) / (unsigned)g.tiles_n) + 1u : 0u;
+    const dim3 grid((unsigned)(cdiv(g.M, S_BM) * g.tiles_n));
+    if (mode == 1) hipLaunchKernelGGL((gemm_s64_kernel<1>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_s64_kernel<2>), grid, dim3(256), 0, s, g);
+}
+
+}  // namespace tal

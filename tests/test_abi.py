@@ -141,7 +141,7 @@ def test_options_are_explicit_calls_not_environment():
         names.append(nm.decode())
         i += 1
     assert "tds_exact_f32" in names and "decode_small_rows" in names and len(names) == len(set(names))
-    assert N.get_option("tds_exact_f32") == 0 and N.get_option("decode_small_rows") == 256
+    assert N.get_option("tds_exact_f32") == 0 and N.get_option("decode_small_rows") == 256 and N.get_option("gconv_short_below") == 4 and N.get_option("gemm_s64_below") == 2
     N.set_option("tds_exact_f32", 1)
     assert N.get_option("tds_exact_f32") == 1
     N.set_option("tds_exact_f32", 0)

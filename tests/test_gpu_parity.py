@@ -345,6 +345,101 @@ def test_gconv_res_f16x3_matches_float64(cg, T, B):
         assert torch.equal(ys, want)
 
 
+@pytest.mark.parametrize("cg,T,B", [(10, 1501, 1), (14, 751, 2), (18, 376, 1), (18, 65, 3)])
+def test_gconv_short_tiles_equal_long_tiles(cg, T, B):
+    """Short inputs take tiles of 64 output steps (option gconv_short_below): every output is the same chain of MFMAs as on the
+    256-step (stride 2: 128-step) tiles, so fp32 and split-form results are BIT-IDENTICAL between the two."""
+    from tal_asrd_amd import ops, _native as N_
+    G = 80
+    g = torch.Generator().manual_seed(77 + cg + T)
+    x = (torch.randn(B, T, G * cg, generator=g) * 2.0).to(dev())
+    w = (torch.randn(G * cg, cg, 21, generator=g) / (21 * cg) ** 0.5).to(dev())
+    b = torch.randn(G * cg, generator=g).to(dev())
+    wf = ops.pack_gconv_f16x3_weight(w, G)
+    cog = {10: 14, 14: 18}.get(cg)
+    if cog:
+        w2 = (torch.randn(G * cog, cg, 21, generator=g) / (21 * cg) ** 0.5).to(dev())
+        b2 = torch.randn(G * cog, generator=g).to(dev())
+        wf2 = ops.pack_gconv_f16x3_weight(w2, G, stride=2)
+    xs = ops.split_f16x3(x.reshape(B * T, G * cg)) if (G * cg) % 32 == 0 else None
+    out = {}
+    try:
+        for below in (0, 1 << 20):
+            N_.set_option("gconv_short_below", below)
+            r = [ops.gconv_res_f16x3(x, wf, b, 0.25, G)]
+            if xs is not None:
+                r.append(ops.gconv_res_split(xs, (B, T, G * cg), wf, b, 0.25, G))
+            if cog and T >= 21:
+                r.append(ops.gconv_s2_f16x3(x, wf2, b2, G * cog, G))
+                if xs is not None and (G * cog) % 32 == 0:
+                    r.append(ops.gconv_s2_split(xs, (B, T, G * cg), True, wf2, b2, G * cog, G))
+            torch.cuda.synchronize()
+            out[below] = r
+    finally:
+        N_.set_option("gconv_short_below", 4)
+    assert len(out[0]) == len(out[1 << 20]) >= 2
+    for a, c in zip(out[0], out[1 << 20]):
+        assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("M,C", [(376, 1440), (1501 + 3, 800), (751, 1120), (130, 800)])
+def test_linear_f16x3_short_input_kernel(M, C):
+    """The 64 x 80-tile kernel for short inputs (csrc/gemm_s64.hip; option gemm_s64_below) against float64 and against the
+    K-sliced 128 x 160 launches it replaces: relu layer and residual layer, fp32 and split-form output, fp32 and split-form
+    residual, guarded and unguarded; rows behind the output untouched; bitwise repeatable."""
+    from tal_asrd_amd import ops, _native as N_
+    lib = N_.lib()
+    g = torch.Generator().manual_seed(M + C)
+    K = C
+    x = torch.randn(M, K, generator=g).to(dev())
+    w0 = (torch.randn(C, K, generator=g) / K ** 0.5).to(dev())
+    b0 = torch.randn(C, generator=g).to(dev())
+    xs, w0s = ops.split_f16x3(x), ops.split_f16x3(w0)
+    nws = lib.tal_linear_workspace_bytes(M, C, K)
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev())
+    flag = torch.zeros(16, dtype=torch.int32, device=dev())
+    guard = 3
+
+    def run(mode, out_split, guarded):
+        y = torch.full(((M + guard) * C * 4,), 0x5A, dtype=torch.uint8, device=dev())
+        if guarded:
+            N_.check(lib.tal_linear_f16x3_guarded_fwd(N_.ptr(xs), N_.ptr(w0s), N_.ptr(b0), N_.ptr(xs) if mode == 2 else None, 1 if mode == 2 else 0,
+                                                      0.3, mode, M, C, K, N_.ptr(y), out_split, N_.ptr(flag), N_.ptr(ws), nws, N_.stream_handle()),
+                     "tal_linear_f16x3_guarded_fwd")
+        else:
+            N_.check(lib.tal_linear_f16x3_fwd(N_.ptr(xs), N_.ptr(w0s), N_.ptr(b0), N_.ptr(x) if mode == 2 else None, 0.3, mode, M, C, K, N_.ptr(y),
+                                              out_split, N_.ptr(ws), nws, N_.stream_handle()), "tal_linear_f16x3_fwd")
+        torch.cuda.synchronize()
+        assert bool((y[M * C * 4:] == 0x5A).all())
+        return y[:M * C * 4]
+
+    def decode(y, out_split):
+        if not out_split:
+            return y.view(torch.float32).reshape(M, C)
+        h = y.view(torch.float16).reshape(M, C // 32, 64).float()
+        return (h[:, :, :32] + h[:, :, 32:] / 2048.0).reshape(M, C)
+
+    xd = decode(xs.view(torch.uint8).reshape(-1), 1).double()         # what both kernels are given
+    lin = xd @ w0.double().t() + b0.double()
+    tol = 2e-5 * max(1.0, K ** 0.5 / 8)
+    try:
+        for mode, out_split, guarded in [(1, 0, False), (2, 0, False), (1, 1, False), (1, 1, True), (2, 1, True), (2, 0, True)]:
+            N_.set_option("gemm_s64_below", 1 << 20)
+            a = run(mode, out_split, guarded)
+            assert torch.equal(a, run(mode, out_split, guarded))
+            N_.set_option("gemm_s64_below", 0)
+            b = run(mode, out_split, guarded)
+            res = (xd if guarded else x.double())
+            ref = torch.relu(lin) if mode == 1 else res + 0.3 * lin
+            ea = float((decode(a, out_split).double() - ref).abs().max())
+            eb = float((decode(b, out_split).double() - ref).abs().max())
+            assert ea < tol and eb < tol, (mode, out_split, guarded, ea, eb)
+            assert float((decode(a, out_split) - decode(b, out_split)).abs().max()) < 2e-5, (mode, out_split, guarded)
+    finally:
+        N_.set_option("gemm_s64_below", 2)
+    assert int(flag[0]) == 0
+
+
 @pytest.mark.parametrize("cig,cog,T,B", [(10, 14, 300, 1), (14, 18, 277, 2), (10, 14, 1000, 2), (14, 18, 21, 1), (14, 18, 22, 1),
                                         (10, 14, 555, 1)])
 def test_gconv_s2_f16x3_matches_float64(cig, cog, T, B):

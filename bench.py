@@ -562,8 +562,9 @@ def main():
             issued = gm["work"] + (0.0 if f32_only else 2.0 * pw)
             nb = len(mine) if args.workload == "segments" else (args.segments if args.batched else 1)
             line["roofline"] = {"bound": "mfma",
-                                "kernel": "tal::gemm_glds_kernel (dense layers; TDS pointwise layers in the fp16x3 form: fp32 "
-                                          "products as 3 f16 MFMAs, fp32 accumulate)" if not f32_only else
+                                "kernel": "tal::gemm_w64_kernel (256 x 160 tiles; launches below one round of them: gemm_glds_kernel / "
+                                          "gemm_s64_kernel) -- the dense layers; TDS pointwise layers in the fp16x3 form: fp32 "
+                                          "products as 3 f16 MFMAs, fp32 accumulate" if not f32_only else
                                           "tal::gemm_glds_kernel (fp32 MFMA dense layer, all epilogues)",
                                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                                 "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,

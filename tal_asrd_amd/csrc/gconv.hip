@@ -362,6 +362,10 @@ typedef _Float16 f16x8a8 __attribute__((ext_vector_type(8), aligned(8)));
 #ifndef GC_PF
 #define GC_PF 2
 #endif
+// K permutation of the fragment reads (GcLayout::PERM); 0: plain order (ablation)
+#ifndef GC_KPERM
+#define GC_KPERM 1
+#endif
 #define GC_LB(CIG, STRIDE) (((CIG) > 16 && (STRIDE) == 1) ? GC_LB18 : 2)
 typedef _Float16 f16x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -381,6 +385,15 @@ struct GcLayout {
     static constexpr int tap0(int s) { return STRIDE == 2 ? s : 0; }
     static constexpr int nk(int s) { return s < NSEG ? ((ntap(s) - 1) * pitch(s) + nch(s) + 31) / 32 : 0; }
     static constexpr int NKS = nk(0) + nk(1);
+    // K permutation against LDS bank conflicts (single-segment stride-1 layouts whose rows are an ODD number of 8-byte bank
+    // pairs apart: 12 or 20 halves).  Lanes 0-31 of a fragment read are 16 output steps x 2 k groups; with the k groups 16
+    // bytes apart every such read is a 2-way conflict (p * d = 4 mod 64 banks has a solution |d| <= 15 for p = 6, 10: SQ_LDS_
+    // BANK_CONFLICT = 48 % of the LDS cycles, the LDS array 70-75 % busy); 128 bytes apart it is conflict-free -- the 16 rows
+    // fill every other bank pair, the second k group the rest.  So inside a block of 128 slab halves (4 K chunks) MFMA j takes
+    // its k groups 0..3 from the 16-byte pieces j, j + 8, j + 4, j + 12; the weights are packed with the same permutation
+    // (pack_gconv_mfma_kernel).  Chunks behind the last whole block of four keep the plain order.
+    static constexpr bool PERM = NSEG == 1 && STRIDE == 1 && pitch(0) % 8 == 4 && GC_KPERM;
+    static constexpr int NKP = PERM ? (nk(0) / 4) * 4 : 0;
     static constexpr int rows(int s, int tt) { return STRIDE == 2 ? tt + ntap(s) - 1 : tt + KS - 1; }
     static constexpr int slab(int s, int tt) {       // halves, incl. the K round-up the last output step reads past its window
         if (s >= NSEG) return 0;
@@ -392,6 +405,7 @@ struct GcLayout {
 // runtime mirror for the weight packer
 struct GcPackDesc {
     int nseg, pitch[2], ntap[2], nch[2], choff[2], tap0[2], nk[2], tapstep, cig, cog, mt_n, groups;
+    int perm_nk;      // K chunks of segment 0 in the permuted order (GcLayout::PERM)
 };
 template <int CIG, int STRIDE>
 static GcPackDesc make_pack_desc(int cog, int groups) {
@@ -403,6 +417,7 @@ static GcPackDesc make_pack_desc(int cog, int groups) {
         d.choff[s2] = LY::choff(s2); d.tap0[s2] = LY::tap0(s2); d.nk[s2] = LY::nk(s2);
     }
     d.tapstep = STRIDE; d.cig = CIG; d.cog = cog; d.mt_n = (cog + 15) / 16; d.groups = groups;
+    d.perm_nk = LY::NKP;
     return d;
 }
 // the (C_in/G, C_out/G, stride) combinations with a kernel; false: none
@@ -598,18 +613,31 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
             if (i < nvalid) bv[i] = bias[g * COG + ch0 + i];
         const int tbeg = part * NBW, tend = (part + 1) * NBW;
         // fragment of K chunk c for output column (16 tb + col): segment base + (16 tb + col) * pitch + 8 kg + 32 ks
-        const _Float16* hs = s_hi + gl * GS + 8 * kg;
-        const _Float16* ls = s_lo + gl * GS + 8 * kg;
+        // (LY::PERM: k group kg of the chunks below LY::NKP sits 64 (kg & 1) + 32 (kg >> 1) halves into its block of 128)
+        constexpr int NKP = LY::NKP;
+        const int kgo = LY::PERM ? 64 * (kg & 1) + 32 * (kg >> 1) : 8 * kg;
+        const _Float16* hs = s_hi + gl * GS + kgo;
+        const _Float16* ls = s_lo + gl * GS + kgo;
         int four = 4;                        // (opaque to the compiler: hs2 / ls2 become separate base registers, still LDS pointers)
         asm volatile("" : "+v"(four));
         const _Float16* hs2 = hs + four;     // second halves of the fragments (gconv_frag)
         const _Float16* ls2 = ls + four;
+        // chunks behind the last whole block of four: plain order
+        const _Float16* hst = s_hi + gl * GS + 8 * kg;
+        const _Float16* lst = s_lo + gl * GS + 8 * kg;
+        const _Float16* hst2 = hst + four;
+        const _Float16* lst2 = lst + four;
         int boff0 = (tbeg * 16 + col) * P0, boff1 = SL0 + (tbeg * 16 + col) * P1;
-        auto frag_off = [&](int c, int b0, int b1) { return c < NK0 ? b0 + 32 * c : b1 + 32 * (c - NK0); };
+        auto frag_off = [&](int c, int b0, int b1) {
+            return c < NKP ? b0 + 128 * (c >> 2) + 8 * (c & 3) : (c < NK0 ? b0 + 32 * c : b1 + 32 * (c - NK0));
+        };
         auto frag = [&](const _Float16* base, int c, int b0, int b1) {
-            const _Float16* base2 = base == hs ? hs2 : ls2;
-            return c < NK0 ? gconv_frag<P0>(base + frag_off(c, b0, b1), base2 + frag_off(c, b0, b1))
-                           : gconv_frag<P1>(base + frag_off(c, b0, b1), base2 + frag_off(c, b0, b1));
+            const bool is_hi = base == hs;
+            const bool plain = LY::PERM && c >= NKP;
+            const _Float16* b1p = plain ? (is_hi ? hst : lst) : base;
+            const _Float16* b2p = plain ? (is_hi ? hst2 : lst2) : (is_hi ? hs2 : ls2);
+            return c < NK0 ? gconv_frag<P0>(b1p + frag_off(c, b0, b1), b2p + frag_off(c, b0, b1))
+                           : gconv_frag<P1>(b1p + frag_off(c, b0, b1), b2p + frag_off(c, b0, b1));
         };
         // operand fragments are read PF K chunks ahead of their MFMAs (a ring of PF + 1 register slots; the first PF chunks of the
         // next block are read under the last MFMAs of the current one and carried across the epilogue)
@@ -834,7 +862,9 @@ __global__ void pack_gconv_mfma_kernel(const float* __restrict__ src, _Float16* 
     r /= nks;
     const int mt = (int)(r % d.mt_n), g = (int)(r / d.mt_n);
     const int sg = c < d.nk[0] ? 0 : 1, ks = c - (sg ? d.nk[0] : 0);
-    const int co = mt * 16 + (l & 15), k = 32 * ks + 8 * (l >> 4) + i;
+    const int kg = l >> 4;
+    const int co = mt * 16 + (l & 15);
+    const int k = (sg == 0 && ks < d.perm_nk) ? 128 * (ks >> 2) + 8 * (ks & 3) + 64 * (kg & 1) + 32 * (kg >> 1) + i : 32 * ks + 8 * kg + i;
     const int j = k / d.pitch[sg], cc = k - j * d.pitch[sg];
     float v = 0.f;
     if (co < d.cog && j < d.ntap[sg] && cc < d.nch[sg])

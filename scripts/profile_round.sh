@@ -15,7 +15,7 @@ TAL_OPTIONS=tds_exact_f32 python bench.py --no-cpu-baseline > $O/bench_1h_fp32.j
 TAL_OPTIONS=tds_fp32_activations python bench.py --no-cpu-baseline > $O/bench_1h_fp32_activations.json 2> /dev/null
 python bench.py --workload segments --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_segments_64x5min.json 2> /dev/null
 python bench.py --workload decode --no-cpu-baseline --steps 2 --warmup 1 > $O/bench_decode_1h_episode.json 2> /dev/null
-python scripts/bench_short.py 10 30 60 300 > $O/short_clips.txt 2>&1
+python scripts/bench_short.py 10 30 60 120 300 600 > $O/short_clips_product.txt 2>&1
 python scripts/bench_greedy_step.py 1 16 32 64 128 256 > $O/decode_step.txt 2>&1
 python scripts/bench_episode_streams.py 3600 8 2>&1 | grep -v amdgpu.ids > $O/episode_streams.txt
 cd /tmp && export TMPDIR=/tmp
@@ -34,9 +34,9 @@ python scripts/pmc_generic.py $I tal > $O/pmc_inst_all_kernels.txt
 S=$(find $O/stats -name "*.db" | head -1); F=$(find $O/pmc_fetch -name "*.db" | head -1); W=$(find $O/pmc_write -name "*.db" | head -1)
 python scripts/rocpd_summary.py $S > $O/bench_1h_kernel_stats.txt
 python scripts/pmc_traffic_json.py $F $W > $O/pmc_traffic.json
-(python scripts/rocpd_pmc.py $F tal::; python scripts/rocpd_pmc.py $W tal::) > $O/pmc_traffic_all_kernels.txt
+(python scripts/rocpd_pmc.py $F tal; python scripts/rocpd_pmc.py $W tal) > $O/pmc_traffic_all_kernels.txt
 python scripts/rocpd_summary.py $(find $O/dstats -name "*.db" | head -1) > $O/decode_5min_kernel_stats.txt
 python scripts/rocpd_sequence.py $(find $O/gstep -name "*.db" | head -1) 37 > $O/decode_step_U32_kernel_sequence.txt
-python scripts/rocpd_sequence.py $(find $O/short -name "*.db" | head -1) 70 > $O/clip_30s_kernel_sequence.txt
+python scripts/rocpd_sequence.py $(find $O/short -name "*.db" | head -1) 52 > $O/clip_30s_kernel_sequence.txt
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_inst $O/dstats $O/gstep $O/short
 ls -la $O

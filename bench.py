@@ -226,20 +226,50 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # TAL_BENCH_BACKEND=gloo is a plumbing self-test only (N ranks sharing the visible GPUs, results
     # staged through host memory); real runs use RCCL ("nccl") with one GPU per rank.
-    backend = "gloo" if fake else os.environ.get("TAL_BENCH_BACKEND", "nccl")
+    backend = "gloo" if (fake and not os.environ.get("TAL_BENCH_RCCL_FAIL")) else os.environ.get("TAL_BENCH_BACKEND", "nccl")
     if fake:
         dev = torch.device("cpu")
     else:
-        dev = torch.device("cuda", local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank)
+        # (fewer visible GPUs than ranks happens in the plumbing tests only: the ranks then share them)
+        dev = torch.device("cuda", local_rank % torch.cuda.device_count() if torch.cuda.device_count() < world else local_rank)
         torch.cuda.set_device(dev)
     dist = None
+    backend_note = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # RCCL first; if the communicator cannot be built or its first collective RAISES (symmetric over the ranks: IPC /
+            # driver set-up), the run continues on gloo with results staged through host memory and SAYS SO in its line
+            # (`collective_backend`) -- a degraded number beats none on a node nobody could try beforehand.  (A communicator
+            # that hangs instead is beyond this: torch's watchdog ends the process after the timeout; measured on a one-GPU
+            # box with two ranks, where RCCL waits for the duplicate device for the whole 300 s.)
+            try:
+                if os.environ.get("TAL_BENCH_RCCL_FAIL"):       # (tests: take the fall-back path without touching RCCL)
+                    raise RuntimeError("TAL_BENCH_RCCL_FAIL is set")
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError("RCCL all_reduce returned %r for %d ranks" % (probe.item(), world))
+            except Exception as e:          # noqa: BLE001
+                backend_note = "gloo (RCCL unusable: %s)" % str(e).splitlines()[0][:200]
+                print("[bench] rank %d: %s" % (rank, backend_note), file=sys.stderr, flush=True)
+                had_group = dist.is_initialized()
+                try:
+                    dist.destroy_process_group()
+                except Exception:           # noqa: BLE001
+                    pass
+                backend = "gloo"
+                # (rank 0 served the first rendezvous store itself unless torchrun's agent does: a store that was opened may
+                #  linger on its port)
+                if had_group and not os.environ.get("TORCHELASTIC_USE_AGENT_STORE"):
+                    os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
 
     def sync():
         if not fake:
@@ -516,6 +546,8 @@ def main():
                        "audio_resident_in_hbm": True},
         }
         line.update(extra)
+        if world > 1:
+            line["collective_backend"] = backend_note or ("rccl" if backend == "nccl" else backend)
         if fake:
             line["data"] = "FAKE (TAL_BENCH_FAKE plumbing self-test: no GPU work, not a measurement)"
         if args.workload == "segments":

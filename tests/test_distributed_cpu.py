@@ -5,6 +5,8 @@ import socket
 import subprocess
 import sys
 
+import pytest
+
 from tests.conftest import ROOT
 
 
@@ -55,3 +57,28 @@ def test_bench_entry_more_ranks_than_segments():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 3 and line["gathered_segments"] == 2
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_falls_back_to_gloo_when_rccl_raises(launcher):
+    """A run whose RCCL communicator cannot be built (simulated: TAL_BENCH_RCCL_FAIL raises where init_process_group("nccl")
+    would) continues on gloo and says so in its line -- under bench.py's own launcher and under torch.distributed.run."""
+    import json
+    env = dict(os.environ, TAL_BENCH_FAKE="1", TAL_BENCH_RCCL_FAIL="1", MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TAL_BENCH_BACKEND"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--segments", "4", "--seconds", "30"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["gathered_segments"] == 4
+    assert line["collective_backend"].startswith("gloo (RCCL unusable")

@@ -759,7 +759,32 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
                 if (tail < best) { best = tail; split = sp; }
             }
         }
-        if (split < 2) {
+        // One partial round of 160-wide tiles that already puts two workgroups on some CUs (256 < tiles <= 512) runs as long as
+        // a full one.  When N is a multiple of 96 and the 5/3 as many 96-wide tiles still fit the round, they finish in ~0.6 of
+        // it with every CU busy (5-minute clip, stage 3: 270 -> 450 tiles).  Same MFMA chain per output: bit-identical results.
+        // Cost per K step of a round, us (scripts/bench_gemm_short.py): 0.82 with one workgroup per CU, 1.27 with two, x NSUB / 5.
+        bool n96 = false;
+        int64_t nb3 = 0;
+        // (only the split-form layers of a TDS block -- the launches launch_glds_stage sends to the static-addressing epilogue; the
+        //  generic epilogue's row / column arithmetic is written for 160- and 32-column waves)
+        const bool epi_ok = g.out_split && g.range_flag && g.ldy % 4 == 0 && g.ldy < (1 << 21) && (reinterpret_cast<uintptr_t>(g.Y) & 15) == 0 &&
+                            (mode != 2 || (g.res_split && g.ldres % 4 == 0 && g.ldres < (1 << 21) && (reinterpret_cast<uintptr_t>(g.res) & 15) == 0));
+        if (split < 2 && epi_ok && g.f16x3 && nbatch == 1 && (mode == 1 || mode == 2) && g.N % 96 == 0 && !opt(OPT_GEMM_NO_N96)) {
+            nb3 = cdiv(g.M, 128) * (g.N / 96);
+            auto cost = [&](int64_t tiles, double scale) {
+                const int64_t fr = tiles / slots, r = tiles % slots;
+                const double two = 10.0 + 1.27 * scale * nk, one = 10.0 + 0.82 * scale * nk;
+                return fr * two + (r == 0 ? 0.0 : (r <= slots / 2 ? one : two));
+            };
+            n96 = nb3 < (1ll << 31) && cost(nb3, 0.6) < 0.95 * cost(nb, 1.0);
+        }
+        if (n96) {
+            GemmArgs h = g;
+            h.tiles_n = g.N / 96;
+            h.tiles_n_magic = h.tiles_n > 1 ? (unsigned)((1ull << 32) / (unsigned)h.tiles_n) + 1u : 0u;
+            if (mode == 1) launch_glds_stage<1, 3, false>(h, dim3((unsigned)nb3), s);
+            else launch_glds_stage<2, 3, false>(h, dim3((unsigned)nb3), s);
+        } else if (split < 2) {
             launch_glds<5>(g, mode, false, grid, s);
         } else {
             GemmArgs h = g;

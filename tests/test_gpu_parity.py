@@ -382,6 +382,49 @@ def test_gconv_short_tiles_equal_long_tiles(cg, T, B):
         assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("M", [1900, 3751])
+def test_linear_f16x3_96_wide_tiles_equal_160_wide_tiles(M):
+    """Mid-sized launches with N % 96 == 0 (a 5-minute clip's third stage) take 128 x 96 tiles when those fill the chip better than
+    128 x 160 (option gemm_no_n96): the same MFMA chain per output, so relu layer and split-residual layer are BIT-IDENTICAL."""
+    from tal_asrd_amd import ops, _native as N_
+    lib = N_.lib()
+    C = K = 1440
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=g).to(dev())
+    w0 = (torch.randn(C, K, generator=g) / K ** 0.5).to(dev())
+    b0 = torch.randn(C, generator=g).to(dev())
+    xs, w0s = ops.split_f16x3(x), ops.split_f16x3(w0)
+    nws = lib.tal_linear_workspace_bytes(M, C, K)
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev())
+    flag = torch.zeros(16, dtype=torch.int32, device=dev())
+
+    def run(mode):
+        y = torch.full(((M + 2) * C * 4,), 0x5A, dtype=torch.uint8, device=dev())
+        N_.check(lib.tal_linear_f16x3_guarded_fwd(N_.ptr(xs), N_.ptr(w0s), N_.ptr(b0), N_.ptr(xs) if mode == 2 else None, 1 if mode == 2 else 0,
+                                                  0.3, mode, M, C, K, N_.ptr(y), 1, N_.ptr(flag), N_.ptr(ws), nws, N_.stream_handle()),
+                 "tal_linear_f16x3_guarded_fwd")
+        torch.cuda.synchronize()
+        assert bool((y[M * C * 4:] == 0x5A).all())
+        return y
+    try:
+        N_.set_option("gemm_s64_below", 0)          # (1900 rows would otherwise take the 64 x 80 tiles)
+        for mode in (1, 2):
+            N_.set_option("gemm_no_n96", 0)
+            a = run(mode)
+            N_.set_option("gemm_no_n96", 1)
+            assert torch.equal(a, run(mode)), mode
+    finally:
+        N_.set_option("gemm_no_n96", 0)
+        N_.set_option("gemm_s64_below", 2)
+    h = a[:M * C * 4].view(torch.float16).reshape(M, C // 32, 64).float()
+    got = (h[:, :, :32] + h[:, :, 32:] / 2048.0).reshape(M, C).double()
+    xd = ops.split_f16x3(x)[:M * K * 4].view(torch.float16).reshape(M, K // 32, 64).float()
+    xd = (xd[:, :, :32] + xd[:, :, 32:] / 2048.0).reshape(M, K).double()
+    ref = xd + 0.3 * (xd @ w0.double().t() + b0.double())
+    assert float((got - ref).abs().max()) < 2e-5 * max(1.0, K ** 0.5 / 8)
+    assert int(flag[0]) == 0
+
+
 @pytest.mark.parametrize("M,C", [(376, 1440), (1501 + 3, 800), (751, 1120), (130, 800)])
 def test_linear_f16x3_short_input_kernel(M, C):
     """The 64 x 80-tile kernel for short inputs (csrc/gemm_s64.hip; option gemm_s64_below) against float64 and against the

@@ -669,7 +669,13 @@ extern "C" size_t tal_sd_head_workspace_bytes(int64_t M, int S) {
     // (value, index) partials of the fused arg-max: one pair per row and per 32-column wave slice.  The small-M
     // kernel (32 x 128 tile, 4 waves side by side) writes 4 slots per 128-column tile, the last tile included
     // even when it is partly past S, hence the second term.
-    return (size_t)(M > 0 ? M : 1) * (size_t)sd_head_part_ld(S) * 8;
+    const size_t partials = (size_t)(M > 0 ? M : 1) * (size_t)sd_head_part_ld(S) * 8;
+    // The same bytes serve first as K-slice scratch of the embedding layer (1440 -> 128: ONE column tile, so a clip of minutes is
+    // a few dozen 128-row tiles for 256 CUs -- 120 us on 30 workgroups for a 5-minute clip; cut along K 8 ways it is ~30 us).
+    // launch_gemm slices only launches below a quarter round (128 tiles).
+    const int64_t tiles = cdiv(M > 0 ? M : 1, 128);
+    const size_t slices = tiles <= 128 ? (size_t)tiles * 8 * 128 * 160 * sizeof(float) : 0;
+    return partials > slices ? partials : slices;
 }
 
 extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_embed, const float* b_embed, int E,
@@ -678,7 +684,11 @@ extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_
     TAL_CHECK_ARG(x && w_embed && w_logit && feat, "tal_sd_head_fwd: null pointer");
     TAL_CHECK_ARG(M >= 0 && C > 0 && E > 0 && S > 0, "tal_sd_head_fwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_linear(x, w_embed, b_embed, nullptr, 0.f, 0, M, E, C, feat, s);
+    // (with a workspace the embedding layer of a short / medium input is cut along K: see tal_sd_head_workspace_bytes; the
+    //  workspace's later use -- arg-max partials -- is ordered behind it on the stream)
+    int rc = workspace && workspace_bytes >= tal_sd_head_workspace_bytes(M, S) && M > 512
+                 ? launch_linear_ws(x, w_embed, b_embed, nullptr, 0.f, 0, M, E, C, feat, reinterpret_cast<float*>(workspace), workspace_bytes, s)
+                 : launch_linear(x, w_embed, b_embed, nullptr, 0.f, 0, M, E, C, feat, s);
     if (rc) return rc;
     if (!logits && !ids) return TAL_OK;
     if (logits) {

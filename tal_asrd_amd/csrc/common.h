@@ -109,6 +109,7 @@ enum Option {
     OPT_LOGMEL_NO_FOLD,           // plans built afterwards use the direct 400-term DFT (no symmetric-window folding)
     OPT_DECODE_NO_SMALL,          // decoder layers on the batched-GEMM path even for a decode step
     OPT_DECODE_SMALL_ROWS,        // largest prefix (rows) the latency-oriented decoder layer takes (default 256)
+    OPT_GEMM_NO_ROW_SPLIT,        // never split a one-round-plus-remainder fp16x3 launch into two launches by rows
     OPT_GEMM_NO_N96,              // never the 128 x 96 tiles for mid-sized fp16x3 launches (N % 96 == 0)
     OPT_GEMM_S64_BELOW,           // fp16x3 relu / residual layers take 64 x 80 tiles while those number at most this many per CU (default 2; 0: never)
     OPT_GCONV_SHORT_BELOW,        // grouped convs take 64-step tiles while the long tiles give a CU fewer workgroups than this (default 4)

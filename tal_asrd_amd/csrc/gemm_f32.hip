@@ -678,6 +678,26 @@ int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s) {
         h.tiles_n_magic = h.tiles_n > 1 ? (unsigned)((1ull << 32) / (unsigned)h.tiles_n) + 1u : 0u;
         const int64_t nb = cdiv(g.M, 256) * h.tiles_n;
         if (nb >= slots && nb < (1ll << 31) && nb * h.tiles_n < (1ll << 32)) {
+            // ONE full round and a remainder of a few thousand rows (a 5-minute clip's first stage: 295 tiles): the rows of the
+            // whole round's row blocks run here, the rest goes back through this dispatcher as a launch of its own (64 x 80 or
+            // 128 x 96 / 160 tiles) -- K slices of the 39 leftover tiles plus their fix-up launch cost 34 us on top of the
+            // round's 45, the second launch ~16.  Rows are independent: results do not change.
+            const int64_t rb = slots / h.tiles_n, rows1 = rb * 256;
+            if (nb < 2 * slots && nb % slots != 0 && g.M - rows1 > 128 && g.M - rows1 <= 4096 && !opt(OPT_GEMM_NO_ROW_SPLIT)) {
+                {
+                    ProfScope prof(PROF_GEMM, 2.0 * (double)rows1 * (double)g.N * (double)g.K, s);
+                    GemmArgs a = h;
+                    a.M = rows1;
+                    launch_gemm_w64(a, mode, false, dim3((unsigned)(rb * h.tiles_n)), s);
+                    TAL_CHECK_LAUNCH("gemm (256 x 160 tiles)");
+                }
+                GemmArgs r = g;
+                r.M = g.M - rows1;
+                r.A = g.A + rows1 * g.lda;
+                r.Y = g.Y ? g.Y + rows1 * g.ldy : nullptr;
+                r.res = g.res ? g.res + rows1 * g.ldres : nullptr;
+                return launch_gemm(r, mode, 1, s);
+            }
             ProfScope prof(PROF_GEMM, 2.0 * (double)g.M * (double)g.N * (double)g.K, s);
             const int64_t rem = nb % slots, full = nb - rem;
             const int nk = g.K / BK;

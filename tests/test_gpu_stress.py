@@ -279,3 +279,53 @@ def test_fp16_range_guard_routes_to_exact_kernels():
         tds.blocks[0][1][0].fc[0].weight[0, 0, 0] = 1.0e6
     tds._descriptor()
     assert tds._packs[0]["blocks"][0]["fc0_split"] is None
+
+
+def test_tds_dense_pair_random_row_counts():
+    """The TDS block's dense pair (relu layer -> split-residual layer, split form in and out, under the range guard) at row
+    counts that walk every branch of the dispatcher -- 64 x 80 tiles, K-sliced 128 x 160 tiles, 128 x 96 tiles, the 256 x 160
+    kernel with and without its K-sliced tail, a 256 x 160 round + a short-input launch for the remaining rows -- against
+    float64, with guard rows behind both outputs and a bitwise repeat."""
+    from tal_asrd_amd import ops, _native as N_
+    lib = N_.lib()
+    rng = np.random.default_rng(11)
+    rows = {800: [129, 130, 1500, 3200, 3300, 13056, 13057, 13056 + 129, 15001, 17200, 26200],
+            1120: [333, 1170, 1200, 4600, 9216 + 200, 9216 + 4096, 9216 + 4097],
+            1440: [376, 1819, 1825, 3751, 4267, 4300, 7168 + 64, 7168 + 333, 7501, 12000]}
+    for C, ms in rows.items():
+        g = torch.Generator().manual_seed(C)
+        w0 = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev()); b0 = torch.randn(C, generator=g).to(dev())
+        w1 = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev()); b1 = torch.randn(C, generator=g).to(dev())
+        w0s, w1s = ops.split_f16x3(w0), ops.split_f16x3(w1)
+        w0d, w1d, b0d, b1d = w0.double(), w1.double(), b0.double(), b1.double()
+        for M in ms:
+            x = torch.randn(M, C, generator=g).to(dev())
+            xs = ops.split_f16x3(x)
+            nws = lib.tal_linear_workspace_bytes(M, C, C)
+            ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev())
+            flag = torch.zeros(16, dtype=torch.int32, device=dev())
+            guard = 2
+
+            def pair():
+                hs = torch.full(((M + guard) * C * 4,), 0x5A, dtype=torch.uint8, device=dev())
+                ys = torch.full(((M + guard) * C * 4,), 0x5A, dtype=torch.uint8, device=dev())
+                N_.check(lib.tal_linear_f16x3_guarded_fwd(N_.ptr(xs), N_.ptr(w0s), N_.ptr(b0), None, 0, 0.0, 1, M, C, C, N_.ptr(hs), 1,
+                                                          N_.ptr(flag), N_.ptr(ws), nws, N_.stream_handle()), "relu layer")
+                N_.check(lib.tal_linear_f16x3_guarded_fwd(N_.ptr(hs), N_.ptr(w1s), N_.ptr(b1), N_.ptr(xs), 1, 0.3, 2, M, C, C, N_.ptr(ys), 1,
+                                                          N_.ptr(flag), N_.ptr(ws), nws, N_.stream_handle()), "residual layer")
+                torch.cuda.synchronize()
+                return hs, ys
+
+            def decode(buf):
+                h = buf[:M * C * 4].view(torch.float16).reshape(M, C // 32, 64).float()
+                return (h[:, :, :32] + h[:, :, 32:] / 2048.0).reshape(M, C).double()
+            hs, ys = pair()
+            hs2, ys2 = pair()
+            assert torch.equal(hs, hs2) and torch.equal(ys, ys2), (C, M)
+            assert bool((hs[M * C * 4:] == 0x5A).all()) and bool((ys[M * C * 4:] == 0x5A).all()), (C, M)
+            xd = decode(xs.view(torch.uint8).reshape(-1))
+            hd = decode(hs)
+            tol = 2e-5 * max(1.0, C ** 0.5 / 8)
+            assert float((hd - torch.relu(xd @ w0d.t() + b0d)).abs().max()) < tol, (C, M)
+            assert float((decode(ys) - (xd + 0.3 * (hd @ w1d.t() + b1d))).abs().max()) < tol, (C, M)
+            assert int(flag[0]) == 0

@@ -28,10 +28,10 @@ constexpr int NFFT = 400;
 constexpr int HOP = 160;
 constexpr int NBIN = 201;
 constexpr int NMEL = 80;
-constexpr int FB = 32;                         // frames per workgroup
+constexpr int FB = 32;                         // frames per workgroup (long inputs); short inputs: FB_SHORT
+constexpr int FB_SHORT = 16;                   // (half the matrix work per wave, twice the workgroups: a 30-second clip is 94 workgroups of 32 frames)
 constexpr int NTILE = 13;                      // 13 x 16 = 208 >= 201 bins
-constexpr int NS = (FB - 1) * HOP + NFFT + 1;  // 5361 samples per workgroup (+1: the folded DFT touches x[400])
-constexpr int NSP = NS + NS / HOP + 2;         // + one pad word per hop
+// samples per workgroup: (FB - 1) * HOP + NFFT + 1 (+1: the folded DFT touches x[400]), + one pad word per hop (in the kernel)
 constexpr int NFOLD = 204;                     // folded DFT length: n = 0..200, padded to a multiple of 4
 constexpr int PLD = NTILE * 16 + 1;            // power tile pitch (209)
 constexpr int HTILE = 7;                       // 7 x 16 = 112 >= 101 bins (k = 0..100) of the even / odd half transforms
@@ -49,9 +49,12 @@ struct LogmelPlan {
     float mel_w[NMEL * MAXW];
 };
 
+template <int FBT>       // frames per workgroup: 32 (two 16-frame MFMA row blocks per wave and bin tile) or 16 (one)
 __global__ __launch_bounds__(256, 3) void logmel_kernel(const LogmelPlan* __restrict__ plan,
                                                     const float* __restrict__ audio, int64_t L, int64_t T, float eps,
                                                     float* __restrict__ out, double* __restrict__ partial) {
+    constexpr int FB = FBT, NS = (FB - 1) * HOP + NFFT + 1, NSP = NS + NS / HOP + 2;
+    constexpr bool TWO = FBT == 32;
     __shared__ float samp[NSP];
     __shared__ float P[FB * PLD];
     __shared__ double red[4];
@@ -102,13 +105,15 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const LogmelPlan* __rest
                     const int on = n + (n >= HOP ? 1 : 0);            // + pad words crossed
                     const int om = m + (m >= 2 * HOP ? 2 : 1);
                     const double x0n = (double)s0[on], x0m = (double)s0[om];
-                    const double x1n = (double)s1[on], x1m = (double)s1[om];
                     const f64x2 bb = fq[k * 16];
                     const double br = bb.x, bi = bb.y;
                     r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0n + x0m, br, r0, 0, 0, 0);
                     i0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0n - x0m, bi, i0, 0, 0, 0);
-                    r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1n + x1m, br, r1, 0, 0, 0);
-                    i1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1n - x1m, bi, i1, 0, 0, 0);
+                    if constexpr (TWO) {
+                        const double x1n = (double)s1[on], x1m = (double)s1[om];
+                        r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1n + x1m, br, r1, 0, 0, 0);
+                        i1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1n - x1m, bi, i1, 0, 0, 0);
+                    }
                 }
                 if (par == 0) { re0 = r0; im0 = i0; re1 = r1; im1 = i1; }
                 else { ore0 = r0; oim0 = i0; ore1 = r1; oim1 = i1; }
@@ -123,8 +128,10 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const LogmelPlan* __rest
                     const double a1 = re1[e] + ore1[e], b1 = im1[e] + oim1[e], c1 = re1[e] - ore1[e], d1 = im1[e] - oim1[e];
                     P[frame * PLD + bin] = (float)(a0 * a0 + b0 * b0);
                     P[frame * PLD + NFFT / 2 - bin] = (float)(c0 * c0 + d0 * d0);
-                    P[(frame + 16) * PLD + bin] = (float)(a1 * a1 + b1 * b1);
-                    P[(frame + 16) * PLD + NFFT / 2 - bin] = (float)(c1 * c1 + d1 * d1);
+                    if constexpr (TWO) {
+                        P[(frame + 16) * PLD + bin] = (float)(a1 * a1 + b1 * b1);
+                        P[(frame + 16) * PLD + NFFT / 2 - bin] = (float)(c1 * c1 + d1 * d1);
+                    }
                 }
             }
             continue;
@@ -139,13 +146,15 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const LogmelPlan* __rest
 #pragma unroll
                 for (int kk = 0; kk < 40; kk += 4) {
                     const double a0 = (double)sp0[base + kk];
-                    const double a1 = (double)sp1[base + kk];
                     const double br = bq[kk * 32];
                     const double bi = bq[kk * 32 + 16];
                     re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, br, re0, 0, 0, 0);
                     im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bi, im0, 0, 0, 0);
-                    re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, br, re1, 0, 0, 0);
-                    im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bi, im1, 0, 0, 0);
+                    if constexpr (TWO) {
+                        const double a1 = (double)sp1[base + kk];
+                        re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, br, re1, 0, 0, 0);
+                        im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bi, im1, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const LogmelPlan* __rest
         for (int e = 0; e < 4; ++e) {
             const int frame = kq + 4 * e;
             P[frame * PLD + j * 16 + fi] = (float)(re0[e] * re0[e] + im0[e] * im0[e]);
-            P[(frame + 16) * PLD + j * 16 + fi] = (float)(re1[e] * re1[e] + im1[e] * im1[e]);
+            if constexpr (TWO) P[(frame + 16) * PLD + j * 16 + fi] = (float)(re1[e] * re1[e] + im1[e] * im1[e]);
         }
     }
     __syncthreads();
@@ -330,7 +339,7 @@ extern "C" int tal_logmel_plan_init(const float* window, const float* fb, void* 
 
 extern "C" size_t tal_logmel_workspace_bytes(int B, int64_t L) {
     const int64_t T = 1 + L / HOP;
-    return (size_t)(B * cdiv(T, FB) + 4) * sizeof(double);
+    return (size_t)(B * cdiv(T, FB_SHORT) + 4) * sizeof(double);
 }
 
 extern "C" int tal_logmel_fwd(const void* plan, const float* audio, int B, int64_t L, float eps, int subtract_mean,
@@ -344,14 +353,20 @@ extern "C" int tal_logmel_fwd(const void* plan, const float* audio, int B, int64
     }
     hipStream_t s = (hipStream_t)stream;
     const int64_t T = 1 + L / HOP;
-    const int64_t nblk = cdiv(T, FB);
+    // short inputs (fewer than two 32-frame workgroups per CU): 16 frames per workgroup
+    const bool short_in = (int64_t)B * cdiv(T, FB) < 2 * (int64_t)device_cus();
+    const int64_t nblk = cdiv(T, short_in ? FB_SHORT : FB);
     double* partial = reinterpret_cast<double*>(workspace);
     float* mean_ws = reinterpret_cast<float*>(partial + B * nblk + 2);
     {
         // algorithmic HBM bytes: read L samples, write T*80 floats per item
         ProfScope prof(PROF_LOGMEL, (double)B * ((double)L + (double)T * NMEL) * 4.0, s);
-        hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, s,
-                           reinterpret_cast<const LogmelPlan*>(plan), audio, L, T, eps, out, partial);
+        if (short_in)
+            hipLaunchKernelGGL(logmel_kernel<FB_SHORT>, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, s,
+                               reinterpret_cast<const LogmelPlan*>(plan), audio, L, T, eps, out, partial);
+        else
+            hipLaunchKernelGGL(logmel_kernel<FB>, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, s,
+                               reinterpret_cast<const LogmelPlan*>(plan), audio, L, T, eps, out, partial);
     }
     TAL_CHECK_LAUNCH("tal_logmel_fwd");
     hipLaunchKernelGGL(logmel_mean_kernel, dim3(1), dim3(256), 0, s, partial, (int64_t)B * nblk,

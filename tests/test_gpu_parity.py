@@ -589,6 +589,28 @@ def test_speaker_ids_fused_path(sd_model):
     assert (ids.cpu().numpy() != g["ids"]).sum() == 0
 
 
+@pytest.mark.parametrize("seconds", [12, 30, 95, 300, 420])
+def test_speaker_ids_do_not_depend_on_dispatch_choices(sd_model, seconds):
+    """Which kernels a launch takes depends on its size (64 x 80 / 128 x 96 / 128 x 160 / 256 x 160 dense tiles with or without K
+    slices, a round + remainder split by rows, 64- / 256-step conv tiles, the K-sliced head layer): the same clip with every
+    round-3 choice switched off must give the SAME speaker ids and features equal to fp32 rounding."""
+    from tal_asrd_amd import synth, _native as N_
+    audio = torch.from_numpy(synth.synth_audio_batch(1, seconds * 16000, 4321 + seconds)).to(dev())
+    names = {"gemm_s64_below": (2, 0), "gconv_short_below": (4, 0), "gemm_no_n96": (0, 1), "gemm_no_row_split": (0, 1), "gemm_no_w64": (0, 1)}
+    feat, ids = sd_model.speaker_ids(audio)
+    torch.cuda.synchronize()
+    try:
+        for name, (on, off) in names.items():
+            N_.set_option(name, off)
+        feat2, ids2 = sd_model.speaker_ids(audio)
+        torch.cuda.synchronize()
+    finally:
+        for name, (on, off) in names.items():
+            N_.set_option(name, on)
+    assert torch.equal(ids, ids2)
+    assert float((feat - feat2).abs().max()) < 2e-4 * max(1.0, float(feat.abs().max()))
+
+
 @pytest.mark.parametrize("M,S", [(33000, 6008), (32768 + 1, 6008), (70001, 1000)])
 def test_long_input_argmax_head_matches_logits_argmax(M, S):
     """The A-stationary arg-max kernel (long inputs, 128-d features): same ids as arg-max over materialised

@@ -665,11 +665,13 @@ static int sd_head_part_ld(int S) {
     return (int)(a > b ? a : b);
 }
 
+static size_t sd_head_partials_bytes(int64_t M, int S) { return (size_t)(M > 0 ? M : 1) * (size_t)sd_head_part_ld(S) * 8; }
+
 extern "C" size_t tal_sd_head_workspace_bytes(int64_t M, int S) {
     // (value, index) partials of the fused arg-max: one pair per row and per 32-column wave slice.  The small-M
     // kernel (32 x 128 tile, 4 waves side by side) writes 4 slots per 128-column tile, the last tile included
     // even when it is partly past S, hence the second term.
-    const size_t partials = (size_t)(M > 0 ? M : 1) * (size_t)sd_head_part_ld(S) * 8;
+    const size_t partials = sd_head_partials_bytes(M, S);
     // The same bytes serve first as K-slice scratch of the embedding layer (1440 -> 128: ONE column tile, so a clip of minutes is
     // a few dozen 128-row tiles for 256 CUs -- 120 us on 30 workgroups for a 5-minute clip; cut along K 8 ways it is ~30 us).
     // launch_gemm slices only launches below a quarter round (128 tiles).
@@ -697,8 +699,10 @@ extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_
         return ids ? launch_argmax_rows(logits, M, S, ids, s) : TAL_OK;
     }
     TAL_CHECK_ARG(workspace, "tal_sd_head_fwd: ids without logits needs a workspace");
-    if (workspace_bytes < tal_sd_head_workspace_bytes(M, S)) {
-        set_error("tal_sd_head_fwd: workspace %zu < %zu bytes", workspace_bytes, tal_sd_head_workspace_bytes(M, S));
+    // (the arg-max partials are what the call cannot do without; the larger figure tal_sd_head_workspace_bytes returns for short /
+    //  medium inputs only enables the K-sliced embedding layer above)
+    if (workspace_bytes < sd_head_partials_bytes(M, S)) {
+        set_error("tal_sd_head_fwd: workspace %zu < %zu bytes", workspace_bytes, sd_head_partials_bytes(M, S));
         return TAL_ENOMEM;
     }
     if (M == 0) return TAL_OK;

@@ -347,14 +347,16 @@ extern "C" int tal_logmel_fwd(const void* plan, const float* audio, int B, int64
                               void* stream) {
     TAL_CHECK_ARG(plan && audio && out && workspace, "tal_logmel_fwd: null pointer");
     TAL_CHECK_ARG(B > 0 && L > NFFT / 2, "tal_logmel_fwd: need B>0 and L>%d for reflect padding (L=%lld)", NFFT / 2, (long long)L);
-    if (workspace_bytes < tal_logmel_workspace_bytes(B, L)) {
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t T = 1 + L / HOP;
+    // (a workspace sized for 32-frame workgroups only -- the figure before the short-input form existed -- is accepted)
+    const size_t need_long = (size_t)(B * cdiv(T, FB) + 4) * sizeof(double);
+    if (workspace_bytes < need_long) {
         set_error("tal_logmel_fwd: workspace %zu < %zu bytes", workspace_bytes, tal_logmel_workspace_bytes(B, L));
         return TAL_ENOMEM;
     }
-    hipStream_t s = (hipStream_t)stream;
-    const int64_t T = 1 + L / HOP;
     // short inputs (fewer than two 32-frame workgroups per CU): 16 frames per workgroup
-    const bool short_in = (int64_t)B * cdiv(T, FB) < 2 * (int64_t)device_cus();
+    const bool short_in = (int64_t)B * cdiv(T, FB) < 2 * (int64_t)device_cus() && workspace_bytes >= tal_logmel_workspace_bytes(B, L);
     const int64_t nblk = cdiv(T, short_in ? FB_SHORT : FB);
     double* partial = reinterpret_cast<double*>(workspace);
     float* mean_ws = reinterpret_cast<float*>(partial + B * nblk + 2);

@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event timing")
     ap.add_argument("--no-exact-pass", action="store_true", help="clip workload: skip the extra pass on the exact fp32 kernels (value_exact_f32)")
+    ap.add_argument("--no-clip-latency", action="store_true", help="clip workload: skip the 30 s / 5 min call latencies (clip_latency)")
     ap.add_argument("--no-one-gpu-reference", action="store_true", help="segments workload at N > 1: skip rank 0's solo pass over all segments")
     ap.add_argument("--cpu-threads", type=str, default="8,16,32,64,128", help="thread counts the CPU baseline is swept over")
     a = ap.parse_args()
@@ -460,6 +461,27 @@ def main():
                             "stream under the compute of the clip before it (SDModel.speaker_ids_stream)" % n_stream}
         del host
 
+    # The other two clip lengths BASELINE.json names (configs[0]: 30 s, configs[1]: 5 min), as call latencies beside `value`:
+    # they take other kernels than the 1-hour clip (64 x 80 / 128 x 96 dense tiles, 64-step conv tiles, K-sliced head layer)
+    clip_latency = None
+    if rank == 0 and args.workload == "clip" and not fake and world == 1 and not args.no_clip_latency:
+        clip_latency = {}
+        with torch.no_grad():
+            for sec in (30, 300):
+                a = torch.from_numpy(synth.synth_audio_batch(1, sec * 16000, 1234)).to(dev)
+                for _ in range(5):
+                    model.speaker_ids(a)
+                sync()
+                t_c = time.perf_counter()
+                for _ in range(30):
+                    model.speaker_ids(a)
+                sync()
+                dt_c = (time.perf_counter() - t_c) / 30
+                clip_latency["%d s" % sec] = {"ms_per_call": 1e3 * dt_c, "frames_per_s": (1 + sec * 100) / dt_c}
+                del a
+        clip_latency["what"] = "SDModel.speaker_ids on ONE resident clip of that length, 30 calls back to back (each ends with the " \
+                               "range-guard read-back, i.e. a device synchronisation)"
+
     # ------------------------------------------------------------------ timed region
     def timed_pass(with_prof):
         sync()
@@ -615,6 +637,8 @@ def main():
             streamed["fraction_of_resident_value"] = streamed["value"] / line["value"]
             streamed["steady_state_fraction_of_resident_value"] = line["ms_per_step"] / streamed["ms_per_clip_after_the_first"]
             line["stream_of_clips_from_host"] = streamed
+        if clip_latency is not None:
+            line["clip_latency"] = clip_latency
         if h2d_ms is not None:
             line["h2d_ms_per_clip"] = h2d_ms
             line["value_including_h2d"] = total_frames / (elapsed + 1e-3 * h2d_ms * args.segments * args.steps)

@@ -16,7 +16,12 @@ __global__ void spin_kernel(unsigned long long ticks, int* sink) {
 
 static double run(int S, int N, int G, double us) {
     std::vector<hipStream_t> st(S);
-    for (auto& s : st) hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);          // (numerically lowest = highest priority)
+    for (int i = 0; i < S; ++i) {
+        if (getenv("PRIO")) hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, hi + i % (lo - hi + 1));
+        else hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking);
+    }
     const unsigned long long ticks = (unsigned long long)(us * 100.0);      // 100 MHz counter
     auto work = [&](int i) {
         for (int k = 0; k < N; ++k) hipLaunchKernelGGL(spin_kernel, dim3(G), dim3(256), 0, st[i], ticks, nullptr);
@@ -35,7 +40,7 @@ static double run(int S, int N, int G, double us) {
 int main() {
     const int N = 2000;
     if (getenv("QUICK")) {
-        for (int S : {1, 2, 4, 8, 16})
+        for (int S : {1, 2, 3, 4, 5, 6, 8, 12, 16, 24})
             printf("spin 8 us, 16 workgroups, %2d streams: %7.1f kernels/ms overall\n", S, run(S, N, 16, 8.0));
         return 0;
     }

@@ -148,7 +148,7 @@ class System:
 
     # ------------------------------------------------------------------ several episodes in flight
     @torch.no_grad()
-    def transcribe_unaligned_many(self, episodes, streams=4, **kw):
+    def transcribe_unaligned_many(self, episodes, streams=8, **kw):
         """`transcribe_unaligned` over a list of episodes with up to `streams` decode sessions in flight -- the loop the
         reference runs this path in (tal/asr/system.py:625-742 per test item, one after the other): each session is the
         ordinary sliding-window decode on its own HIP stream with its own context (prefix buffer, workspace, window K / V^T,
@@ -156,6 +156,10 @@ class System:
         interpreter lock, so the launch work of the sessions overlaps, and a decode step (a chain of ~35 small dependent
         kernels on a few dozen CUs) of one session runs beside the others' on the chip.  An episode's waveform is uploaded
         on its session's stream (pinned host memory: the copy runs under the other sessions' compute).
+
+        `streams` = 8: the device executes at most four kernels at a time (its four hardware queues), and which streams share a
+        queue is not under the caller's control -- eight streams fill the four queues whatever the assignment, four may land two
+        to a queue (2.5x against 3.0x measured; scripts/ubench/launch_rate.hip, profiles/r3_ubench_launch_rate.txt).
 
         episodes: list of (audio [1, L] float tensor -- host (pinned or not) or device --, audio_lens LongTensor [1]).
         Returns [(utterance dicts, generated, alignments)] in episode order, identical to the solo runs."""

@@ -15,7 +15,9 @@
 //     of 18 KB: tiles kt + 2 .. kt + 4 are in flight while tile kt is multiplied (a tile's MFMAs are 0.1 us, an L2 round
 //     trip is several times that);
 //   * the fragments of tile kt + 1 are read from LDS into a second register set while tile kt is multiplied from the
-//     first (12 ds_read_b128 per wave and K step): with one wave per SIMD nothing else hides an LDS round trip;
+//     first (12 ds_read_b128 per wave and K step): with one wave per SIMD nothing else hides an LDS round trip; these reads
+//     and the LDS-DMA loads of tile kt + 4 are issued one behind each of the step's 15 MFMAs (issued in front of them they
+//     cost 1.5-2.5 us per layer: 24.1 -> 21.0 us per layer pair at K = 800, 35.4 -> 30.8 at 1440);
 //   * ONE barrier per K step; same operand geometry and source-side XOR swizzle as gemm_glds_kernel;
 //   * MFMA operand A = 16 W rows (output columns), B = 16 X rows: a lane ends up with 4 consecutive output columns of one
 //     row -- the epilogue (bias, ReLU / ReZero residual, hi / lo split, range guard) runs on registers and stores 8 or 16
@@ -166,22 +168,34 @@ __global__ __launch_bounds__(256, 2) void gemm_s64_kernel(const GemmArgs g) {
         constexpr int B = decltype(bc)::value, cur = B & 1, nxt = cur ^ 1;
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PER_WAVE) : "memory");
         __builtin_amdgcn_s_barrier();
-        read_frags(f[nxt], ((B + 1) % S_NBUF) * BUF);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const unsigned nrec = kt + 4 < nk ? NREC : 0u;
-            const int kofs = (kt + 4) * (BK * 4);
-#pragma unroll
-            for (int t = 0; t < PER_WAVE; ++t) dma(t, nrec, B * BUF, kofs);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        // One wave per SIMD: whatever is issued in front of the MFMAs is matrix time lost.  The 12 fragment reads of tile kt + 1 and
+        // the 5 LDS-DMA loads of tile kt + 4 are therefore issued BETWEEN the 15 MFMAs of tile kt, one behind each (an MFMA
+        // occupies the pipe for 16 cycles and the issue port for 4).
+        const unsigned nrec = kt + 4 < nk ? NREC : 0u;
+        const int kofs = (kt + 4) * (BK * 4);
+        constexpr int nbuf = ((B + 1) % S_NBUF) * BUF;
+        auto read_item = [&](int m) {          // m-th fragment read of the next tile: xh, xl, wh[0], wl[0], wh[1], ...
+            if (m == 0) f[nxt].xh = *reinterpret_cast<const f16x8*>(lds + nbuf + x_lane + sh);
+            else if (m == 1) f[nxt].xl = *reinterpret_cast<const f16x8*>(lds + nbuf + x_lane + sl);
+            else if (m & 1) f[nxt].wl[(m - 2) >> 1] = *reinterpret_cast<const f16x8*>(lds + nbuf + w_lane + ((m - 2) >> 1) * 16 * 32 + sl);
+            else f[nxt].wh[(m - 2) >> 1] = *reinterpret_cast<const f16x8*>(lds + nbuf + w_lane + ((m - 2) >> 1) * 16 * 32 + sh);
+        };
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[cur].wh[j], f[cur].xh, acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (3 * j < 12) read_item(3 * j);
+            __builtin_amdgcn_sched_barrier(0);
             accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[cur].wh[j], f[cur].xl, accx[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (3 * j + 1 < 12) read_item(3 * j + 1);
+            __builtin_amdgcn_sched_barrier(0);
             accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[cur].wl[j], f[cur].xh, accx[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (3 * j + 2 < 12) read_item(3 * j + 2);
+            dma(j, nrec, B * BUF, kofs);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     };
     int kt = 0;
     for (; kt + 4 <= nk; kt += 4) {

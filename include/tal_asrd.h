@@ -88,6 +88,12 @@ size_t tal_logmel_workspace_bytes(int B, int64_t L);
 int tal_logmel_fwd(const void* plan, const float* audio, int B, int64_t L, float eps,
                    int subtract_mean, float* out, float* mean_out, double* sum_out,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* The same call on a half-precision waveform (fp16 [B, L]): the reference's GPU-era call sites hand the model
+ * `audio.half()` (tal/asr/system.py:92,285; tal/baseline/reconcile.py:78).  Samples are widened to fp32 while they are
+ * staged (exact), so the result equals tal_logmel_fwd on the widened waveform bit for bit; out stays fp32. */
+int tal_logmel_f16_fwd(const void* plan, const void* audio_f16, int B, int64_t L, float eps,
+                       int subtract_mean, float* out, float* mean_out, double* sum_out,
+                       void* workspace, size_t workspace_bytes, void* stream);
 /* x[i] -= *mean for n floats (second half of the two-step / multi-GPU form). */
 int tal_subtract_scalar(float* x, int64_t n, const float* mean, void* stream);
 

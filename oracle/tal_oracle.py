@@ -393,6 +393,80 @@ def ngram_repeat_mask(xs, n):
 
 
 # ----------------------------------------------------------------------------
+# Sliding-window greedy decode of a whole episode -- the CPU leg of BASELINE.json configs[4]
+# ----------------------------------------------------------------------------
+def generate_unaligned(audio, generated, audio_lens, sd, eos=1, chunk_size=357, max_iters=1000000, max_positions=512,
+                       thresh_prct=0.5, shift_prct=0.25, stall_patience=25, rep_n=5, skip_prct=0.1,
+                       n_layers=4, nhead=4):
+    """System.generate_unaligned (tal/asr/system.py:254-524) for ONE episode on the CPU, doing the work the reference
+    does per generated token: the whole live prefix through all decoder layers (no cache: the loop decodes with
+    causal_mask=False, :350-351), the memory window re-projected in every layer, the LM head over every prefix position
+    (:243-246), then log_softmax / argmax of the last one (:355-387).  The waveform is rounded to fp16 first (:285).
+    -> (token ids [n], recorded window starts [n-1], attention rows: list of [S] arrays).
+    Pinned by tests/golden/flow_unaligned*.npz, recorded from the reference's own function (tests/test_oracle_golden.py)."""
+    audio = np.asarray(audio, dtype=np.float32).astype(np.float16).astype(np.float32)          # :285
+    with torch.no_grad():
+        enc = asr_encode(audio, sd, audio_lens)                                                # :290
+        mem_all, mask_all = enc["encoder_out"], enc["encoder_padding_mask"]
+        enc_len = int((~mask_all).sum(dim=-1)[0])                                              # :291
+        toks = [int(t) for t in np.asarray(generated).reshape(-1)]
+        starts, rows = [], []
+        win = hist = 0                      # chunk_start, history_start (:300-303)
+        best = 0.0                          # highest_progress
+        stale = since = 0                   # num_no_improve, window_time
+        for _ in range(max_iters):
+            prefix = toks[hist:]                                                               # :338
+            assert len(prefix) <= max_positions, "Cannot exceed max context length"
+            sl = slice(win, win + chunk_size)                                                  # python slice semantics, :347-348
+            memory = {"encoder_out": mem_all[:, sl], "encoder_padding_mask": mask_all[:, sl]}
+            logits, attn = asr_decode(np.asarray([prefix]), memory, sd, causal_mask=False, n_layers=n_layers, nhead=nhead)
+            last = logits[:, -1, :]
+            if torch.isnan(last).any():
+                raise Exception("Logits contain nans!")
+            toks.append(int(F.log_softmax(last, dim=-1).argmax(dim=-1)[0]))                    # :366-387
+            row = torch.stack(attn, dim=0).mean(dim=0)[0, -1]                                  # :392-397
+            starts.append(win)
+            rows.append(row.numpy().copy())
+            ramp = torch.arange(row.numel()).to(row) / row.numel()                             # :405-408
+            progress = float((row * ramp).sum())
+            if progress > best:                                                                # :411-419
+                stale = 0
+                if since > 5:
+                    best = progress
+            else:
+                stale += 1
+            stalling = stale >= stall_patience
+            repeating = int(ngram_repeat_mask(np.asarray([prefix]), rep_n).sum()) > rep_n * 2  # :426-429
+            last_chunk = enc_len - win <= chunk_size
+            reset = stalling or repeating
+            kept = True
+            if not last_chunk:
+                if reset:                                                                      # :437-456
+                    win += int(chunk_size * skip_prct)
+                    if repeating:
+                        back = 2 * rep_n - 1
+                        del toks[-back:], starts[-back:], rows[-back:]
+                        kept = False
+                    toks[-1] = eos
+                    hist = len(toks) - 1
+                    best, since = 0.0, 0
+                elif progress > thresh_prct:                                                   # :462-476
+                    size = len(toks) - hist
+                    win += int(chunk_size * shift_prct)
+                    hist += int(torch.tensor(shift_prct / thresh_prct * (size - 1)).floor().long())
+                    best, since = 0.0, 0
+            if kept:
+                starts[-1] = win            # the reference appends the chunk_start TENSOR and advances it in place (:400,441,468)
+            win = min(win, enc_len - chunk_size)                                               # :480
+            hist = max(hist, max(len(toks) - max_positions, 0))                                # :482-483
+            assert hist < len(toks) and len(toks) - hist <= max_positions
+            since += 1
+            if reset and last_chunk:                                                           # :510-519
+                break
+    return np.asarray(toks, dtype=np.int64), np.asarray(starts, dtype=np.int64), rows
+
+
+# ----------------------------------------------------------------------------
 # End-to-end CPU path used as bench.py's cpu_baseline ("port")
 # ----------------------------------------------------------------------------
 def sd_path(audio, sd):

@@ -61,6 +61,7 @@ SIGNATURES = {
     "tal_logmel_plan_init": (_i, [_p, _p, _p, _p]),
     "tal_logmel_workspace_bytes": (_sz, [_i, _i64]),
     "tal_logmel_fwd": (_i, [_p, _p, _i, _i64, _f, _i, _p, _p, _p, _p, _sz, _p]),
+    "tal_logmel_f16_fwd": (_i, [_p, _p, _i, _i64, _f, _i, _p, _p, _p, _p, _sz, _p]),
     "tal_subtract_scalar": (_i, [_p, _i64, _p, _p]),
     "tal_linear_fwd": (_i, [_p, _p, _p, _p, _f, _i, _i64, _i, _i, _p, _p]),
     "tal_linear_workspace_bytes": (_sz, [_i64, _i, _i]),

@@ -49,9 +49,12 @@ struct LogmelPlan {
     float mel_w[NMEL * MAXW];
 };
 
-template <int FBT>       // frames per workgroup: 32 (two 16-frame MFMA row blocks per wave and bin tile) or 16 (one)
+// AT: element type of the waveform -- float, or _Float16 for callers that hand over `.half()` audio as the reference's
+// GPU-era call sites do (tal/asr/system.py:92,285, tal/baseline/reconcile.py:78); the samples are widened while they are
+// staged into LDS (exact), everything after that is the same arithmetic.
+template <int FBT, typename AT>       // frames per workgroup: 32 (two 16-frame MFMA row blocks per wave and bin tile) or 16 (one)
 __global__ __launch_bounds__(256, 3) void logmel_kernel(const LogmelPlan* __restrict__ plan,
-                                                    const float* __restrict__ audio, int64_t L, int64_t T, float eps,
+                                                    const AT* __restrict__ audio, int64_t L, int64_t T, float eps,
                                                     float* __restrict__ out, double* __restrict__ partial) {
     constexpr int FB = FBT, NS = (FB - 1) * HOP + NFFT + 1, NSP = NS + NS / HOP + 2;
     constexpr bool TWO = FBT == 32;
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const LogmelPlan* __rest
     const int w = wave_id();
     const int b = blockIdx.y;
     const int64_t f0 = (int64_t)blockIdx.x * FB;
-    const float* ab = audio + (int64_t)b * L;
+    const AT* ab = audio + (int64_t)b * L;
 
     const int64_t p0 = f0 * HOP - NFFT / 2;
     for (int i = tid; i < NS; i += 256) {
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const LogmelPlan* __rest
         if (p < 0) p = -p;                       // reflect (no edge repeat), as torch.stft pad_mode='reflect'
         if (p >= L) p = 2 * (L - 1) - p;
         p = p < 0 ? 0 : (p >= L ? L - 1 : p);    // frames past T (tail block) only
-        samp[i + i / HOP] = ab[p];
+        samp[i + i / HOP] = (float)ab[p];
     }
     __syncthreads();
 
@@ -342,17 +345,18 @@ extern "C" size_t tal_logmel_workspace_bytes(int B, int64_t L) {
     return (size_t)(B * cdiv(T, FB_SHORT) + 4) * sizeof(double);
 }
 
-extern "C" int tal_logmel_fwd(const void* plan, const float* audio, int B, int64_t L, float eps, int subtract_mean,
-                              float* out, float* mean_out, double* sum_out, void* workspace, size_t workspace_bytes,
-                              void* stream) {
-    TAL_CHECK_ARG(plan && audio && out && workspace, "tal_logmel_fwd: null pointer");
-    TAL_CHECK_ARG(B > 0 && L > NFFT / 2, "tal_logmel_fwd: need B>0 and L>%d for reflect padding (L=%lld)", NFFT / 2, (long long)L);
+template <typename AT>
+static int logmel_fwd_impl(const void* plan, const AT* audio, int B, int64_t L, float eps, int subtract_mean,
+                           float* out, float* mean_out, double* sum_out, void* workspace, size_t workspace_bytes,
+                           void* stream, const char* what) {
+    TAL_CHECK_ARG(plan && audio && out && workspace, "%s: null pointer", what);
+    TAL_CHECK_ARG(B > 0 && L > NFFT / 2, "%s: need B>0 and L>%d for reflect padding (L=%lld)", what, NFFT / 2, (long long)L);
     hipStream_t s = (hipStream_t)stream;
     const int64_t T = 1 + L / HOP;
     // (a workspace sized for 32-frame workgroups only -- the figure before the short-input form existed -- is accepted)
     const size_t need_long = (size_t)(B * cdiv(T, FB) + 4) * sizeof(double);
     if (workspace_bytes < need_long) {
-        set_error("tal_logmel_fwd: workspace %zu < %zu bytes", workspace_bytes, tal_logmel_workspace_bytes(B, L));
+        set_error("%s: workspace %zu < %zu bytes", what, workspace_bytes, tal_logmel_workspace_bytes(B, L));
         return TAL_ENOMEM;
     }
     // short inputs (fewer than two 32-frame workgroups per CU): 16 frames per workgroup
@@ -362,20 +366,35 @@ extern "C" int tal_logmel_fwd(const void* plan, const float* audio, int B, int64
     float* mean_ws = reinterpret_cast<float*>(partial + B * nblk + 2);
     {
         // algorithmic HBM bytes: read L samples, write T*80 floats per item
-        ProfScope prof(PROF_LOGMEL, (double)B * ((double)L + (double)T * NMEL) * 4.0, s);
+        ProfScope prof(PROF_LOGMEL, (double)B * ((double)L * sizeof(AT) + (double)T * NMEL * 4.0), s);
         if (short_in)
-            hipLaunchKernelGGL(logmel_kernel<FB_SHORT>, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, s,
+            hipLaunchKernelGGL((logmel_kernel<FB_SHORT, AT>), dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, s,
                                reinterpret_cast<const LogmelPlan*>(plan), audio, L, T, eps, out, partial);
         else
-            hipLaunchKernelGGL(logmel_kernel<FB>, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, s,
+            hipLaunchKernelGGL((logmel_kernel<FB, AT>), dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, s,
                                reinterpret_cast<const LogmelPlan*>(plan), audio, L, T, eps, out, partial);
     }
-    TAL_CHECK_LAUNCH("tal_logmel_fwd");
+    TAL_CHECK_LAUNCH(what);
     hipLaunchKernelGGL(logmel_mean_kernel, dim3(1), dim3(256), 0, s, partial, (int64_t)B * nblk,
                        (double)B * (double)T * (double)NMEL, mean_out, sum_out, mean_ws);
-    TAL_CHECK_LAUNCH("tal_logmel_fwd(mean)");
+    TAL_CHECK_LAUNCH(what);
     if (subtract_mean) return launch_subtract(out, (int64_t)B * T * NMEL, mean_ws, s);
     return TAL_OK;
+}
+
+extern "C" int tal_logmel_fwd(const void* plan, const float* audio, int B, int64_t L, float eps, int subtract_mean,
+                              float* out, float* mean_out, double* sum_out, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    return logmel_fwd_impl<float>(plan, audio, B, L, eps, subtract_mean, out, mean_out, sum_out, workspace, workspace_bytes,
+                                  stream, "tal_logmel_fwd");
+}
+
+extern "C" int tal_logmel_f16_fwd(const void* plan, const void* audio_f16, int B, int64_t L, float eps, int subtract_mean,
+                                  float* out, float* mean_out, double* sum_out, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(audio_f16) & 1) == 0, "tal_logmel_f16_fwd: audio must be 2-byte aligned");
+    return logmel_fwd_impl<_Float16>(plan, reinterpret_cast<const _Float16*>(audio_f16), B, L, eps, subtract_mean, out,
+                                     mean_out, sum_out, workspace, workspace_bytes, stream, "tal_logmel_f16_fwd");
 }
 
 extern "C" int tal_subtract_scalar(float* x, int64_t n, const float* mean, void* stream) {

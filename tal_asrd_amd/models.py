@@ -13,7 +13,8 @@ Differences that are deliberate and documented in DESIGN.md:
     reference's [B, C, T] contract by transposing at its edge, while
     `encode_features` (which receives and returns time-major tensors in the
     reference too) never transposes;
-  * fp32 end to end (the reference's .half() casts are GPU-era AMP plumbing);
+  * fp32 results end to end; the waveform itself may arrive as fp16 (the reference's callers cast it: system.py:92,285,
+    reconcile.py:78) -- the front-end widens it exactly and computes in fp32 / fp64 from there;
   * CPU tensors are rejected: there is no fallback path.
 The nn.Conv1d / nn.Linear / nn.MultiheadAttention children are parameter
 containers that keep the reference's key names and default initialisation; the
@@ -110,7 +111,7 @@ class LogMelSpec(nn.Module):
 
     @torch.no_grad()
     def forward(self, audio: torch.Tensor):
-        """audio [batch, audio_len] -> [batch, frames, n_mels], minus the global mean of this call."""
+        """audio [batch, audio_len] (fp32 or fp16) -> [batch, frames, n_mels] fp32, minus the global mean of this call."""
         N.require_cuda(audio, "LogMelSpec.forward")
         return ops.logmel(self.plan(), audio, eps=self.eps, subtract_mean=True)
 
@@ -397,31 +398,38 @@ class SDModel(nn.Module):
     def speaker_ids_stream(self, host_clips):
         """The loop of tal/baseline/reconcile.py:96-102 (one episode after the other: load, `.cuda()`, get_speaker_ids) over
         waveforms held in host memory, with the upload of episode i + 1 on a copy stream under the compute of episode i:
-        `host_clips` = iterable of [1, L] float32 tensors (pinned memory for a truly asynchronous copy); yields
+        `host_clips` = iterable of [1, L] float32 (or float16) tensors (pinned memory for a truly asynchronous copy); yields
         (feat, ids) per clip, in order.  With ~230 MB per hour of audio and ~50 GB/s of PCIe the copy (4.5 ms) hides
         entirely behind the 18 ms of compute."""
         dev = self.spk_embed_proj.weight.device
         copy_stream = torch.cuda.Stream(device=dev)
         compute = torch.cuda.current_stream(dev)
-        # two device buffers, allocated once per clip length (a fresh allocation per clip would be a hipMalloc, i.e. a device
-        # synchronisation, in the middle of the stream): clip i + 1 lands in the buffer clip i - 1 has finished with
+        # exactly two device buffers (slot 0 / 1), flat and grow-only: sized to the longest clip seen so far, a clip lands in a
+        # view of its slot.  A fresh allocation per clip would be a hipMalloc (a device synchronisation) in the middle of the
+        # stream; one cached buffer per clip SHAPE grows without bound over a corpus whose episodes all differ in length.
         if not hasattr(self, "_stream_bufs"):
-            self._stream_bufs = {}              # kept between calls: (slot, shape) -> device buffer
-        bufs, free_ev = self._stream_bufs, {}
+            self._stream_bufs = [None, None]    # kept between calls
+        bufs, free_ev = self._stream_bufs, [None, None]
 
         def upload(clip, slot):
-            key = (slot, tuple(clip.shape))
-            if key not in bufs:
-                bufs[key] = torch.empty(clip.shape, dtype=torch.float32, device=dev)
-            if key in free_ev:
-                copy_stream.wait_event(free_ev[key])          # the compute that last read this buffer is done
+            if clip.dtype not in (torch.float32, torch.float16):
+                raise N.NativeError("speaker_ids_stream: clips must be float32 or float16 waveforms, got %s" % clip.dtype)
+            nbytes = clip.numel() * clip.element_size()
+            if bufs[slot] is None or bufs[slot].numel() < nbytes:
+                if free_ev[slot] is not None:
+                    free_ev[slot].synchronize()               # (the old buffer's last reader; rare: only when a longer clip arrives)
+                bufs[slot] = torch.empty(nbytes + nbytes // 8, dtype=torch.uint8, device=dev)
+                free_ev[slot] = None
+            view = bufs[slot][:nbytes].view(clip.dtype).view(clip.shape)
+            if free_ev[slot] is not None:
+                copy_stream.wait_event(free_ev[slot])         # the compute that last read this buffer is done
             else:
                 copy_stream.wait_stream(compute)              # (first use: the allocation above is ordered on the compute stream)
             with torch.cuda.stream(copy_stream):
-                bufs[key].copy_(clip, non_blocking=True)
+                view.copy_(clip, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(copy_stream)
-            return bufs[key], done, key
+            return view, done, slot
 
         it = iter(host_clips)
         first = next(it, None)
@@ -430,14 +438,14 @@ class SDModel(nn.Module):
         pending = upload(first, 0)
         i = 0
         while pending is not None:
-            x, done, key = pending
+            x, done, slot = pending
             nxt = next(it, None)
             pending = upload(nxt, (i + 1) & 1) if nxt is not None else None
             compute.wait_event(done)
             out = self.speaker_ids(x)
             ev = torch.cuda.Event()
             ev.record(compute)
-            free_ev[key] = ev
+            free_ev[slot] = ev
             i += 1
             yield out
 

@@ -16,8 +16,8 @@ def _ws(nbytes, device):
 def _f32c(t, what):
     N.require_cuda(t, what)
     if t.dtype != torch.float32:
-        raise N.NativeError("%s: expected float32, got %s (the reference's .half() casts are GPU-era AMP "
-                            "conventions; this path computes in fp32)" % (what, t.dtype))
+        raise N.NativeError("%s: expected float32, got %s (only the waveform may be half precision, as the "
+                            "reference's call sites hand it over; everything behind the front-end is fp32)" % (what, t.dtype))
     return t.contiguous()
 
 
@@ -36,10 +36,20 @@ def logmel_plan(window, fb):
     return plan
 
 
+def _audio(t, what):
+    """The waveform is the one tensor the reference's callers hand over in half precision (`audio_x.half()`,
+    tal/asr/system.py:92,285; `x_wav.cuda().half()`, tal/baseline/reconcile.py:78): fp16 and fp32 are both taken as they
+    are (the kernel widens fp16 samples while it stages them); anything else raises."""
+    N.require_cuda(t, what)
+    if t.dtype not in (torch.float32, torch.float16):
+        raise N.NativeError("%s: the waveform must be float32 or float16, got %s" % (what, t.dtype))
+    return t.contiguous()
+
+
 def logmel(plan, audio, eps=1e-6, subtract_mean=True, return_stats=False):
-    """audio [B, L] -> [B, T, 80] (LogMelSpec.forward, tal/asr/models.py:35-53)."""
+    """audio [B, L] fp32 or fp16 -> [B, T, 80] fp32 (LogMelSpec.forward, tal/asr/models.py:35-53)."""
     lib = N.lib()
-    audio = _f32c(audio, "logmel")
+    audio = _audio(audio, "logmel")
     if audio.dim() != 2:
         raise N.NativeError("logmel: audio must be [batch, samples]")
     B, L = audio.shape
@@ -49,8 +59,9 @@ def logmel(plan, audio, eps=1e-6, subtract_mean=True, return_stats=False):
     stats = torch.empty(2, dtype=torch.float64, device=audio.device)
     nws = lib.tal_logmel_workspace_bytes(B, L)
     ws = _ws(nws, audio.device)
-    N.check(lib.tal_logmel_fwd(N.ptr(plan), N.ptr(audio), B, L, eps, 1 if subtract_mean else 0, N.ptr(out),
-                               N.ptr(mean), N.ptr(stats), N.ptr(ws), nws, N.stream_handle()), "tal_logmel_fwd")
+    fwd = lib.tal_logmel_f16_fwd if audio.dtype == torch.float16 else lib.tal_logmel_fwd
+    N.check(fwd(N.ptr(plan), N.ptr(audio), B, L, eps, 1 if subtract_mean else 0, N.ptr(out),
+                N.ptr(mean), N.ptr(stats), N.ptr(ws), nws, N.stream_handle()), "tal_logmel_fwd")
     return (out, mean, stats) if return_stats else out
 
 

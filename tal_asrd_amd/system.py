@@ -17,8 +17,9 @@ KV cache would change results (hard parts).
 
 Not built (not on the acoustic hot path): LM fusion (`self.lm`, system.py:127-138 -- no
 language model ships with the reference), training / validation steps, data loaders.
-The half-precision casts (`force_half`, system.py:92,285) are accepted and ignored: this
-path computes in fp32 (BASELINE.json: logits within 1e-3 of the fp32 CPU path).
+The half-precision casts of the waveform (`force_half`, system.py:91-92,285) are performed as written: the model
+takes the fp16 waveform, widens it exactly in the front-end and computes in fp32 from there (BASELINE.json: logits
+within 1e-3 of the fp32 CPU path run on the same -- fp16-rounded -- audio).
 """
 import ctypes as C
 import threading
@@ -169,7 +170,7 @@ class System:
         # everything the sessions share is built once, on the caller's stream, before any of them starts
         first_audio = episodes[0][0]
         with self._lock:
-            warm = first_audio[:, :min(first_audio.shape[1], 16000 * 40)].to(dev).float()
+            warm = first_audio[:, :min(first_audio.shape[1], 16000 * 40)].to(dev)
             self.model.encode(warm, torch.tensor([warm.shape[1]]))
             from . import decoder as D
             D._stack_structs(self.model.decoder)
@@ -248,7 +249,9 @@ class System:
         model = self.model
         use_spk = self.args.spk_weight > 0
         dev = audio_x.device
-        encoder_out = model.encode(audio_x.float(), audio_lens)
+        if force_half:
+            audio_x = audio_x.half()                    # system.py:91-92
+        encoder_out = model.encode(audio_x, audio_lens)
         batch_size = generated.size(0)
         cur_beam = 1
         gen = generated.detach().cpu().numpy().astype(np.int64)           # [rows, len] host bookkeeping
@@ -325,8 +328,9 @@ class System:
             raise ValueError("generate_unaligned handles one episode at a time (system.py:331,411 call .item())")
         dev = audio_x.device
         max_positions = model.max_positions if max_positions is None else max_positions
+        audio_x = audio_x.half()                        # system.py:285
         with self._lock:
-            encoder_out = model.encode(audio_x.float(), audio_lens)
+            encoder_out = model.encode(audio_x, audio_lens)
         enc, mask = encoder_out["encoder_out"], encoder_out["encoder_padding_mask"]
         encoder_len = int((~mask).sum(dim=-1).cpu().item())
         eos = self.tokenizer.eos_token_id

@@ -67,10 +67,12 @@ def window_bounds(n_samples, window_frames, stride_frames):
     return [(stride_frames * i, stride_frames * i + window_frames) for i in range(n)]
 
 
-def transcribe_batch(batch, system, beam_width=4, length=60, use_eot=True, eot_token_id=None):
+def transcribe_batch(batch, system, beam_width=4, length=60, use_eot=True, eot_token_id=None, force_half=True):
     """One `System.generate` call on a list of 1-D waveforms (zero-padded to the longest).
     tal/asr/transcribe.py:172-210.  Returns the list System.generate returns for the sequences
-    (CPU LongTensor per window, None where no beam finished)."""
+    (CPU LongTensor per window, None where no beam finished).  The reference's call leaves `force_half` at
+    System.generate's default (True: the waveform is cast to half, system.py:91-92); it is a parameter here so that a
+    caller can keep the fp32 samples."""
     lens = [int(w.numel()) for w in batch]
     longest = max(lens)
     dev = batch[0].device
@@ -86,12 +88,13 @@ def transcribe_batch(batch, system, beam_width=4, length=60, use_eot=True, eot_t
     generated = torch.full((len(batch), 1), prime, dtype=torch.long, device=dev)
     seqs, _ = system.generate(audio_x=audio, generated=generated,
                               audio_lens=torch.tensor(lens, dtype=torch.long, device=dev), length=length,
-                              beam_size=beam_width, terminate_token=eot_token_id if use_eot else None)
+                              beam_size=beam_width, terminate_token=eot_token_id if use_eot else None,
+                              force_half=force_half)
     return seqs
 
 
 def transcribe_file(x_wav, system, window_frames, stride_frames, batch_size=15, beam_width=4, length=60,
-                    truncate=-1.0, splice=False, use_eot=True, eot_token_id=None, decode=None):
+                    truncate=-1.0, splice=False, use_eot=True, eot_token_id=None, decode=None, force_half=True):
     """tal/asr/transcribe.py:79-169 for a waveform already loaded (1-D float tensor on the GPU).
     `decode` turns a token sequence into text (the reference uses its sentencepiece tokenizer, whose
     model file is not in the repository); without it the token sequences themselves are returned
@@ -108,7 +111,7 @@ def transcribe_file(x_wav, system, window_frames, stride_frames, batch_size=15, 
         batch.append(x_wav[s:e])
         if len(batch) == batch_size or i == len(bounds) - 1:
             seqs = transcribe_batch(batch, system, beam_width=beam_width, length=length, use_eot=use_eot,
-                                    eot_token_id=eot_token_id)
+                                    eot_token_id=eot_token_id, force_half=force_half)
             outputs.extend(sq if decode is None else decode(sq) for sq in seqs if sq is not None)
             batch = []
     if splice:

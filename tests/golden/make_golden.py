@@ -460,7 +460,33 @@ def sec_flow_short(ns):
          attn_flat=np.concatenate([a.numpy()[0] for _, a in align]).astype(np.float32), min_margin=float(min(margins)))
 
 
-SECTIONS = {"flow_short": sec_flow_short, "variants": sec_variants, "keys": sec_keys, "unit": sec_unit, "sd": sec_sd, "asr": sec_asr,
+def sec_half(ns):
+    """What the reference's call sites compute when they hand the model `audio.half()` (tal/asr/system.py:91-92,285,
+    tal/baseline/reconcile.py:78): the model's arithmetic on the fp16-ROUNDED waveform.  torch-CPU has no half STFT / conv,
+    so the reference modules are run in fp32 on the rounded samples (`force_half=False` on pre-rounded audio); the tests hand
+    the un-rounded fp32 waveform to the literal call sequences and must land on these values."""
+    import types
+    System = ns.system.System
+    # reconcile.get_speaker_ids (:76-85) on the 30 s clip
+    audio = synth.synth_audio_batch(1, 480000, 1234).astype(np.float16).astype(np.float32)
+    _sd_fixture(ns, "sd_30s_half", audio)
+    # System.generate with force_half=True (the default), beam 1 with the speaker head
+    model = _asr_model(ns)
+    tok = types.SimpleNamespace(eos_token_id=1, bos_token_id=0, pad_token_id=2)
+    lens = [160000, 120000]
+    audio = synth.synth_audio_batch(2, 160000, 77, lens=lens).astype(np.float16).astype(np.float32)
+    me = types.SimpleNamespace(model=model, lm=None, tokenizer=tok, args=types.SimpleNamespace(spk_weight=1.0, lm_weight=0.0))
+    seqs, spks = System.generate(me, torch.from_numpy(audio), torch.full((2, 1), 0, dtype=torch.long), torch.tensor(lens),
+                                 length=24, beam_size=1, terminate_token=1, force_half=False, force_output=True)
+    out = {"audio_seed": 77, "audio_lens": np.asarray(lens), "length": 24, "beam": 1, "terminate_token": 1}
+    for i, sq in enumerate(seqs):
+        out["seq_%d" % i] = sq.numpy()
+        out["spk_argmax_%d" % i] = spks[i].argmax(-1).numpy()
+        out["spk_sample_%d" % i] = spks[i][:, ::200].numpy()
+    save("flow_generate_beam1_half", **out)
+
+
+SECTIONS = {"half": sec_half, "flow_short": sec_flow_short, "variants": sec_variants, "keys": sec_keys, "unit": sec_unit, "sd": sec_sd, "asr": sec_asr,
             "decode": sec_decode, "gru": sec_gru, "flow": sec_flow,
             "transcribe": sec_transcribe, "uisrnn": sec_uisrnn}
 

@@ -133,12 +133,12 @@ def test_windowed_transcription_matches_reference_transcribe_file(asr_model):
         return " ".join(str(int(t)) for t in seq)
     for beam in (1, 2):
         got = transcribe_file(audio, sys_, g["window"], g["stride"], batch_size=g["batch_size"], beam_width=beam,
-                              length=g["length"], use_eot=True, eot_token_id=g["eot"], decode=text)
+                              length=g["length"], use_eot=True, eot_token_id=g["eot"], decode=text, force_half=False)
         assert got == g["beam%d_texts" % beam]
         spliced = transcribe_file(audio, sys_, g["window"], g["stride"], batch_size=g["batch_size"],
                                   beam_width=beam, length=g["length"], use_eot=True, eot_token_id=g["eot"],
-                                  decode=text, splice=True)
+                                  decode=text, splice=True, force_half=False)
         assert spliced == g["beam%d_spliced" % beam]
     raw = transcribe_file(audio, sys_, g["window"], g["stride"], batch_size=3, beam_width=1, length=g["length"],
-                          use_eot=True, eot_token_id=g["eot"])
+                          use_eot=True, eot_token_id=g["eot"], force_half=False)
     assert [text(s) for s in raw] == g["beam1_texts"]       # batch composition does not change results

@@ -589,6 +589,30 @@ def test_speaker_ids_fused_path(sd_model):
     assert (ids.cpu().numpy() != g["ids"]).sum() == 0
 
 
+def test_speaker_ids_stream_over_clips_of_different_lengths(sd_model):
+    """The episode-after-episode loop (tal/baseline/reconcile.py:96-102) over host clips that all differ in length (as real
+    episodes do), one of them half precision: every result equals the one-clip call, in order, across two calls -- and the
+    model keeps exactly two upload buffers, sized to the longest clip, however many lengths it has seen."""
+    from tal_asrd_amd import synth
+    secs = [20, 45, 12, 33, 45, 8]
+    clips = [torch.from_numpy(synth.synth_audio_batch(1, s * 16000 + 17 * i, 700 + i)).pin_memory() for i, s in enumerate(secs)]
+    clips[3] = clips[3].half().pin_memory()
+    want = []
+    for c in clips:
+        f, i = sd_model.speaker_ids(c.to(dev()))
+        want.append((f.clone(), i.clone()))
+    for rep in range(2):
+        got = [(f.clone(), i.clone()) for f, i in sd_model.speaker_ids_stream(clips)]
+        assert len(got) == len(clips)
+        for (f, i), (wf, wi) in zip(got, want):
+            assert torch.equal(i, wi) and torch.equal(f, wf)
+    bufs = sd_model._stream_bufs
+    assert len(bufs) == 2 and all(b is not None for b in bufs)
+    longest = max(c.numel() * c.element_size() for c in clips)
+    assert all(b.numel() <= longest + longest // 8 for b in bufs)
+    assert list(sd_model.speaker_ids_stream([])) == []
+
+
 @pytest.mark.parametrize("seconds", [12, 30, 95, 300, 420])
 def test_speaker_ids_do_not_depend_on_dispatch_choices(sd_model, seconds):
     """Which kernels a launch takes depends on its size (64 x 80 / 128 x 96 / 128 x 160 / 256 x 160 dense tiles with or without K

@@ -1,6 +1,7 @@
 """Pin the CPU oracle (oracle/tal_oracle.py) against golden vectors recorded
 from the reference's own modules (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import tal_oracle as O
@@ -78,11 +79,13 @@ def test_positional_encoding():
     np.testing.assert_allclose((torch.from_numpy(g["x"]) + pe[:5]).numpy(), g["y"], atol=0, rtol=0)
 
 
-def _check_sd(name, sd_weights, with_lens):
+def _check_sd(name, sd_weights, with_lens, half_audio=False):
     g = golden(name)
     B, L = int(g["batch"]), int(g["audio_len"])
     lens = g["audio_lens"].tolist() if with_lens else None
     audio = synth.synth_audio_batch(B, L, int(g["audio_seed"]), lens=lens)
+    if half_audio:          # the reference's call sites cast the waveform to half (reconcile.py:78, system.py:92,285)
+        audio = audio.astype(np.float16).astype(np.float32)
     with torch.no_grad():
         mel = O.logmel(audio)
         np.testing.assert_allclose(mel[:, g["mel_rows"]].numpy(), g["mel_sample"], atol=TOL, rtol=0)
@@ -106,6 +109,10 @@ def _check_sd(name, sd_weights, with_lens):
 def test_sd_30s(sd_weights):
     g = _check_sd("sd_30s", sd_weights, False)
     assert g["ids"].shape == (1, 358)
+
+
+def test_sd_30s_half_audio(sd_weights):
+    _check_sd("sd_30s_half", sd_weights, False, half_audio=True)
 
 
 def test_sd_b2_ragged(sd_weights):
@@ -178,3 +185,20 @@ def test_core_rnn():
     m, h = O.core_rnn(g2["x3"], None, sd2, depth=2)
     np.testing.assert_allclose(m.numpy(), g2["m3"], atol=TOL, rtol=0)
     np.testing.assert_allclose(h.numpy(), g2["h3"], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["flow_unaligned_short", "flow_unaligned"])
+def test_generate_unaligned_port(asr_weights, name):
+    """The CPU port of System.generate_unaligned (bench.py's configs[4] CPU leg) against the trajectories recorded from the
+    reference's own function: token stream, recorded window starts, attention rows."""
+    g = golden(name)
+    L = int(g["audio_len"])
+    audio = synth.synth_audio_batch(1, L, int(g["audio_seed"]))        # un-rounded: the port casts to half as system.py:285 does
+    toks, starts, rows = O.generate_unaligned(audio, [[1]], [L], asr_weights, max_iters=int(g["max_iters"]), stall_patience=25)
+    np.testing.assert_array_equal(toks, g["generated"][0])
+    np.testing.assert_array_equal(starts, g["chunk_start"])
+    if "attn" in g.files:
+        np.testing.assert_allclose(np.stack(rows), g["attn"], atol=1e-5, rtol=0)
+    else:
+        assert [r.shape[0] for r in rows] == g["attn_len"].tolist()
+        np.testing.assert_allclose(np.concatenate(rows), g["attn_flat"], atol=1e-5, rtol=0)

@@ -89,13 +89,18 @@ def self_launch(args):
     the library is built once here so that the ranks do not race hipcc)."""
     import __graft_entry__ as g
     g.build()
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # this launcher serves the rendezvous store for the whole run, as torch.distributed.run's agent does (the ranks see
+    # TORCHELASTIC_USE_AGENT_STORE and connect as clients): the RCCL probe, the agreement on its outcome and every process
+    # group of the run hang off ONE store on ONE reserved port.  (A TCP store is host-side only: nothing here touches the GPU.)
+    import datetime
+    import torch.distributed as dist
+    store = dist.TCPStore("127.0.0.1", 0, args.gpus, is_master=True, timeout=datetime.timedelta(seconds=600), wait_for_workers=False)
+    port = store.port
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_PORT=str(port), TORCHELASTIC_USE_AGENT_STORE="True",
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     # a rank that dies (before the rendezvous, say) must not leave the others waiting for the collective timeout
@@ -143,7 +148,7 @@ def build_asr_model(dev):
     for k, v in sd.items():
         own[k] = torch.from_numpy(v.copy())
     model.load_state_dict(own)
-    return model.to(dev)
+    return model.to(dev), sd
 
 
 def dense_layer_algorithmic_bytes(frames, batch=1):
@@ -213,7 +218,7 @@ def decode_episode_gpu(system, sdm, audio, lens, sync):
     t0 = time.perf_counter()
     utts, gen, _ = system.transcribe_unaligned(audio, lens)
     sync(); t1 = time.perf_counter()
-    feat, ids = sdm.speaker_ids(audio)
+    feat, ids = sdm.speaker_ids(audio.half())           # x_wav.cuda().half(), tal/baseline/reconcile.py:78
     sync(); t2 = time.perf_counter()
     tp = feat.shape[1]
     kept = [u for u in utts if int(u["chunkStart"].max()) <= tp - 357]
@@ -314,7 +319,73 @@ class FakeSD:
         return out
 
 
+def open_store(rank, world):
+    """The run's rendezvous store: served by the launcher (torch.distributed.run's agent / self_launch) when there is one,
+    else by rank 0.  Host-side only."""
+    import datetime
+    import torch.distributed as dist
+    served = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+    return dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")), world,
+                         is_master=(rank == 0 and not served), timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+
+
+def rccl_probe_child():
+    """`bench.py --rccl-probe` (started by rccl_probe as a CHILD process): build an RCCL communicator over all ranks' children
+    and run one all-reduce.  Exit code 0 = usable.  TAL_BENCH_RCCL_FAIL simulates the failure modes in the CPU tests:
+    "1" raise on every rank, "rankN" raise on rank N only, "hang" never return."""
+    rank, world, local = (int(os.environ[k]) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
+    mode = os.environ.get("TAL_BENCH_RCCL_FAIL", "")
+    if mode == "hang":
+        time.sleep(3600)
+    if mode == "1" or mode == "rank%d" % rank:
+        print("TAL_BENCH_RCCL_FAIL is set", file=sys.stderr)
+        return 1
+    if os.environ.get("TAL_BENCH_FAKE"):
+        return 0                      # (plumbing tests: no GPU, nothing to probe on the ranks that are not told to fail)
+    import datetime
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    # (always a client: the store is served by the launcher or by rank 0's parent process, which is waiting for this child)
+    store = dist.PrefixStore("tal_rccl_probe", dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]),
+                                                             world, is_master=False, timeout=datetime.timedelta(seconds=30)))
+    dist.init_process_group("nccl", store=store, rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=30))
+    t = torch.ones(1, device=dev)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    if int(t.item()) != world:
+        print("RCCL all_reduce returned %r for %d ranks" % (t.item(), world), file=sys.stderr)
+        return 1
+    dist.destroy_process_group()
+    return 0
+
+
+def rccl_probe(store, rank, world):
+    """Is RCCL usable on this node?  Decided BEFORE this rank touches the GPU, in bounded time, and identically on every rank:
+    each rank starts a child process that builds a communicator with the other ranks' children and runs one all-reduce; a
+    child that has not finished after TAL_BENCH_PROBE_TIMEOUT (45 s) is killed (a communicator that hangs costs seconds, not
+    torch's 300 s watchdog per rank); every rank publishes its outcome in the store and reads all of them, so ONE failing or
+    hanging rank sends ALL ranks to gloo.  -> None (RCCL is fine) or the reason it is not."""
+    limit = float(os.environ.get("TAL_BENCH_PROBE_TIMEOUT", "45"))
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rccl-probe"], stdout=subprocess.DEVNULL,
+                             stderr=subprocess.PIPE, text=True)
+    try:
+        _, err = child.communicate(timeout=limit)
+        verdict = "ok" if child.returncode == 0 else "rank %d: %s" % (rank, (err.strip().splitlines() or ["exit code %d" % child.returncode])[-1][:200])
+    except subprocess.TimeoutExpired:
+        child.kill()                 # (exactly the process started above)
+        child.communicate()
+        verdict = "rank %d: no communicator + all-reduce within %.0f s" % (rank, limit)
+    store.set("tal_rccl_probe_result/%d" % rank, verdict)
+    verdicts = [store.get("tal_rccl_probe_result/%d" % r).decode() for r in range(world)]     # (blocks until every rank has published)
+    bad = [v for v in verdicts if v != "ok"]
+    return bad[0] if bad else None
+
+
 def main():
+    if "--rccl-probe" in sys.argv[1:]:
+        raise SystemExit(rccl_probe_child())
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
@@ -331,54 +402,43 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not fake and not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # TAL_BENCH_BACKEND=gloo is a plumbing self-test only (N ranks sharing the visible GPUs, results
     # staged through host memory); real runs use RCCL ("nccl") with one GPU per rank.
     backend = "gloo" if (fake and not os.environ.get("TAL_BENCH_RCCL_FAIL")) else os.environ.get("TAL_BENCH_BACKEND", "nccl")
+    dist = None
+    backend_note = None
+    store = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        store = open_store(rank, world)
+        if backend == "nccl":
+            # RCCL first -- probed in child processes before this rank has touched the GPU, under a deadline, with the outcome
+            # agreed through the store (rccl_probe): if the communicator cannot be built, its first collective fails or
+            # either HANGS on ANY rank, every rank continues on gloo with results staged through host memory and the line SAYS
+            # SO (`collective_backend`) -- a degraded number beats none on a node nobody could try beforehand.
+            why = rccl_probe(store, rank, world)
+            if why is not None:
+                backend_note = "gloo (RCCL unusable: %s)" % why
+                print("[bench] rank %d: %s" % (rank, backend_note), file=sys.stderr, flush=True)
+                backend = "gloo"
+    if not fake and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if fake:
         dev = torch.device("cpu")
     else:
         # (fewer visible GPUs than ranks happens in the plumbing tests only: the ranks then share them)
         dev = torch.device("cuda", local_rank % torch.cuda.device_count() if torch.cuda.device_count() < world else local_rank)
         torch.cuda.set_device(dev)
-    dist = None
-    backend_note = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
+        # (every group of the run is namespaced in the one store: no second port, nothing lingers from the probe)
         if backend == "nccl":
-            # RCCL first; if the communicator cannot be built or its first collective RAISES (symmetric over the ranks: IPC /
-            # driver set-up), the run continues on gloo with results staged through host memory and SAYS SO in its line
-            # (`collective_backend`) -- a degraded number beats none on a node nobody could try beforehand.  (A communicator
-            # that hangs instead is beyond this: torch's watchdog ends the process after the timeout; measured on a one-GPU
-            # box with two ranks, where RCCL waits for the duplicate device for the whole 300 s.)
-            try:
-                if os.environ.get("TAL_BENCH_RCCL_FAIL"):       # (tests: take the fall-back path without touching RCCL)
-                    raise RuntimeError("TAL_BENCH_RCCL_FAIL is set")
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
-                probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                if int(probe.item()) != world:
-                    raise RuntimeError("RCCL all_reduce returned %r for %d ranks" % (probe.item(), world))
-            except Exception as e:          # noqa: BLE001
-                backend_note = "gloo (RCCL unusable: %s)" % str(e).splitlines()[0][:200]
-                print("[bench] rank %d: %s" % (rank, backend_note), file=sys.stderr, flush=True)
-                had_group = dist.is_initialized()
-                try:
-                    dist.destroy_process_group()
-                except Exception:           # noqa: BLE001
-                    pass
-                backend = "gloo"
-                # (rank 0 served the first rendezvous store itself unless torchrun's agent does: a store that was opened may
-                #  linger on its port)
-                if had_group and not os.environ.get("TORCHELASTIC_USE_AGENT_STORE"):
-                    os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+            dist.init_process_group("nccl", store=dist.PrefixStore("tal_rccl", store), rank=rank, world_size=world, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+            dist.init_process_group(backend, store=dist.PrefixStore("tal_" + backend, store), rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=600))
 
     def sync():
         if not fake:
@@ -396,32 +456,19 @@ def main():
     if args.workload == "decode":
         from tal_asrd_amd.system import System
         from tal_asrd_amd.tokenizer import SynthTokenizer
-        from tal_asrd_amd.wder_format import unaligned_to_wder
-        asr = build_asr_model(dev)
+        asr, asr_sd = build_asr_model(dev)
         sdm, sd = build_sd_model(dev)
         if dist is not None:
             D.broadcast_module(asr)
             D.broadcast_module(sdm)
         system = System(asr, tokenizer=SynthTokenizer(10000))
-        import numpy as np
-        audio = torch.from_numpy(synth.synth_audio_batch(1, L, 2469 + rank).astype(np.float16).astype(np.float32)).to(dev)
+        audio = torch.from_numpy(synth.synth_audio_batch(1, L, 2469 + rank)).to(dev)     # (generate_unaligned casts it to half, system.py:285)
         lens = torch.tensor([L])
         stats = {}
 
         def step():
-            t0 = time.perf_counter()
-            utts, gen, _ = system.transcribe_unaligned(audio, lens)
-            sync(); t1 = time.perf_counter()
-            feat, ids = sdm.speaker_ids(audio)
-            sync(); t2 = time.perf_counter()
-            tp = feat.shape[1]
-            kept = [u for u in utts if int(u["chunkStart"].max()) <= tp - 357]
-            ref = [{"episode": "e", "utterance": "x", "speaker": 0, "role": "host"}]
-            out = unaligned_to_wder([(ref, kept)], {"e": feat[0]}, {"e": ids[0]}, {}, system.tokenizer, word_level=True,
-                                    num_ids=6008)
-            sync(); t3 = time.perf_counter()
-            stats.update(tokens=int(gen.shape[1]) - 1, utterances=len(utts), words=len(out[0][1]),
-                         decode_ms=1e3 * (t1 - t0), sd_ms=1e3 * (t2 - t1), wder_format_ms=1e3 * (t3 - t2))
+            st, _ = decode_episode_gpu(system, sdm, audio, lens, sync)
+            stats.update(st)
         units_per_step = world * frames
         scaling = "weak"
         workload = ("1 x %.0f s 16 kHz episode per GPU: ASRModel encode + sliding-window greedy decode "
@@ -590,6 +637,59 @@ def main():
         clip_latency["what"] = "SDModel.speaker_ids on ONE resident clip of that length, 30 calls back to back (each ends with the " \
                                "range-guard read-back, i.e. a device synchronisation)"
 
+    # What ONE rank of an 8 / 4 / 2 / 1-GPU run of configs[3] (64 x 5-minute segments, tal/asr/transcribe.py:124-162 batches)
+    # computes per step: its 8 / 16 / 32 / 64 segments as one batched call.  Measurable on one GPU, and what the 8-GPU target
+    # hangs on: expected speed-up at N ranks ~ t(64) / (t(64 / N) + gather).
+    per_rank_share = None
+    if rank == 0 and args.workload == "clip" and not fake and world == 1 and not args.no_per_rank_share:
+        per_rank_share = {}
+        with torch.no_grad():
+            seg = torch.cat([torch.from_numpy(synth.synth_audio_batch(1, 4800000, 1234 + i)) for i in range(64)]).to(dev)
+            for nb in (64, 32, 16, 8):
+                a = seg[:nb]
+                for _ in range(2):
+                    model.speaker_ids(a)
+                sync()
+                t_c = time.perf_counter()
+                for _ in range(4):
+                    model.speaker_ids(a)
+                sync()
+                dt_c = (time.perf_counter() - t_c) / 4
+                per_rank_share[str(nb)] = {"ms": 1e3 * dt_c, "frames_per_s": nb * 30001 / dt_c}
+            del seg, a
+        f64 = per_rank_share["64"]["frames_per_s"]
+        for nb in (32, 16, 8):
+            per_rank_share[str(nb)]["efficiency_vs_64"] = per_rank_share[str(nb)]["frames_per_s"] / f64
+        per_rank_share["expected_speedup"] = {str(64 // nb): per_rank_share["64"]["ms"] / (per_rank_share[str(nb)]["ms"] + 0.25)
+                                              for nb in (32, 16, 8)}
+        per_rank_share["what"] = ("B x 300 s segments as ONE batched SDModel.speaker_ids call on one GPU (B = 64 / N: the share of a rank "
+                                  "of an N-GPU run of configs[3]), 4 calls back to back; expected_speedup[N] = ms(64) / (ms(64 / N) + "
+                                  "0.25 ms for the result gather and the scalar all-reduce): an estimate from one-GPU measurements, "
+                                  "NOT a multi-GPU measurement")
+
+    # BASELINE.json configs[4] beside the headline: a 5-minute episode through the whole joint chain, and the CPU port of
+    # the same chain on the same episode (bounded: ~10 s of CPU time).  --workload decode is the 1-hour form.
+    decode_episode = None
+    if rank == 0 and args.workload == "clip" and not fake and world == 1 and not args.no_decode_episode:
+        from tal_asrd_amd.system import System
+        from tal_asrd_amd.tokenizer import SynthTokenizer
+        asr, asr_sd = build_asr_model(dev)
+        system = System(asr, tokenizer=SynthTokenizer(10000))
+        Le = int(args.decode_episode_seconds * 16000)
+        ep_np = synth.synth_audio_batch(1, Le, 2469)
+        ep = torch.from_numpy(ep_np).to(dev)
+        with torch.no_grad():
+            decode_episode_gpu(system, model, ep, torch.tensor([Le]), sync)         # warm-up
+            st, gen = decode_episode_gpu(system, model, ep, torch.tensor([Le]), sync)
+        decode_episode = {"seconds": args.decode_episode_seconds, "tokens": st["tokens"], "ms": st["total_ms"],
+                          "ms_per_token": st["decode_ms"] / max(st["tokens"], 1), "frames_per_s": (1 + Le // 160) / (1e-3 * st["total_ms"]),
+                          "legs_ms": {k: st[k] for k in ("decode_ms", "sd_ms", "wder_format_ms")},
+                          "what": "one %.0f s episode: ASRModel encode + System.generate_unaligned (tal/asr/system.py:254-524) + SDModel "
+                                  "pass + word-level WDER-input pooling / voting, second of two runs" % args.decode_episode_seconds}
+        if not args.no_cpu_baseline:
+            extra["_decode_episode_cpu_args"] = (asr_sd, ep_np, gen[0].cpu().numpy())
+        del asr, system, ep
+
     # ------------------------------------------------------------------ timed region
     def timed_pass(with_prof):
         sync()
@@ -704,18 +804,9 @@ def main():
                 kern[name] = {"ms_total": ms.value, "launches": n.value, "work": work.value}
             gm = kern["gemm_nt_f32"]
             achieved = gm["work"] / (gm["ms_total"] * 1e-3) / 1e12 if gm["ms_total"] > 0 else 0.0
-            traffic = traffic_source = None
-            try:   # fabric-side bytes per launch: NOT measured in this run -- the figure of the builder's separate
-                   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/profile_round.sh), committed under profiles/
-                for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
-                    path = os.path.join(ROOT, "profiles", name)
-                    if os.path.exists(path):
-                        with open(path) as f:
-                            traffic = json.load(f)["hbm_bytes_per_launch"]
-                        traffic_source = "profiles/%s (builder-run rocprofv3 --pmc passes of the 1-hour clip workload, not this run)" % name
-                        break
-            except Exception:
-                pass
+            # fabric-side bytes per launch: NOT measured in this run -- the figure of the builder's separate rocprofv3 --pmc
+            # FETCH_SIZE / WRITE_SIZE passes (scripts/profile_round.sh), quoted only while it describes this tree's kernels
+            traffic, traffic_source = load_traffic()
             f32_only = exact_mode
             peak = FP32_MATRIX_PEAK_TFLOPS if f32_only else F16_MATRIX_PEAK_TFLOPS
             # MFMA flops actually issued: the pointwise layers run as 3 fp16 MFMAs per fp32 product (hi*hi, hi*lo, lo*hi)
@@ -747,12 +838,40 @@ def main():
             line["stream_of_clips_from_host"] = streamed
         if clip_latency is not None:
             line["clip_latency"] = clip_latency
+        if per_rank_share is not None:
+            line["per_rank_share"] = per_rank_share
         if h2d_ms is not None:
             line["h2d_ms_per_clip"] = h2d_ms
             line["value_including_h2d"] = total_frames / (elapsed + 1e-3 * h2d_ms * args.segments * args.steps)
+        cpu_args = line.pop("_decode_episode_cpu_args", None)
         if not args.no_cpu_baseline and world == 1 and not fake:
-            line["cpu_baseline"] = cpu_baseline(sd, args.cpu_seconds, [c for c in args.cpu_threads.split(",") if c.strip()])
+            threads = [c for c in args.cpu_threads.split(",") if c.strip()]
+            if args.workload == "decode":
+                # the CPU port of the same chain on a BOUNDED sample (a 5-minute episode: ~10 s of CPU time; the 1-hour
+                # episode would take minutes), at the thread count that is best for the encoder path
+                base = cpu_baseline(sd, args.cpu_seconds, threads)
+                Ls = int(min(args.seconds, args.decode_episode_seconds) * 16000)
+                ep_s = synth.synth_audio_batch(1, Ls, 2469 + rank)
+                port = max((decode_episode_cpu(asr_sd, sd, ep_s, c)[0] for c in sorted({base["cores"], min(16, base["host_cpus"])})),
+                           key=lambda r: r["frames_per_s"])       # (the token loop's small GEMMs like fewer threads than the encoder)
+                line["cpu_baseline"] = {"value": port["frames_per_s"], "unit": "frames/s", "cores": port["threads"], "kind": "port",
+                                        "host_cpus": base["host_cpus"], "tokens": port["tokens"], "decode_s": port["decode_s"], "sd_s": port["sd_s"],
+                                        "sample": "%.0f s episode (a bounded sample of the same chain, not the %.0f s episode `value` is "
+                                                  "measured on): %s" % (Ls / 16000, args.seconds, port["what"])}
+            else:
+                line["cpu_baseline"] = cpu_baseline(sd, args.cpu_seconds, threads,
+                                                    full_seconds=None if (args.no_cpu_full_clip or args.workload != "clip") else args.seconds)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+            if decode_episode is not None and cpu_args is not None:
+                port, toks = max((decode_episode_cpu(cpu_args[0], sd, cpu_args[1], c)
+                                  for c in sorted({line["cpu_baseline"]["cores"], min(16, line["cpu_baseline"]["host_cpus"])})),
+                                 key=lambda r: r[0]["frames_per_s"])
+                same = len(toks) == len(cpu_args[2]) and bool((toks == cpu_args[2]).all())
+                decode_episode["cpu_port"] = port
+                decode_episode["gpu_over_cpu"] = decode_episode["frames_per_s"] / port["frames_per_s"]
+                decode_episode["token_stream_identical_to_cpu_port"] = same
+        if decode_episode is not None:
+            line["decode_episode"] = decode_episode
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

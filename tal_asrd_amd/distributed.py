@@ -72,6 +72,16 @@ _DTYPES = [torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.in
            torch.uint8, torch.bool]
 
 
+class _DoneWork:
+    """What SegmentGather.gather(async_op=True) returns as `work` when there is nothing to wait for (one rank)."""
+
+    def wait(self, timeout=None):
+        return True
+
+    def is_completed(self):
+        return True
+
+
 class SegmentGather:
     """Plan + buffers for gathering variable-length per-segment results to rank `dst`, built ONCE for a fixed assignment
     (which rank holds which item, how many rows each has): the (owner, rows) table and the row description travel in one
@@ -141,9 +151,14 @@ class SegmentGather:
     def gather(self, local: dict, async_op: bool = False):
         """local: {item: tensor [rows_i, *trailing]} of this rank's items -> list of n_items tensors (views into the plan's
         receive buffers, item order) on `dst`, None elsewhere.  async_op: returns (work, finish) instead; call
-        work.wait() and then finish() for the list."""
+        work.wait() and then finish() for the list.  The plan owns ONE send buffer: an asynchronous gather must be waited
+        for before the next gather of the same plan is issued (asserted)."""
         if self.world == 1:
-            return [local[i] for i in range(self.n_items)]
+            items = [local[i] for i in range(self.n_items)]
+            return (_DoneWork(), lambda: items) if async_op else items
+        if getattr(self, "_in_flight", None) is not None and not self._in_flight.is_completed():
+            raise RuntimeError("SegmentGather.gather: the previous asynchronous gather of this plan has not been waited for "
+                               "(its send buffer is still in flight)")
         o = 0
         for i in self.local_items:
             n = self.length[i]
@@ -152,6 +167,7 @@ class SegmentGather:
             self.send[o:o + n].copy_(local[i])
             o += n
         work = dist.gather(self.send, self.recv, dst=self.dst, async_op=async_op)
+        self._in_flight = work if async_op else None
 
         def finish():
             if self.rank != self.dst:

@@ -20,17 +20,21 @@ void set_error(const char* fmt, ...) {
 // ---- behaviour switches (tal_set_option) ---------------------------------------------------
 static const char* const g_opt_names[OPT_COUNT] = {
     "tds_exact_f32", "tds_fp32_activations", "gconv_fuse_split", "gconv_c1_generic", "head_no_astationary", "gemm_global_loads",
-    "gemm_no_splitk4", "gemm_no_glds", "gemm_no_splitk_tail", "gemm_no_w64", "logmel_no_fold", "decode_no_small", "decode_small_rows", "gemm_no_row_split", "gemm_no_n96", "gemm_s64_below", "gconv_short_below"};
-static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {256}, {0}, {0}, {2}, {4}};
+    "gemm_no_splitk4", "gemm_no_glds", "gemm_no_splitk_tail", "gemm_no_w64", "logmel_no_fold", "decode_no_small", "decode_small_rows", "gemm_no_row_split", "gemm_no_n96", "gemm_s64_below", "gconv_short_below", "gconv_no_shift18", "gconv_grid_xyz"};
+static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {256}, {0}, {0}, {2}, {4}, {0}, {0}};
 int opt(Option o) { return g_opt[o].load(std::memory_order_relaxed); }
 
 int device_cus() {
-    static int cus = 0;
+    // per device (a process may drive several), filled on first use; racing first uses write the same value
+    static std::atomic<int> table[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int cus = table[dev].load(std::memory_order_relaxed);
     if (!cus) {
-        int dev = 0;
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
         if (cus <= 0) cus = 256;
+        table[dev].store(cus, std::memory_order_relaxed);
     }
     return cus;
 }

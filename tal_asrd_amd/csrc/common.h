@@ -113,10 +113,19 @@ enum Option {
     OPT_GEMM_NO_N96,              // never the 128 x 96 tiles for mid-sized fp16x3 launches (N % 96 == 0)
     OPT_GEMM_S64_BELOW,           // fp16x3 relu / residual layers take 64 x 80 tiles while those number at most this many per CU (default 2; 0: never)
     OPT_GCONV_SHORT_BELOW,        // grouped convs take 64-step tiles while the long tiles give a CU fewer workgroups than this (default 4)
+    OPT_GCONV_NO_SHIFT18,         // 18-channel TDSBlock conv (split form in / out) on the two-M-tile kernel instead of the time-shift-packed one
+    OPT_GCONV_GRID_XYZ,           // matrix-core grouped convs on the plain (time tile, group block, item) grid instead of the XCD-aware 1-D order
     OPT_COUNT
 };
 int opt(Option o);
 int device_cus();      // compute units of the current device
+
+// XCD-aware bijective remap of a 1-D grid: block b runs on XCD b % 8 (observed placement, a speed assumption only); XCD x walks a
+// CONTIGUOUS range of logical blocks, so blocks that are neighbours in the logical order share that XCD's L2
+__device__ __forceinline__ unsigned xcd_logical_block(unsigned nb, unsigned bid) {
+    const unsigned xcd = bid & 7u, q = nb >> 3, r = nb & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
 
 // wave-uniform wave index inside the workgroup, provably uniform to the compiler
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }

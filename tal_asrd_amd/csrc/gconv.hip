@@ -453,6 +453,27 @@ __device__ __forceinline__ f16x8 gconv_frag(const _Float16* p, const _Float16* p
     return *reinterpret_cast<const f16x8u*>(p);
 }
 
+// Which (batch item, time tile, group block) a workgroup takes.  n_tt > 0: a 1-D grid in the XCD-aware order -- group blocks
+// fastest, an XCD walks whole time tiles: a row of the activations is C * 4 bytes shared by all group blocks, and a workgroup's
+// 36-56 channels are 144-224 bytes that start and end inside 128-byte lines, so neighbouring group blocks READ and WRITE the same
+// lines.  On the plain (time tile, group block, item) grid they sit on different XCDs (block b runs on XCD b % 8): every
+// boundary line is fetched by two L2s and leaves two L2s as a partial write (measured 1.85x the input fetched, 1.35x the output
+// written, profiles/r3_pmc_traffic_all_kernels.txt).  n_tt == 0: the plain 3-D grid (option gconv_grid_xyz, ablation).
+#define GC_BLOCK_INDEX(n_tt, n_gb)                                                           \
+    int b, g0;                                                                               \
+    int64_t t0;                                                                              \
+    if (n_tt > 0) {                                                                          \
+        const unsigned L = xcd_logical_block(gridDim.x, blockIdx.x);                         \
+        const unsigned gbi = L % (unsigned)n_gb, rest = L / (unsigned)n_gb;                  \
+        g0 = (int)gbi * GB;                                                                  \
+        t0 = (int64_t)(rest % (unsigned)n_tt) * TT;                                          \
+        b = (int)(rest / (unsigned)n_tt);                                                    \
+    } else {                                                                                 \
+        b = blockIdx.z;                                                                      \
+        g0 = blockIdx.y * GB;                                                                \
+        t0 = (int64_t)blockIdx.x * TT;                                                       \
+    }
+
 // SPLIT: 0 = fp32 output, 1 = fp32 output + its hi / lo split, 2 = the split form only.  XSPLIT: the input is in the split
 // form (per row and 32-channel block: 32 hi halves, 32 lo halves; same bytes as fp32) -- the slab is then filled without
 // any conversion arithmetic and the TDSBlock residual is rebuilt from the slab as hi + lo * 2^-11.
@@ -460,7 +481,7 @@ template <int CIG, int COG, int STRIDE, bool RESID, int GB, int TT, int SPLIT, b
 __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(const float* __restrict__ x, const _Float16* __restrict__ wfrag,
                                                            const float* __restrict__ bias, float alpha, float* __restrict__ y,
                                                            _Float16* __restrict__ ysplit, int64_t T_in, int64_t T_out, int C_in,
-                                                           int C_out, int* __restrict__ range_flag) {
+                                                           int C_out, int* __restrict__ range_flag, int n_tt, int n_gb) {
     using LY = GcLayout<CIG, STRIDE>;
     constexpr int NKS = LY::NKS, NK0 = LY::nk(0), MT = (COG + 15) / 16;
     constexpr int P0 = LY::pitch(0), P1 = LY::pitch(1);
@@ -481,8 +502,7 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
     _Float16* s_hi = slab;
     _Float16* s_lo = slab + GB * GS;
 
-    const int b = blockIdx.z, g0 = blockIdx.y * GB;
-    const int64_t t0 = (int64_t)blockIdx.x * TT;
+    GC_BLOCK_INDEX(n_tt, n_gb)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = wave_id();
     const float* xb = x + (int64_t)b * T_in * C_in;
@@ -848,6 +868,337 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 18 channels per group (the six TDSBlocks of the last stage), split form in and out: TIME-SHIFT PACKING
+// ---------------------------------------------------------------------------------------------
+// 18 = 16 + 2: in gconv_mfma_kernel the second 16-row M tile of a group multiplies two output channels -- 42 of the 84 MFMAs
+// (and fragment reads) per 16 output steps for a ninth of the outputs.  The Hankel view offers a denser packing: moving a
+// channel's weights s slab rows down (k -> k + s P) yields the SAME channel's output s steps later,
+//     sum_k W[co][k - s P] slab[t P + k] = out(co, t + s),
+// so ONE M tile of rows (channel c in {16, 17}) x (shift s in 0..7), run over K = (21 + 7) rows and columns 8 steps apart,
+// produces the two channels for 128 consecutive steps in 18 K chunks: 54 MFMAs per 128 steps instead of 336.
+// Work split: a workgroup = 2 groups x TT steps, wave w = (group w / 2, role h = w % 2).
+//   phase A  wave (g, h) computes the shifted tile of steps [128 h, 128 h + 128) (TT = 64: h = 0 only, 8 columns), finishes it
+//            (bias, fp16x3 combine, ReLU, ReZero residual, hi / lo split) and parks the halves in the slab's pad columns
+//            (18, 19 of the 20-halves rows: never read under a non-zero weight) -- before any output overwrites slab rows;
+//   phase B  the 16-channel tile as before, wave h over the blocks of its half of the tile -- no barrier inside: a block's halves
+//            overwrite its own (dead) slab rows; wave 1 holds back the two blocks whose rows wave 0 still reads.
+// Per 16 output steps and group: 42 + 6.75 MFMAs instead of 84, both waves of a group carry equal work, and the 16 workgroup
+// barriers of a tile's block loop become one.
+// An output's chain of MFMAs depends on its shift s = (t - tile start) % 8 only, and tile starts are multiples of 64: long
+// (256) and short (64) tiles give bit-identical results.  Channels 16, 17 differ from gconv_mfma_kernel's in the last bits
+// (other grouping of the products into K chunks), channels 0-15 are the same chains.
+constexpr int S18_NKA = 18;      // K chunks of the shifted tile: (21 + 7) rows x 20 halves = 560 -> 576
+constexpr int S18_SH = 8;        // shifts per channel
+
+template <int TT>
+__global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __restrict__ x, const _Float16* __restrict__ wfrag,
+                                                             const _Float16* __restrict__ wshift, const float* __restrict__ bias, float alpha,
+                                                             _Float16* __restrict__ ysplit, int64_t T, int C, int* __restrict__ range_flag,
+                                                             int n_tt, int n_gb) {
+    using LY = GcLayout<18, 1>;
+    static_assert(LY::NSEG == 1 && LY::pitch(0) == 20 && LY::PERM && LY::nk(0) == 14, "the shift-packed kernel is built for 40-byte slab rows");
+    constexpr int CG = 18, GB = 2, P = 20, NK = 14, NKP = LY::NKP, PADT = KS / 2;
+    constexpr int TIN = TT + KS - 1, GS = LY::slab(0, TT);
+    static_assert(GS * 2 >= ((TT >= 128 ? TT - 8 : TT - 8) * P + 32 * S18_NKA) * 2, "slab tail");
+    constexpr int CH = GB * CG, CH4 = CH / 4, RPP = 256 / CH4;
+    extern __shared__ __attribute__((aligned(16))) _Float16 slab[];   // [2 (hi, lo)][GB][GS]
+    _Float16* s_hi = slab;
+    _Float16* s_lo = slab + GB * GS;
+
+    GC_BLOCK_INDEX(n_tt, n_gb)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = wave_id();
+    const float* xb = x + (int64_t)b * T * C;
+    const int nrows = (int)(T - t0 < (int64_t)TT ? T - t0 : (int64_t)TT);
+
+    // ---- slab fill from the split-form input (as gconv_mfma_kernel<.., XSPLIT = true>) ----
+    {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const int r0 = tid / CH4, c4 = tid - r0 * CH4;
+        const bool active = r0 < RPP;
+        int so[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ch = c4 * 4 + 2 * q, gl = ch / CG;
+            so[q] = gl * GS + ch - gl * CG;
+        }
+        __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)(T * C * 4), 0x00020000);
+        const int64_t row0 = t0 - PADT + r0;
+        const int cgl = g0 * CG + (active ? c4 * 4 : 0);
+        const int voffs = (int)(row0 * C * 4) + (cgl >> 5) * 128 + (cgl & 31) * 2;
+        constexpr int NPASS = (TIN + RPP - 1) / RPP;
+        u32x2 vh[NPASS], vl[NPASS];
+#pragma unroll
+        for (int u = 0; u < NPASS; ++u) {
+            vh[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, voffs + u * RPP * C * 4, 0, 0);
+            vl[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, voffs + 64 + u * RPP * C * 4, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NPASS; ++u) {
+            const int ti = r0 + u * RPP;
+            if (active && ti < TIN) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    *reinterpret_cast<unsigned*>(s_hi + so[q] + ti * P) = vh[u][q];
+                    *reinterpret_cast<unsigned*>(s_lo + so[q] + ti * P) = vl[u][q];
+                }
+            }
+        }
+        // zeros in the pad columns of every row and behind the last row (finite bytes under zero weights)
+        const f16x2 z2 = {(_Float16)0.f, (_Float16)0.f};
+        for (int i = tid; i < 2 * GB * TIN; i += 256)
+            *reinterpret_cast<f16x2*>(slab + (i / TIN) * GS + (i % TIN) * P + CG) = z2;
+        constexpr int tail2 = (GS - TIN * P) / 2;
+        for (int i = tid; i < 2 * GB * tail2; i += 256)
+            *reinterpret_cast<f16x2*>(slab + (i / tail2) * GS + TIN * P + 2 * (i % tail2)) = z2;
+    }
+    __syncthreads();
+
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int col = lane & 15, kg = lane >> 4;
+    const int gl = w >> 1, h = w & 1, g = g0 + gl;
+    const f32x2 s11 = {1.0f / 2048.0f, 1.0f / 2048.0f}, z0 = {0.f, 0.f}, al2 = {alpha, alpha};
+    float am = 0.f;        // fp16-range guard: the largest |y| this lane turns into halves
+
+    // ---- phase A: channels 16, 17 of 128 (64) steps as one shifted M tile ----
+    constexpr int NRANGE = TT >= 128 ? TT / 128 : 1, NCOLV = TT >= 128 ? 16 : TT / S18_SH;
+    if (h < NRANGE) {
+        const int cn = col & (NCOLV - 1);                          // (TT = 64: columns 8-15 repeat 0-7 and are dropped)
+        const int base = h * 128 + S18_SH * cn;                    // first output step of this column
+        const f16x8* wf = reinterpret_cast<const f16x8*>(wshift) + (int64_t)g * (S18_NKA * 2 * 64) + lane;
+        const _Float16* hs = s_hi + gl * GS + base * P + 8 * kg;   // 16-byte aligned: 8 rows = 320 bytes
+        const _Float16* ls = s_lo + gl * GS + base * P + 8 * kg;
+        const float b16 = bias[g * CG + 16], b17 = bias[g * CG + 17];
+        f32x4 acc = {b16, b17, b16, b17}, ax1 = {0.f, 0.f, 0.f, 0.f}, ax2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < S18_NKA; ++c) {
+            const f16x8 ah = wf[(c * 2 + 0) * 64], al = wf[(c * 2 + 1) * 64];
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(hs + 32 * c), bl = *reinterpret_cast<const f16x8*>(ls + 32 * c);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+            ax1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, ax1, 0, 0, 0);
+            ax2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, ax2, 0, 0, 0);
+        }
+        // rows 4 kg + e of the tile = (shift 2 kg + e / 2, channel 16 + e % 2): this lane holds steps tl, tl + 1 x channels 16, 17
+        const int tl = base + 2 * kg;
+        f32x2 oa = {acc[0], acc[1]}, ob = {acc[2], acc[3]};
+        oa = f32x2{ax1[0] + ax2[0], ax1[1] + ax2[1]} * s11 + oa;
+        ob = f32x2{ax1[2] + ax2[2], ax1[3] + ax2[3]} * s11 + ob;
+        const _Float16* rh = s_hi + gl * GS + (tl + PADT) * P + 16;
+        const _Float16* rl = s_lo + gl * GS + (tl + PADT) * P + 16;
+        const f16x2 ha = *reinterpret_cast<const f16x2*>(rh), la = *reinterpret_cast<const f16x2*>(rl);
+        const f16x2 hb = *reinterpret_cast<const f16x2*>(rh + P), lb = *reinterpret_cast<const f16x2*>(rl + P);
+        oa = al2 * __builtin_elementwise_max(oa, z0) + (__builtin_convertvector(la, f32x2) * s11 + __builtin_convertvector(ha, f32x2));
+        ob = al2 * __builtin_elementwise_max(ob, z0) + (__builtin_convertvector(lb, f32x2) * s11 + __builtin_convertvector(hb, f32x2));
+        if (col < NCOLV) {
+            if (tl < nrows) am = __builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(oa[0]), __builtin_fabsf(oa[1])));
+            if (tl + 1 < nrows) am = __builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(ob[0]), __builtin_fabsf(ob[1])));
+            f16x2p hap, lap, hbp, lbp;
+            if (range_flag) {
+                split_f16x3_pair(oa[0], oa[1], hap, lap);
+                split_f16x3_pair(ob[0], ob[1], hbp, lbp);
+            } else {
+                _Float16 hh[4], ll[4];
+                split_f16x3(oa[0], hh[0], ll[0]); split_f16x3(oa[1], hh[1], ll[1]);
+                split_f16x3(ob[0], hh[2], ll[2]); split_f16x3(ob[1], hh[3], ll[3]);
+                hap = {hh[0], hh[1]}; lap = {ll[0], ll[1]}; hbp = {hh[2], hh[3]}; lbp = {ll[2], ll[3]};
+            }
+            _Float16* oh = s_hi + gl * GS + tl * P + CG;          // pad columns 18, 19 of the OUTPUT step's row
+            _Float16* ol = s_lo + gl * GS + tl * P + CG;
+            *reinterpret_cast<f16x2p*>(oh) = hap;
+            *reinterpret_cast<f16x2p*>(ol) = lap;
+            *reinterpret_cast<f16x2p*>(oh + P) = hbp;
+            *reinterpret_cast<f16x2p*>(ol + P) = lbp;
+        }
+    }
+
+    // ---- phase B: channels 0-15; wave h takes the blocks of its half of the tile, one after the other, WITHOUT barriers ----
+    // A block's output halves overwrite the slab rows of its own 16 steps (dead once the block has its operands: the next block
+    // reads from 16 rows further on).  The only rows two waves of a group contend for are the first 20 of the second half -- wave
+    // 0's last blocks still read them --, so wave 1 keeps the output of its first two blocks in registers (8 VGPRs) until the
+    // barrier that precedes the store phase anyway.
+    typedef _Float16 f16x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+    f16x4a8 keep_h[2], keep_l[2];
+    constexpr int NB = TT / 16, NBH = NB / 2;
+    static_assert(NB % 2 == 0 && NBH >= 2, "blocks per tile");
+    {
+        f16x8 wh[NK], wl[NK];
+        const f16x8* wf = reinterpret_cast<const f16x8*>(wfrag) + (int64_t)(g * 2) * (NK * 2 * 64) + lane;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            wh[ks] = wf[(ks * 2 + 0) * 64];
+            wl[ks] = wf[(ks * 2 + 1) * 64];
+        }
+        const int ch0 = 4 * kg;
+        f32x4 bv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = bias[g * CG + ch0 + i];
+        // fragment of K chunk c for output column (16 tb + col): (16 tb + col) * P + [permuted: 128 (c / 4) + 8 (c % 4), k group kg at
+        // 64 (kg & 1) + 32 (kg >> 1) | plain (c >= NKP): 32 c + 8 kg]; two ds_read_b64 per fragment (gconv_frag)
+        const int kgo = 64 * (kg & 1) + 32 * (kg >> 1);
+        const _Float16* hs = s_hi + gl * GS + kgo;
+        const _Float16* ls = s_lo + gl * GS + kgo;
+        int four = 4;
+        asm volatile("" : "+v"(four));
+        const _Float16* hs2 = hs + four;
+        const _Float16* ls2 = ls + four;
+        const _Float16* hst = s_hi + gl * GS + 8 * kg;
+        const _Float16* lst = s_lo + gl * GS + 8 * kg;
+        const _Float16* hst2 = hst + four;
+        const _Float16* lst2 = lst + four;
+        auto foff = [&](int c, int b0) { return c < NKP ? b0 + 128 * (c >> 2) + 8 * (c & 3) : b0 + 32 * c; };
+        auto frag_h = [&](int c, int b0) { return c < NKP ? gconv_frag<P>(hs + foff(c, b0), hs2 + foff(c, b0)) : gconv_frag<P>(hst + foff(c, b0), hst2 + foff(c, b0)); };
+        auto frag_l = [&](int c, int b0) { return c < NKP ? gconv_frag<P>(ls + foff(c, b0), ls2 + foff(c, b0)) : gconv_frag<P>(lst + foff(c, b0), lst2 + foff(c, b0)); };
+        constexpr int PF = GC_PF, RING = PF + 1;
+        const int tb0 = h * NBH;
+        int boff = (tb0 * 16 + col) * P;
+        f16x8 chh[PF], cll[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            chh[q] = frag_h(q, boff);
+            cll[q] = frag_l(q, boff);
+        }
+        const _Float16* rh = s_hi + gl * GS + ch0;
+        const _Float16* rl = s_lo + gl * GS + ch0;
+        auto block = [&](int tb, bool last, f16x4a8& oh, f16x4a8& ol) {
+            f32x4 acc = bv, ax1 = {0.f, 0.f, 0.f, 0.f}, ax2 = {0.f, 0.f, 0.f, 0.f};
+            const int nb = last ? boff : boff + 16 * P;
+            f16x8 bh[RING], bl[RING];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                bh[q] = chh[q];
+                bl[q] = cll[q];
+            }
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const int pk = ks + PF;
+                if (pk < NK) {
+                    bh[pk % RING] = frag_h(pk, boff);
+                    bl[pk % RING] = frag_l(pk, boff);
+                } else {
+                    bh[pk % RING] = frag_h(pk - NK, nb);
+                    bl[pk % RING] = frag_l(pk - NK, nb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], bh[ks % RING], acc, 0, 0, 0);
+                ax1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], bl[ks % RING], ax1, 0, 0, 0);
+                ax2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks], bh[ks % RING], ax2, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                chh[q] = bh[(NK + q) % RING];
+                cll[q] = bl[(NK + q) % RING];
+            }
+            boff = nb;
+            f32x2 oa = {acc[0], acc[1]}, ob = {acc[2], acc[3]};
+            oa = f32x2{ax1[0] + ax2[0], ax1[1] + ax2[1]} * s11 + oa;
+            ob = f32x2{ax1[2] + ax2[2], ax1[3] + ax2[3]} * s11 + ob;
+            const int ro = (tb * 16 + col + PADT) * P;
+            const f16x2 h01 = *reinterpret_cast<const f16x2*>(rh + ro), l01 = *reinterpret_cast<const f16x2*>(rl + ro);
+            const f16x2 h23 = *reinterpret_cast<const f16x2*>(rh + ro + 2), l23 = *reinterpret_cast<const f16x2*>(rl + ro + 2);
+            oa = al2 * __builtin_elementwise_max(oa, z0) + (__builtin_convertvector(l01, f32x2) * s11 + __builtin_convertvector(h01, f32x2));
+            ob = al2 * __builtin_elementwise_max(ob, z0) + (__builtin_convertvector(l23, f32x2) * s11 + __builtin_convertvector(h23, f32x2));
+            const float am2 = __builtin_fmaxf(__builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(oa[0]), __builtin_fabsf(oa[1]))),
+                                              __builtin_fmaxf(__builtin_fabsf(ob[0]), __builtin_fabsf(ob[1])));
+            am = tb * 16 + col < nrows ? am2 : am;                 // (rows past the end of the sequence are never stored)
+            f16x2p h01p, l01p, h23p, l23p;
+            if (range_flag) {
+                split_f16x3_pair(oa[0], oa[1], h01p, l01p);
+                split_f16x3_pair(ob[0], ob[1], h23p, l23p);
+            } else {
+                _Float16 hh[4], ll[4];
+                split_f16x3(oa[0], hh[0], ll[0]); split_f16x3(oa[1], hh[1], ll[1]);
+                split_f16x3(ob[0], hh[2], ll[2]); split_f16x3(ob[1], hh[3], ll[3]);
+                h01p = {hh[0], hh[1]}; l01p = {ll[0], ll[1]}; h23p = {hh[2], hh[3]}; l23p = {ll[2], ll[3]};
+            }
+            oh = f16x4a8{h01p[0], h01p[1], h23p[0], h23p[1]};
+            ol = f16x4a8{l01p[0], l01p[1], l23p[0], l23p[1]};
+        };
+        auto put = [&](int tb, const f16x4a8& oh, const f16x4a8& ol) {
+            const int so2 = gl * GS + (tb * 16 + col) * P + ch0;
+            *reinterpret_cast<f16x4a8*>(s_hi + so2) = oh;
+            *reinterpret_cast<f16x4a8*>(s_lo + so2) = ol;
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            block(tb0 + i, NBH == 2 && i == 1, keep_h[i], keep_l[i]);
+            if (h == 0) put(tb0 + i, keep_h[i], keep_l[i]);
+        }
+        for (int i = 2; i < NBH; ++i) {
+            f16x4a8 oh, ol;
+            block(tb0 + i, i == NBH - 1, oh, ol);
+            put(tb0 + i, oh, ol);
+        }
+    }
+    note_range(am, range_flag);
+
+    // ---- the tile leaves LDS along rows (as gconv_mfma_kernel's STAGED phase); channels 16, 17 come from the pad columns ----
+    __syncthreads();
+    if (h == 1) {         // every wave has read its operands: the rows wave 0 was still reading can take wave 1's first two blocks
+        const int ch0 = 4 * kg;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int so2 = gl * GS + ((NBH + i) * 16 + col) * P + ch0;
+            *reinterpret_cast<f16x4a8*>(s_hi + so2) = keep_h[i];
+            *reinterpret_cast<f16x4a8*>(s_lo + so2) = keep_l[i];
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CW = GB * CG, PW = 2, NPC = CW / (2 * PW), WPG = CG / 2, NPR = 2 * NPC;
+        constexpr int RP = 256 / NPR, NPO = (TT + RP - 1) / RP;
+        typedef unsigned u32xp __attribute__((ext_vector_type(PW)));
+        const int r = tid / NPR, q = tid - r * NPR;
+        const int a = q / NPC, p = q - a * NPC;          // a: 0 = hi halves, 1 = lo halves
+        int wo[PW];
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const int idx = PW * p + j, gq = idx / WPG, i = idx - gq * WPG;
+            wo[j] = (a * GB + gq) * GS + (i < 8 ? 2 * i : CG) + r * P;
+        }
+        const int c = g0 * CG + 2 * PW * p;
+        char* op = reinterpret_cast<char*>(ysplit) + ((int64_t)b * T + t0 + r) * C * 4 + (c >> 5) * 128 + (c & 31) * 2 + a * 64;
+        const int64_t pstep = (int64_t)RP * C * 4;
+        if (r < RP) {
+            constexpr int CHK = 4;
+            for (int p0 = 0; p0 < NPO; p0 += CHK) {
+                u32xp v[CHK];
+#pragma unroll
+                for (int u = 0; u < CHK; ++u)
+#pragma unroll
+                    for (int j = 0; j < PW; ++j)
+                        v[u][j] = *reinterpret_cast<const unsigned*>(slab + wo[j] + (p0 + u) * RP * P);
+#pragma unroll
+                for (int u = 0; u < CHK; ++u)
+                    if ((p0 + u) * RP + r < nrows) *reinterpret_cast<u32xp*>(op + (p0 + u) * pstep) = v[u];
+            }
+        }
+    }
+}
+
+// weights of the shifted tile: [g][K chunk][hi, lo][lane][8 halves]; row = lane & 15 = 2 s + c (shift s, channel 16 + c),
+// k = 32 chunk + 8 (lane >> 4) + i; k - 20 s = 20 tap + input channel
+__global__ void pack_gconv_shift18_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int groups) {
+    const int64_t total = (int64_t)groups * S18_NKA * 64 * 8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int i = (int)(idx & 7), l = (int)((idx >> 3) & 63);
+    const int c = (int)((idx >> 9) % S18_NKA), g = (int)((idx >> 9) / S18_NKA);
+    const int row = l & 15, sft = row >> 1, co = 16 + (row & 1);
+    const int k = 32 * c + 8 * (l >> 4) + i - 20 * sft;
+    float v = 0.f;
+    if (k >= 0 && k < KS * 20) {
+        const int j = k / 20, cc = k - 20 * j;
+        if (cc < 18) v = src[((int64_t)(g * 18 + co) * 18 + cc) * KS + j];
+    }
+    _Float16 hi, lo;
+    split_f16x3(v, hi, lo);
+    const int64_t base = ((((int64_t)g * S18_NKA + c) * 2) * 64 + l) * 8 + i;
+    dst[base] = hi;
+    dst[base + 64 * 8] = lo;
+}
+
 // reference Conv1d weight [C_out, C_in/G, 21] -> MFMA A fragments [g][mt][K chunk][hi, lo][lane][8 halves]:
 // row = mt * 16 + (lane & 15) (output channel); chunk c of segment s, k = 32 ks + 8 (lane >> 4) + i = j * pitch + cc
 // -> tap tap0 + j * stride, input channel choff + cc
@@ -881,6 +1232,19 @@ __global__ void pack_gconv_mfma_kernel(const float* __restrict__ src, _Float16* 
 template <int CIG, int GB>
 static constexpr bool g0_aligned() { return (CIG * GB) % 4 == 0; }
 
+// grid of the matrix-core kernels: 1-D in the XCD-aware order (GC_BLOCK_INDEX) unless it would not fit 32 bits or the plain
+// grid is asked for
+static dim3 gconv_grid(int64_t tiles, int group_blocks, int B, int& n_tt, int& n_gb) {
+    const int64_t nb = tiles * group_blocks * B;
+    if (nb < (1ll << 31) && tiles < (1ll << 31) && !opt(OPT_GCONV_GRID_XYZ)) {
+        n_tt = (int)tiles;
+        n_gb = group_blocks;
+        return dim3((unsigned)nb);
+    }
+    n_tt = n_gb = 0;
+    return dim3((unsigned)tiles, (unsigned)group_blocks, (unsigned)B);
+}
+
 // x_split: the input is in the split form; y == NULL with ysplit: only the split form of the output is written
 template <int CIG, int COG, int STRIDE, bool RESID, int GB, int TT>
 static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias, float alpha, float* y, void* ysplit, int B,
@@ -888,7 +1252,7 @@ static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias
                             bool x_split = false) {
     using LY = GcLayout<CIG, STRIDE>;
     constexpr size_t lds = (size_t)2 * GB * (LY::slab(0, TT) + LY::slab(1, TT)) * sizeof(_Float16);
-    typedef void (*kern_t)(const float*, const _Float16*, const float*, float, float*, _Float16*, int64_t, int64_t, int, int, int*);
+    typedef void (*kern_t)(const float*, const _Float16*, const float*, float, float*, _Float16*, int64_t, int64_t, int, int, int*, int, int);
     kern_t k;
     if (x_split) k = y ? (ysplit ? (kern_t)gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, 1, true> : (kern_t)gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, 0, true>)
                        : (kern_t)gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, 2, true>;
@@ -906,10 +1270,11 @@ static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias
         }
         attr_done[slot] = reinterpret_cast<const void*>(k);
     }
-    dim3 grid((unsigned)cdiv(T_out, TT), (unsigned)(groups / GB), (unsigned)B);
+    int n_tt, n_gb;
+    const dim3 grid = gconv_grid(cdiv(T_out, TT), groups / GB, B, n_tt, n_gb);
     ProfScope prof(RESID ? PROF_GCONV_RES : PROF_GCONV_S2, 2.0 * (double)B * (double)T_out * C_out * CIG * KS, s);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, reinterpret_cast<const _Float16*>(wfrag), bias, alpha, y,
-                       reinterpret_cast<_Float16*>(ysplit), T_in, T_out, C_in, C_out, range_flag);
+                       reinterpret_cast<_Float16*>(ysplit), T_in, T_out, C_in, C_out, range_flag, n_tt, n_gb);
     TAL_CHECK_LAUNCH("gconv (fp16x3)");
     return TAL_OK;
 }
@@ -925,11 +1290,16 @@ static bool gconv_short_tiles(int64_t T_out, int tt_long, int group_blocks, int 
 // the slab loads address one batch item ([T, C] floats) through a buffer descriptor with 32-bit byte offsets
 bool gconv_f16x3_fits(int64_t T, int C) { return T * C * 4 + (int64_t)300 * C * 4 < ((int64_t)1 << 31); }
 
+// halves of the [g][mt][K chunk][hi, lo][lane][8] fragment table; the 18-channel stride-1 conv keeps a second table behind it:
+// the shifted tile of its two left-over channels (gconv18_shift_kernel)
+static size_t gconv_f16x3_main_halves(const GcPackDesc& d) { return (size_t)d.groups * d.mt_n * (d.nk[0] + d.nk[1]) * 2 * 64 * 8; }
+static bool gconv_has_shift18(const GcPackDesc& d) { return d.cig == 18 && d.cog == 18 && d.tapstep == 1 && d.nseg == 1 && d.pitch[0] == 20; }
+
 size_t gconv_f16x3_weight_bytes(int C_in, int C_out, int groups, int stride) {
     if (groups <= 0 || C_in % groups || C_out % groups) return 0;
     GcPackDesc d;
     if (!gconv_mfma_desc(C_in / groups, C_out / groups, stride, groups, d)) return 0;
-    return (size_t)groups * d.mt_n * (d.nk[0] + d.nk[1]) * 2 * 64 * 8 * sizeof(_Float16);
+    return gconv_f16x3_main_halves(d) * sizeof(_Float16) + (gconv_has_shift18(d) ? (size_t)groups * S18_NKA * 2 * 64 * 8 * sizeof(_Float16) : 0);
 }
 
 int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C_in, int C_out, int groups, int stride, hipStream_t s) {
@@ -940,6 +1310,12 @@ int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C_in, int C_ou
     const int64_t total = (int64_t)groups * d.mt_n * (d.nk[0] + d.nk[1]) * 64 * 8;
     hipLaunchKernelGGL(pack_gconv_mfma_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w_ref, reinterpret_cast<_Float16*>(w_frag), d);
     TAL_CHECK_LAUNCH("tal_pack_gconv_f16x3_weight");
+    if (gconv_has_shift18(d)) {
+        const int64_t ts = (int64_t)groups * S18_NKA * 64 * 8;
+        hipLaunchKernelGGL(pack_gconv_shift18_kernel, dim3((unsigned)cdiv(ts, 256)), dim3(256), 0, s, w_ref,
+                           reinterpret_cast<_Float16*>(w_frag) + gconv_f16x3_main_halves(d), groups);
+        TAL_CHECK_LAUNCH("tal_pack_gconv_f16x3_weight (shifted tile)");
+    }
     return TAL_OK;
 }
 
@@ -953,6 +1329,31 @@ int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias
     TAL_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && C % 4 == 0, "tal_gconv_res_f16x3_fwd: x must be 16-byte aligned");
     TAL_CHECK_ARG(gconv_f16x3_fits(T, C), "tal_gconv_res_f16x3_fwd: one batch item must stay below 2 GiB (T=%lld, C=%d)", (long long)T, C);
     const int cg = C / groups;
+    if (cg == 18 && x_split && !y && y_split && GC_P18 == 20 && GC_KPERM && !opt(OPT_GCONV_NO_SHIFT18)) {
+        // the product path of the last stage: split form in and out -> the time-shift-packed kernel
+        GcPackDesc d;
+        gconv_mfma_desc(18, 18, 1, groups, d);
+        const _Float16* wshift = reinterpret_cast<const _Float16*>(w_frag) + gconv_f16x3_main_halves(d);
+        const bool shortt = gconv_short_tiles(T, 256, groups / 2, B);
+        using LY = GcLayout<18, 1>;
+        const size_t lds = (size_t)2 * 2 * LY::slab(0, shortt ? 64 : 256) * sizeof(_Float16);
+        auto kern = shortt ? gconv18_shift_kernel<64> : gconv18_shift_kernel<256>;
+        static const void* attr_done[2] = {};
+        if (attr_done[shortt] != reinterpret_cast<const void*>(kern)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                set_error("gconv (fp16x3, shifted tile): cannot reserve %zu bytes of LDS", lds);
+                return TAL_EHIP;
+            }
+            attr_done[shortt] = reinterpret_cast<const void*>(kern);
+        }
+        int n_tt, n_gb;
+        const dim3 grid = gconv_grid(cdiv(T, shortt ? 64 : 256), groups / 2, B, n_tt, n_gb);
+        ProfScope prof(PROF_GCONV_RES, 2.0 * (double)B * (double)T * C * cg * KS, s);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, reinterpret_cast<const _Float16*>(w_frag), wshift, bias, alpha,
+                           reinterpret_cast<_Float16*>(y_split), T, C, range_flag, n_tt, n_gb);
+        TAL_CHECK_LAUNCH("gconv (fp16x3, shifted tile)");
+        return TAL_OK;
+    }
     if (gconv_short_tiles(T, 256, groups / (cg == 18 ? 2 : 4), B)) {
         if (cg == 10) return launch_mfma_spec<10, 10, 1, true, 4, 64>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
         if (cg == 14) return launch_mfma_spec<14, 14, 1, true, 4, 64>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);

@@ -221,20 +221,19 @@ __global__ __launch_bounds__(256, 2) void head_argmax_kernel(const float* __rest
 
 }  // namespace
 
-// true when the shape is one this kernel is meant for (the caller falls back to the generic fused path otherwise)
+// Workgroups of a launch: 2 per CU, fewer when that would make a run shorter than half a row block's N tiles (every row block
+// must be covered by <= HP workgroups): a batch of eight 5-minute segments (29,864 rows = 10,998 units) takes 458 instead of 512
+static int64_t head_argmax_grid(int64_t M, int S) {
+    const int64_t units = cdiv(M, HBM) * cdiv(S, HBN), by_runs = units / ((cdiv(S, HBN) + 1) / 2);
+    const int64_t full = 2 * (int64_t)device_cus();
+    return by_runs < full ? by_runs : full;
+}
+
+// true when the shape is one this kernel is meant for (the caller falls back to the generic fused path otherwise): at least
+// one workgroup per CU
 bool head_argmax_applicable(int64_t M, int S, int E) {
     if (E != HK || S < HBN) return false;
-    const int64_t units = cdiv(M, HBM) * cdiv(S, HBN);
-    const bool no_astationary = opt(OPT_HEAD_NO_ASTATIONARY) != 0;
-    static int cus = 0;           // (one query per process: hipGetDeviceProperties costs tens of microseconds per call)
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-                  ? p.multiProcessorCount : 256;
-    }
-    // every workgroup needs a run of at least half a row block's N tiles, so that a row block spans <= HP workgroups
-    return units >= (int64_t)2 * cus * ((cdiv(S, HBN) + 1) / 2) && !no_astationary;
+    return head_argmax_grid(M, S) >= device_cus() && !opt(OPT_HEAD_NO_ASTATIONARY);
 }
 
 int head_argmax_partials() { return HP; }
@@ -244,21 +243,15 @@ int launch_head_argmax(const float* feat, const float* w, const void* w_split, c
                        int32_t* part_idx, hipStream_t s) {
     TAL_CHECK_ARG(feat && (w || w_split) && b && part_val && part_idx, "head_argmax: null pointer");
     TAL_CHECK_ARG(((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(w_split)) & 15) == 0, "head_argmax: operands must be 16-byte aligned");
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-                  ? p.multiProcessorCount : 256;
-    }
     const int NT = (int)cdiv(S, HBN);
-    const int64_t U = cdiv(M, HBM) * NT;
+    const int64_t U = cdiv(M, HBM) * NT, grid = head_argmax_grid(M, S);
+    TAL_CHECK_ARG(grid >= 1, "head_argmax: too few rows (M=%lld)", (long long)M);
     ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)S * HK, s);
     if (w_split)
-        hipLaunchKernelGGL(head_argmax_kernel<true>, dim3((unsigned)(2 * cus)), dim3(256), 0, s, feat, reinterpret_cast<const float*>(w_split), b, M,
+        hipLaunchKernelGGL(head_argmax_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, feat, reinterpret_cast<const float*>(w_split), b, M,
                            S, NT, U, part_val, part_idx);
     else
-        hipLaunchKernelGGL(head_argmax_kernel<false>, dim3((unsigned)(2 * cus)), dim3(256), 0, s, feat, w, b, M, S, NT, U, part_val, part_idx);
+        hipLaunchKernelGGL(head_argmax_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, feat, w, b, M, S, NT, U, part_val, part_idx);
     TAL_CHECK_LAUNCH("head_argmax");
     return TAL_OK;
 }

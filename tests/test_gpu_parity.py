@@ -345,6 +345,43 @@ def test_gconv_res_f16x3_matches_float64(cg, T, B):
         assert torch.equal(ys, want)
 
 
+@pytest.mark.parametrize("T,B", [(1, 1), (7, 2), (64, 1), (65, 1), (129, 2), (255, 1), (256, 1), (300, 2), (1031, 1), (4000, 1)])
+def test_gconv18_time_shift_packing(T, B):
+    """18 channels per group, split form in and out (the six TDSBlocks of the last stage): the time-shift-packed kernel
+    (channels 16, 17 of 128 steps as ONE shifted M tile) against the two-M-tile kernel it replaces -- channels 0-15 of every
+    group are the same chains of MFMAs (bit-identical halves), channels 16, 17 agree with float64 to the conv tolerance; on
+    both tile lengths (64 / 256 steps), which are bit-identical to each other."""
+    from tal_asrd_amd import ops, _native as N_
+    from tests.test_gpu_stress import _unsplit
+    G, cg = 80, 18
+    C = G * cg
+    g = torch.Generator().manual_seed(4100 + T)
+    x = torch.randn(B, T, C, generator=g) * 3.0
+    w = torch.randn(C, cg, 21, generator=g) / (21 * cg) ** 0.5
+    b = torch.randn(C, generator=g)
+    xs = ops.split_f16x3(x.reshape(B * T, C).to(dev()))
+    xq = _unsplit(xs, B * T, C).reshape(B, T, C).cpu()
+    ref = xq + 0.4 * torch.relu(torch.nn.functional.conv1d(xq.permute(0, 2, 1), w.double(), b.double(), padding=10, groups=G)).permute(0, 2, 1)
+    wf = ops.pack_gconv_f16x3_weight(w.to(dev()), G)
+    out = {}
+    try:
+        for shift in (1, 0):
+            for below in (0, 1 << 20):
+                N_.set_option("gconv_no_shift18", 1 - shift)
+                N_.set_option("gconv_short_below", below)
+                out[(shift, below)] = ops.gconv_res_split(xs, (B, T, C), wf, b.to(dev()), 0.4, G).clone()
+        torch.cuda.synchronize()
+    finally:
+        N_.set_option("gconv_no_shift18", 0)
+        N_.set_option("gconv_short_below", 4)
+    assert torch.equal(out[(1, 0)], out[(1, 1 << 20)])                      # long tiles == short tiles
+    got_new = _unsplit(out[(1, 0)], B * T, C).reshape(B * T, G, cg)
+    got_old = _unsplit(out[(0, 0)], B * T, C).reshape(B * T, G, cg)
+    assert torch.equal(got_new[:, :, :16], got_old[:, :, :16])              # the 16-channel tile: identical chains
+    np.testing.assert_allclose(got_new.reshape(B, T, C).cpu().numpy(), ref.numpy(), atol=3e-5, rtol=1e-5)
+    assert float((got_new[:, :, 16:] - got_old[:, :, 16:]).abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("cg,T,B", [(10, 1501, 1), (14, 751, 2), (18, 376, 1), (18, 65, 3)])
 def test_gconv_short_tiles_equal_long_tiles(cg, T, B):
     """Short inputs take tiles of 64 output steps (option gconv_short_below): every output is the same chain of MFMAs as on the
@@ -635,7 +672,7 @@ def test_speaker_ids_do_not_depend_on_dispatch_choices(sd_model, seconds):
     assert float((feat - feat2).abs().max()) < 2e-4 * max(1.0, float(feat.abs().max()))
 
 
-@pytest.mark.parametrize("M,S", [(33000, 6008), (32768 + 1, 6008), (70001, 1000)])
+@pytest.mark.parametrize("M,S", [(33000, 6008), (32768 + 1, 6008), (70001, 1000), (29864, 6008), (16800, 6008), (17001, 6008)])
 def test_long_input_argmax_head_matches_logits_argmax(M, S):
     """The A-stationary arg-max kernel (long inputs, 128-d features): same ids as arg-max over materialised
     logits, ragged last row block and last column tile, and the LOWEST index on exact ties (two identical

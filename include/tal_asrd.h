@@ -364,6 +364,13 @@ typedef struct tal_greedy_ctx {
     float* picked_host_dev;  /* device alias of picked_host; NULL: resolved (hipHostGetDevicePointer) by the first sync 2 / 3 step */
     uint32_t seq;            /* library-owned: sequence value of the latest sync 2 / 3 step (start at 0) */
     uint32_t _pad;
+    int64_t k_pitch;         /* floats between the K rows k_cache[l] points at; 0: E (a window of its own) */
+    /* episode-wide K | V table (tal_greedy_set_window; all 0 / NULL: windows are projected one by one with tal_cross_kv_fwd):
+     * kv_all[l] = [enc_frames, kv_pitch] floats, K in columns [0, E), V (no bias) in [E, 2E) of a frame's row -- one dense layer
+     * over the whole encoder output per decoder layer, x in_proj_weight[E : 3E] with bias (in_proj_bias[E : 2E] | 0) */
+    const float* const* kv_all;
+    const uint8_t* kpm_all;  /* key-padding bytes of the whole episode [enc_frames] or NULL */
+    int64_t enc_frames, kv_pitch;
 } tal_greedy_ctx;
 size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H, int FF, int V, int E0, int n_layers);
 /* sync: 0 = enqueue only; 1 = copy {token, attention row} to picked_host and wait for the stream; 2 = the last kernel writes
@@ -374,6 +381,68 @@ size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H, int FF, i
 int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int64_t n_gen, int sync, void* stream);
 /* 1: the context's latest sync 2 / 3 step has delivered; 0: not after wait_ms milliseconds (0 = one look); < 0: error. */
 int tal_greedy_step_poll(const tal_greedy_ctx* c, int wait_ms);
+/* The same step for G sessions (1 <= G <= 8) in SHARED launches: one chain of 34 launches advances every session by one token
+ * (the decode loop of System.generate_unaligned is batch 1 -- .item() at tal/asr/system.py:331,411,417 --, so a corpus of
+ * episodes is decoded as concurrent sessions; a chain of small dependent launches per session tops out at the device's four
+ * hardware queues).  Each session keeps its own context (prefix, window K / V^T, workspace, tickets, pinned result buffer);
+ * every launch takes the G argument sets by value and runs the single-session kernel body per session, so a session's token,
+ * attention row and hidden states are bit-identical to tal_greedy_step_fwd's.  All sessions decode with the same model and are
+ * enqueued on `stream`; results are delivered as with sync == 3 (tal_greedy_step_poll per context).  A session joins a merged
+ * step only while its step takes the latency-oriented kernels in the forms the merged launches use (tal_greedy_group_ok: prefix
+ * <= 192 tokens, window > 64 frames, ...); step the others with tal_greedy_step_fwd. */
+int tal_greedy_group_ok(const tal_greedy_ctx* c, int64_t history_start, int64_t n_gen);
+/* Windows as views of an episode-wide K | V table (tal_greedy_ctx.kv_all): V^T [E, pad4(S)] of the frames [frame0, frame0 + S)
+ * for n_layers (<= 8) layers in one transposing launch (pad columns zero); tal_greedy_set_window points a context's k_cache
+ * (rows kv_pitch apart: the context's k_pitch must equal kv_pitch), mem_kpm and -- through that launch -- its vt_cache buffers at
+ * the window [frame0, frame0 + S). */
+int tal_window_vt_fwd(const float* const* kv_all, int n_layers, int64_t frame0, int S, int E, int64_t kv_pitch,
+                      float* const* vt, void* stream);
+int tal_greedy_set_window(tal_greedy_ctx* c, int64_t frame0, void* stream);
+int tal_greedy_step_multi_fwd(tal_greedy_ctx* const* ctxs, const int64_t* history_start, const int64_t* n_gen, int G,
+                              void* stream);
+/* HOST side of the sliding-window loop: the decisions System.generate_unaligned takes on a step's result (tal/asr/system.py:
+ * 389-521: attention centre of mass -> progress / stall counters, n-gram repetition, window shift by shift_frames with the
+ * proportional cut of the text history, skip + roll-back + forced EOS on a stall or repetition, clamps, end of the episode),
+ * as one call per generated token on a plain state struct -- the loop body runs ~5,700 times per hour of audio beside a 0.3 ms
+ * GPU step, and in a group of sessions that share their launches the host side, not the GPU, sets the pace.
+ * All pointers are HOST pointers owned by the caller. */
+typedef struct tal_unaligned_state {
+    int64_t* gen;              /* token stream, capacity gen_cap; gen[0 : n] are valid */
+    int64_t gen_cap, n;
+    int64_t history_start;     /* first token of the live prefix (the next step's input is gen[history_start : n]) */
+    int64_t chunk_start;       /* first encoder frame of the next step's window (python-slice semantics: may be negative) */
+    int64_t encoder_len;       /* unpadded encoder frames of the episode */
+    int64_t eos, it, max_iters;
+    int64_t* rec_chunk_start;  /* one record per kept token: the window start as the reference records it, ... */
+    float* rec_attn;           /* ... the attention row (rec_stride floats reserved per record), ... */
+    int32_t* rec_len;          /* ... and its length */
+    int64_t rec_cap, n_rec;
+    int32_t rec_stride;
+    int32_t chunk_size, max_positions, stall_patience, rep_n;
+    int32_t skip_frames;       /* int(chunk_size * skip_prct) */
+    int32_t shift_frames;      /* int(chunk_size * shift_prct) */
+    float del_prct;            /* float32(shift_prct / thresh_prct) */
+    double thresh_prct;
+    double highest_progress;
+    int32_t num_no_improve, window_time;
+    int32_t flags;             /* TAL_UNALIGNED_* of the latest consume, OR-ed with what the caller has not cleared */
+    int32_t gen_pinned;        /* gen[] is pinned host memory: tal_unaligned_group_run uploads a rewritten prefix itself */
+} tal_unaligned_state;
+#define TAL_UNALIGNED_WINDOW_MOVED 1      /* chunk_start changed: re-materialise the window and its cross-attention K / V^T */
+#define TAL_UNALIGNED_PREFIX_REWRITTEN 2  /* roll-back / forced EOS rewrote gen[]: upload the prefix before the next step */
+#define TAL_UNALIGNED_DONE 4              /* the episode is finished */
+#define TAL_UNALIGNED_GROW 8              /* gen / record capacity is used up: enlarge before the next consume */
+#define TAL_UNALIGNED_ALONE 16            /* (group_run) the next step does not take the merged kernels' forms: step it alone */
+/* One step's result {token, attention row [S]} -> state.  Returns the flags (>= 0) or a negative TAL_E* code. */
+int tal_unaligned_consume(tal_unaligned_state* st, int64_t token, const float* attn, int S);
+/* Advance G sessions (state i <-> context i) by merged steps (tal_greedy_step_multi_fwd + poll +
+ * tal_unaligned_consume per session) until a session raises a flag the library cannot serve itself -- it moves a window that is
+ * a view of the context's episode-wide K | V table (tal_greedy_set_window) and uploads a rewritten prefix from a pinned token
+ * stream; DONE, GROW, ALONE and windows outside the table go back to the caller -- or max_steps steps are done.  Returns the number of steps
+ * taken (>= 0; 0 when a session could not start: its ALONE / GROW flag says why) or a negative TAL_E* code.  dev_cap[i] =
+ * capacity of ctxs[i]->tokens in tokens. */
+int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greedy_ctx* const* ctxs, const int64_t* dev_cap, int G,
+                            int max_steps, void* stream);
 /* HOST helper (no device work, `row` is a host pointer): ngram_repeat_mask(row, n).sum() of tal/asr/util.py:5-17, the
  * repetition detector System.generate_unaligned evaluates once per generated token (system.py:418-421). */
 int64_t tal_ngram_repeat_count(const int64_t* row, int64_t len, int n);

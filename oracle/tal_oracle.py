@@ -397,12 +397,14 @@ def ngram_repeat_mask(xs, n):
 # ----------------------------------------------------------------------------
 def generate_unaligned(audio, generated, audio_lens, sd, eos=1, chunk_size=357, max_iters=1000000, max_positions=512,
                        thresh_prct=0.5, shift_prct=0.25, stall_patience=25, rep_n=5, skip_prct=0.1,
-                       n_layers=4, nhead=4):
+                       n_layers=4, nhead=4, on_step=None):
     """System.generate_unaligned (tal/asr/system.py:254-524) for ONE episode on the CPU, doing the work the reference
     does per generated token: the whole live prefix through all decoder layers (no cache: the loop decodes with
     causal_mask=False, :350-351), the memory window re-projected in every layer, the LM head over every prefix position
     (:243-246), then log_softmax / argmax of the last one (:355-387).  The waveform is rounded to fp16 first (:285).
     -> (token ids [n], recorded window starts [n-1], attention rows: list of [S] arrays).
+    on_step(token, row, win, hist, n_tokens, finished): called after every step with the step's raw result and the state the
+    control flow left behind (tests drive the product's host-side control flow with it).
     Pinned by tests/golden/flow_unaligned*.npz, recorded from the reference's own function (tests/test_oracle_golden.py)."""
     audio = np.asarray(audio, dtype=np.float32).astype(np.float16).astype(np.float32)          # :285
     with torch.no_grad():
@@ -423,7 +425,8 @@ def generate_unaligned(audio, generated, audio_lens, sd, eos=1, chunk_size=357, 
             last = logits[:, -1, :]
             if torch.isnan(last).any():
                 raise Exception("Logits contain nans!")
-            toks.append(int(F.log_softmax(last, dim=-1).argmax(dim=-1)[0]))                    # :366-387
+            picked = int(F.log_softmax(last, dim=-1).argmax(dim=-1)[0])                        # :366-387
+            toks.append(picked)
             row = torch.stack(attn, dim=0).mean(dim=0)[0, -1]                                  # :392-397
             starts.append(win)
             rows.append(row.numpy().copy())
@@ -461,6 +464,8 @@ def generate_unaligned(audio, generated, audio_lens, sd, eos=1, chunk_size=357, 
             hist = max(hist, max(len(toks) - max_positions, 0))                                # :482-483
             assert hist < len(toks) and len(toks) - hist <= max_positions
             since += 1
+            if on_step is not None:
+                on_step(picked, row.numpy(), win, hist, len(toks), reset and last_chunk)
             if reset and last_chunk:                                                           # :510-519
                 break
     return np.asarray(toks, dtype=np.int64), np.asarray(starts, dtype=np.int64), rows

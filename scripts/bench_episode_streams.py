@@ -37,13 +37,15 @@ torch.cuda.synchronize(); t_solo = time.perf_counter() - t0
 steps = sum(int(g_.shape[1]) - 1 for _, g_, _ in solo)
 print("one at a time: %d episodes x %.0f s, %d decode steps, %.3f s = %.0f frames/s, %.3f ms per step"
       % (n_ep, seconds, steps, t_solo, n_ep * frames / t_solo, 1e3 * t_solo / steps), flush=True)
-for k in (1, 2, 4, 8, 16):
-    if k > n_ep:
-        break
+modes = [(k, 1) for k in (1, 2, 4, 8, 16) if k <= n_ep]
+# sessions advanced in step through SHARED launches (tal_greedy_step_multi_fwd): (host threads, sessions per group)
+modes += [(t, gsz) for t, gsz in ((1, 8), (2, 4), (2, 8), (4, 2), (4, 4), (3, 8), (4, 8)) if gsz <= n_ep]
+for k, gsz in modes:
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    many = system.transcribe_unaligned_many(eps, streams=k)
+    many = system.transcribe_unaligned_many(eps, streams=k, group=gsz)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    same = all(torch.equal(a[1].cpu(), b[1].cpu()) and [int(c[0]) for c, _ in a[2]] == [int(c[0]) for c, _ in b[2]]
-               for a, b in zip(solo, many))
-    print("%2d sessions in flight: %.3f s = %.0f frames/s (%.2fx one at a time), %.3f ms per step overall, trajectories identical: %s"
-          % (k, dt, n_ep * frames / dt, t_solo / dt, 1e3 * dt / steps, same), flush=True)
+    same = all(torch.equal(a[1].cpu(), b[1].cpu()) and [int(c[0]) for c, _ in a[2]] == [int(c[0]) for c, _ in b[2]] and
+               all(torch.equal(x[1], y[1]) for x, y in zip(a[2], b[2])) for a, b in zip(solo, many))
+    what = "%2d sessions in flight, own launches" % k if gsz == 1 else "%d thread(s) x groups of %d sessions, shared launches" % (k, gsz)
+    print("%s: %.3f s = %.0f frames/s (%.2fx one at a time), %.3f ms per step overall, trajectories identical: %s"
+          % (what, dt, n_ep * frames / dt, t_solo / dt, 1e3 * dt / steps, same), flush=True)

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("TAL_ASRD_LIB", os.path.join(_HERE, "libtal_asrd_hip.s
 TAL_MAX_STAGES = 4
 TAL_MAX_DEPTH = 8
 TAL_TDS_EXACT_F32 = 1
+TAL_GROUP_MAX = 8       # sessions per merged decode step (csrc/common.h)
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -44,8 +45,21 @@ class GreedyCtx(C.Structure):
                 ("k_cache", C.c_void_p), ("vt_cache", C.c_void_p), ("mem_kpm", C.c_void_p), ("tokens", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("picked_dev", C.c_void_p),
                 ("picked_host", C.c_void_p), ("tickets", C.c_void_p), ("picked_host_dev", C.c_void_p),
-                ("seq", C.c_uint32), ("_pad", C.c_uint32)]
+                ("seq", C.c_uint32), ("_pad", C.c_uint32), ("k_pitch", C.c_int64), ("kv_all", C.c_void_p), ("kpm_all", C.c_void_p),
+                ("enc_frames", C.c_int64), ("kv_pitch", C.c_int64)]
 
+
+class UnalignedState(C.Structure):
+    _fields_ = [("gen", C.c_void_p), ("gen_cap", C.c_int64), ("n", C.c_int64), ("history_start", C.c_int64), ("chunk_start", C.c_int64),
+                ("encoder_len", C.c_int64), ("eos", C.c_int64), ("it", C.c_int64), ("max_iters", C.c_int64),
+                ("rec_chunk_start", C.c_void_p), ("rec_attn", C.c_void_p), ("rec_len", C.c_void_p), ("rec_cap", C.c_int64),
+                ("n_rec", C.c_int64), ("rec_stride", C.c_int32), ("chunk_size", C.c_int32), ("max_positions", C.c_int32),
+                ("stall_patience", C.c_int32), ("rep_n", C.c_int32), ("skip_frames", C.c_int32), ("shift_frames", C.c_int32),
+                ("del_prct", C.c_float), ("thresh_prct", C.c_double), ("highest_progress", C.c_double),
+                ("num_no_improve", C.c_int32), ("window_time", C.c_int32), ("flags", C.c_int32), ("gen_pinned", C.c_int32)]
+
+
+UNALIGNED_WINDOW_MOVED, UNALIGNED_PREFIX_REWRITTEN, UNALIGNED_DONE, UNALIGNED_GROW, UNALIGNED_ALONE = 1, 2, 4, 8, 16
 
 # name -> (restype, argtypes); must list every symbol include/tal_asrd.h declares
 # (tests/test_abi.py checks header <-> table <-> library).
@@ -102,6 +116,12 @@ SIGNATURES = {
     "tal_greedy_step_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "tal_greedy_step_fwd": (_i, [C.POINTER(GreedyCtx), _i64, _i64, _i, _p]),
     "tal_greedy_step_poll": (_i, [C.POINTER(GreedyCtx), _i]),
+    "tal_greedy_group_ok": (_i, [C.POINTER(GreedyCtx), _i64, _i64]),
+    "tal_window_vt_fwd": (_i, [_p, _i, _i64, _i, _i, _i64, _p, _p]),
+    "tal_greedy_set_window": (_i, [C.POINTER(GreedyCtx), _i64, _p]),
+    "tal_greedy_step_multi_fwd": (_i, [C.POINTER(C.POINTER(GreedyCtx)), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i, _p]),
+    "tal_unaligned_consume": (_i, [C.POINTER(UnalignedState), _i64, _p, _i]),
+    "tal_unaligned_group_run": (_i, [C.POINTER(C.POINTER(UnalignedState)), C.POINTER(C.POINTER(GreedyCtx)), C.POINTER(C.c_int64), _i, _i, _p]),
     "tal_ngram_repeat_count": (_i64, [_p, _i64, _i]),
     "tal_greedy_pick_fwd": (_i, [_p, _i, _p, _i, _i64, _i, _p, _p, _p]),
     "tal_log_softmax_rows": (_i, [_p, _i64, _i, _p, _p]),

@@ -253,6 +253,14 @@ struct AttnArgs {
     int U, S, H, prob_row0;
 };
 
+// several independent problems in one launch (the decode steps of several sessions): argument structs by value
+constexpr int TAL_GROUP_MAX = 8;
+template <typename T>
+struct ArgPack {
+    T a[TAL_GROUP_MAX];
+    int n;
+};
+
 bool skinny_gemm_applicable(const SkinnyArgs& g);
 int launch_skinny_gemm(const SkinnyArgs& g, int mode, hipStream_t s);
 bool attn_small_applicable(int U, int S, int hd);
@@ -261,5 +269,10 @@ size_t attn_split_scratch_floats(int B, int U, int S, int H, int hd);
 int attn_split_tickets(int B, int U, int H);
 int launch_attn_split(const AttnArgs& g, int B, int hd, float* scratch, unsigned* tickets, hipStream_t s);
 int launch_head_average(const float* probs, float* avg, int B, int H, int U, int S, hipStream_t s);
+// the multi forms: G <= TAL_GROUP_MAX problems (one batch item each for the attention kernels) in one launch, every problem's
+// results bit-identical to its own launch
+int launch_skinny_gemm_multi(const SkinnyArgs* g, int G, int mode, hipStream_t s);
+int launch_attn_small_multi(const AttnArgs* g, int G, int hd, hipStream_t s);
+int launch_attn_split_multi(const AttnArgs* g, float* const* scratch, unsigned* const* tickets, int G, int hd, hipStream_t s);
 
 }  // namespace tal

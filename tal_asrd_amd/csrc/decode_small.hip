@@ -21,17 +21,27 @@ namespace tal {
 // One workgroup = 16 output columns x up to 32 rows (blockIdx.y picks the 32-row half).  NW waves split K; a wave's whole
 // K slice (<= 8 chunks of 16 k when K <= 128 NW) is requested before its first MFMA, so a launch costs ONE operand round
 // trip -- a CU pulls only ~25-60 GB/s, and the round trip, not the arithmetic, is what a launch this small pays for.
+// The kernels of this file exist in two launch forms that share one body each: the ordinary one (one problem per launch) and
+// the MULTI form, which runs the same body for up to TAL_GROUP_MAX independent problems -- the decode steps of several
+// sessions (System.transcribe_unaligned_many) -- in ONE launch: the argument structs travel by value in the kernel argument
+// segment, a grid dimension picks the problem, a block outside its problem's own grid returns.  A problem's outputs are the
+// same instructions on the same operands in both forms, i.e. bit-identical.  `Blk` carries the block coordinates (and the
+// grid extents the body derives indices from) of the problem's OWN grid.
+struct Blk {
+    unsigned x, y, z, gx, gy;
+};
+
 template <int MODE, int MT, int NW>
-__global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(const SkinnyArgs g) {
+__device__ __forceinline__ void skinny_gemm_body(const SkinnyArgs& g, const Blk blk) {
     __shared__ __attribute__((aligned(16))) float part[NW * MT * 256];   // [wave][m tile][row 16][col 16]
-    const int n0 = blockIdx.x * 16;
-    const int m0 = blockIdx.y * 32;
+    const int n0 = blk.x * 16;
+    const int m0 = blk.y * 32;
     const int lane = threadIdx.x & 63, w = wave_id();
     const int r16 = lane & 15, kq = lane >> 4;
     const int KS = g.ksplit > 1 ? g.ksplit : 1;
     const int Kw = g.K / (NW * KS);                // this wave's share of K
     const int nchunk = Kw >> 4;                    // 16 k per chunk = 4 MFMAs
-    const int kofs = ((int)blockIdx.z * NW + w) * Kw;
+    const int kofs = ((int)blk.z * NW + w) * Kw;
     const float* wp = g.W + (int64_t)(n0 + r16) * g.ldw + kofs + 4 * kq;
     const float* ap[MT];
 #pragma unroll
@@ -100,8 +110,8 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(const SkinnyArgs g
     }
     if (KS > 1) {
         __shared__ unsigned ticket;
-        const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x, ntile = gridDim.x * gridDim.y;
-        float* mine = g.sk_part + ((size_t)blockIdx.z * ntile + tile) * 512 + t * 4;
+        const unsigned tile = blk.y * blk.gx + blk.x, ntile = blk.gx * blk.gy;
+        float* mine = g.sk_part + ((size_t)blk.z * ntile + tile) * 512 + t * 4;
         if (t < MT * 64) { st_agent(mine, v.x); st_agent(mine + 1, v.y); st_agent(mine + 2, v.z); st_agent(mine + 3, v.w); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -136,6 +146,20 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(const SkinnyArgs g
     *reinterpret_cast<f32x4*>(g.Y + (int64_t)m * g.ldy + col) = v;
 }
 
+template <int MODE, int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(const SkinnyArgs g) {
+    skinny_gemm_body<MODE, MT, NW>(g, Blk{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y});
+}
+
+// multi form: grid (N / 16, max row tiles, problem x K slice); all problems share N, K and the K split (the weights' shape)
+template <int MODE, int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_gemm_multi_kernel(const ArgPack<SkinnyArgs> p, int KS) {
+    const SkinnyArgs& g = p.a[blockIdx.z / KS];
+    const unsigned gy = (unsigned)((g.M + 31) / 32);
+    if (blockIdx.y >= gy) return;
+    skinny_gemm_body<MODE, MT, NW>(g, Blk{blockIdx.x, blockIdx.y, blockIdx.z % KS, gridDim.x, gy});
+}
+
 bool skinny_gemm_applicable(const SkinnyArgs& g) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (g.ksplit > 1 && (!g.sk_part || !g.sk_tickets || g.K % (64 * g.ksplit) != 0)) return false;
@@ -160,6 +184,51 @@ static void launch_skinny_nw(const SkinnyArgs& g, hipStream_t s) {
     else launch_skinny_mt<MODE, 4>(g, s);
 }
 
+template <int MODE, int NW>
+static void launch_skinny_multi_mt(const ArgPack<SkinnyArgs>& p, int mmax, int KS, hipStream_t s) {
+    const dim3 grid((unsigned)(p.a[0].N / 16), (unsigned)((mmax + 31) / 32), (unsigned)(KS * p.n));
+    // (one M tile per workgroup only when EVERY problem has at most 16 rows; a problem of <= 16 rows on the two-tile form computes
+    //  the same chains for its rows and drops the clamped duplicates)
+    if (mmax <= 16) hipLaunchKernelGGL((skinny_gemm_multi_kernel<MODE, 1, NW>), grid, dim3(64 * NW), 0, s, p, KS);
+    else hipLaunchKernelGGL((skinny_gemm_multi_kernel<MODE, 2, NW>), grid, dim3(64 * NW), 0, s, p, KS);
+}
+
+template <int MODE>
+static void launch_skinny_multi_nw(const ArgPack<SkinnyArgs>& p, int mmax, int KS, hipStream_t s) {
+    const int k = p.a[0].K / KS;
+    if (k >= 2048 && k % 256 == 0) launch_skinny_multi_mt<MODE, 16>(p, mmax, KS, s);
+    else if (k >= 1024 && k % 128 == 0) launch_skinny_multi_mt<MODE, 8>(p, mmax, KS, s);
+    else launch_skinny_multi_mt<MODE, 4>(p, mmax, KS, s);
+}
+
+// G problems with the same W shape (N, K, ldw) and K split in one launch (see Blk)
+int launch_skinny_gemm_multi(const SkinnyArgs* g, int G, int mode, hipStream_t s) {
+    TAL_CHECK_ARG(g && G >= 1 && G <= TAL_GROUP_MAX, "skinny gemm (multi): %d problems", G);
+    TAL_CHECK_ARG(mode >= 0 && mode <= 3, "skinny gemm (multi): mode %d", mode);
+    ArgPack<SkinnyArgs> p;
+    p.n = G;
+    int mmax = 0;
+    double work = 0.0;
+    const int KS = g[0].ksplit > 1 ? g[0].ksplit : 1;
+    for (int i = 0; i < G; ++i) {
+        TAL_CHECK_ARG(skinny_gemm_applicable(g[i]) && (mode != 2 || g[i].res), "skinny gemm (multi): problem %d (M=%d N=%d K=%d) not supported", i, g[i].M, g[i].N, g[i].K);
+        TAL_CHECK_ARG(g[i].N == g[0].N && g[i].K == g[0].K && (g[i].ksplit > 1 ? g[i].ksplit : 1) == KS,
+                      "skinny gemm (multi): problems must share N, K and the K split");
+        p.a[i] = g[i];
+        mmax = g[i].M > mmax ? g[i].M : mmax;
+        work += 2.0 * g[i].M * (double)g[i].N * g[i].K;
+    }
+    ProfScope prof(PROF_GEMM, work, s);
+    switch (mode) {
+        case 0: launch_skinny_multi_nw<0>(p, mmax, KS, s); break;
+        case 1: launch_skinny_multi_nw<1>(p, mmax, KS, s); break;
+        case 2: launch_skinny_multi_nw<2>(p, mmax, KS, s); break;
+        default: launch_skinny_multi_nw<3>(p, mmax, KS, s); break;
+    }
+    TAL_CHECK_LAUNCH("skinny gemm (multi)");
+    return TAL_OK;
+}
+
 int launch_skinny_gemm(const SkinnyArgs& g, int mode, hipStream_t s) {
     TAL_CHECK_ARG(skinny_gemm_applicable(g), "skinny gemm: shape M=%d N=%d K=%d not supported", g.M, g.N, g.K);
     TAL_CHECK_ARG(mode >= 0 && mode <= 3 && (mode != 2 || g.res), "skinny gemm: mode %d", mode);
@@ -180,9 +249,9 @@ int launch_skinny_gemm(const SkinnyArgs& g, int mode, hipStream_t s) {
 // steps in flight while the current 8 are multiplied.
 constexpr int ATT_NW = 8;
 template <int HD>
-__global__ __launch_bounds__(64 * ATT_NW) void attn_small_kernel(const AttnArgs g) {
+__device__ __forceinline__ void attn_small_body(const AttnArgs& g, const Blk blk) {
     extern __shared__ __attribute__((aligned(16))) float sc[];   // [16][SP] scores -> probabilities
-    const int u0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+    const int u0 = blk.x * 16, h = blk.y, b = blk.z;
     const int lane = threadIdx.x & 63, w = wave_id();
     const int r16 = lane & 15, kq = lane >> 4;
     const int U = g.U, S = g.S;
@@ -320,6 +389,20 @@ __global__ __launch_bounds__(64 * ATT_NW) void attn_small_kernel(const AttnArgs 
     }
 }
 
+template <int HD>
+__global__ __launch_bounds__(64 * ATT_NW) void attn_small_kernel(const AttnArgs g) {
+    attn_small_body<HD>(g, Blk{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y});
+}
+
+// multi form: grid (max query blocks, heads, problem); every problem is one batch item
+template <int HD>
+__global__ __launch_bounds__(64 * ATT_NW) void attn_small_multi_kernel(const ArgPack<AttnArgs> p) {
+    const AttnArgs& g = p.a[blockIdx.z];
+    const unsigned gx = (unsigned)((g.U + 15) / 16);
+    if (blockIdx.x >= gx) return;
+    attn_small_body<HD>(g, Blk{blockIdx.x, blockIdx.y, 0u, gx, gridDim.y});
+}
+
 bool attn_small_applicable(int U, int S, int hd) { return (hd == 128 || hd == 64 || hd == 32 || hd == 16) && S >= 1 && S <= 960 && U >= 1; }
 
 int launch_attn_small(const AttnArgs& g, int B, int hd, hipStream_t s) {
@@ -339,6 +422,33 @@ int launch_attn_small(const AttnArgs& g, int B, int hd, hipStream_t s) {
     return TAL_OK;
 }
 
+int launch_attn_small_multi(const AttnArgs* g, int G, int hd, hipStream_t s) {
+    TAL_CHECK_ARG(g && G >= 1 && G <= TAL_GROUP_MAX, "attn_small (multi): %d problems", G);
+    ArgPack<AttnArgs> p;
+    p.n = G;
+    int umax = 0, smax = 0;
+    double work = 0.0;
+    for (int i = 0; i < G; ++i) {
+        TAL_CHECK_ARG(attn_small_applicable(g[i].U, g[i].S, hd) && g[i].H == g[0].H, "attn_small (multi): problem %d (U=%d S=%d hd=%d) not supported", i, g[i].U, g[i].S, hd);
+        TAL_CHECK_ARG(g[i].ldq % 4 == 0 && g[i].ldk % 4 == 0 && g[i].ldvt % 4 == 0 && g[i].ldvt >= g[i].S, "attn_small (multi): row pitches must be multiples of 4");
+        p.a[i] = g[i];
+        umax = g[i].U > umax ? g[i].U : umax;
+        smax = g[i].S > smax ? g[i].S : smax;
+        work += (double)g[i].H * g[i].U * g[i].S * 8.0;
+    }
+    const size_t lds = (size_t)16 * (((smax + 15) & ~15) + 4) * sizeof(float);
+    const dim3 grid((unsigned)((umax + 15) / 16), (unsigned)g[0].H, (unsigned)G);
+    ProfScope prof(PROF_OTHER, work, s);
+    switch (hd) {
+        case 128: hipLaunchKernelGGL((attn_small_multi_kernel<128>), grid, dim3(64 * ATT_NW), lds, s, p); break;
+        case 64: hipLaunchKernelGGL((attn_small_multi_kernel<64>), grid, dim3(64 * ATT_NW), lds, s, p); break;
+        case 32: hipLaunchKernelGGL((attn_small_multi_kernel<32>), grid, dim3(64 * ATT_NW), lds, s, p); break;
+        default: hipLaunchKernelGGL((attn_small_multi_kernel<16>), grid, dim3(64 * ATT_NW), lds, s, p); break;
+    }
+    TAL_CHECK_LAUNCH("attn_small (multi)");
+    return TAL_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The same attention with the KEY axis cut over workgroups (cross-attention of a decode step: 357 keys x 512 features of
 // K and V^T are 1.4 MB, and the 8 workgroups of the kernel above each pull 367 KB through one CU at 25-60 GB/s).
@@ -353,13 +463,13 @@ __host__ __device__ static inline int split_cb(int S) { const int nblk = (S + 15
 __host__ __device__ static inline size_t split_record_floats(int hd, int cb) { return (size_t)16 * hd + 32 + (size_t)16 * 16 * cb; }
 
 template <int HD>
-__global__ __launch_bounds__(256) void attn_split_kernel(const AttnArgs g, int CB, int NCH, float* __restrict__ scratch,
-                                                        unsigned* __restrict__ tickets) {
+__device__ __forceinline__ void attn_split_body(const AttnArgs& g, int CB, int NCH, float* __restrict__ scratch,
+                                                unsigned* __restrict__ tickets, const Blk blk) {
     extern __shared__ __attribute__((aligned(16))) float sc[];   // [16][SPc] chunk scores -> exp(s - m_c)
     __shared__ float mrow[16], lrow[16], wsh[16 * SPLIT_NCH], Lsh[16];
     __shared__ unsigned ticket;
-    const int u0 = blockIdx.x * 16, h = blockIdx.y;
-    const int b = blockIdx.z / NCH, ch = blockIdx.z % NCH;
+    const int u0 = blk.x * 16, h = blk.y;
+    const int b = blk.z / NCH, ch = blk.z % NCH;
     const int lane = threadIdx.x & 63, w = wave_id();
     const int r16 = lane & 15, kq = lane >> 4;
     const int U = g.U, S = g.S;
@@ -368,7 +478,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const AttnArgs g, int C
     const int Sc = CB * 16, SPc = Sc + 4;
     constexpr int NC = HD / 16;
     const size_t rec_f = split_record_floats(HD, CB);
-    const size_t group = ((size_t)b * gridDim.y + h) * gridDim.x + blockIdx.x;      // (item, head, row block)
+    const size_t group = ((size_t)b * blk.gy + h) * blk.gx + blk.x;      // (item, head, row block)
     float* rec = scratch + (group * NCH + ch) * rec_f;
     // V^T fragments of this chunk for the wave's feature blocks (NC / 4 of them): requested first
     constexpr int FB = (NC + 3) / 4;
@@ -562,6 +672,28 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const AttnArgs g, int C
     }
 }
 
+template <int HD>
+__global__ __launch_bounds__(256) void attn_split_kernel(const AttnArgs g, int CB, int NCH, float* __restrict__ scratch,
+                                                        unsigned* __restrict__ tickets) {
+    attn_split_body<HD>(g, CB, NCH, scratch, tickets, Blk{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y});
+}
+
+// multi form: grid (max query blocks, heads, problem x SPLIT_NCH chunk slots); every problem is one batch item with its own
+// scratch and tickets; its key-chunk geometry (CB, NCH) follows from its S as in launch_attn_split
+struct AttnSplitAux {
+    float* scratch[TAL_GROUP_MAX];
+    unsigned* tickets[TAL_GROUP_MAX];
+};
+template <int HD>
+__global__ __launch_bounds__(256) void attn_split_multi_kernel(const ArgPack<AttnArgs> p, const AttnSplitAux aux) {
+    const unsigned i = blockIdx.z / SPLIT_NCH, ch = blockIdx.z % SPLIT_NCH;
+    const AttnArgs& g = p.a[i];
+    const int CB = split_cb(g.S), nblk = (g.S + 15) / 16, NCH = (nblk + CB - 1) / CB;
+    const unsigned gx = (unsigned)((g.U + 15) / 16);
+    if (blockIdx.x >= gx || (int)ch >= NCH) return;
+    attn_split_body<HD>(g, CB, NCH, aux.scratch[i], aux.tickets[i], Blk{blockIdx.x, blockIdx.y, ch, gx, gridDim.y});
+}
+
 size_t attn_split_scratch_floats(int B, int U, int S, int H, int hd) {
     return (size_t)B * H * ((U + 15) / 16) * SPLIT_NCH * split_record_floats(hd, split_cb(S));
 }
@@ -584,6 +716,37 @@ int launch_attn_split(const AttnArgs& g, int B, int hd, float* scratch, unsigned
         default: hipLaunchKernelGGL((attn_split_kernel<16>), grid, dim3(256), lds, s, g, CB, NCH, scratch, tickets); break;
     }
     TAL_CHECK_LAUNCH("attn_split");
+    return TAL_OK;
+}
+
+int launch_attn_split_multi(const AttnArgs* g, float* const* scratch, unsigned* const* tickets, int G, int hd, hipStream_t s) {
+    TAL_CHECK_ARG(g && scratch && tickets && G >= 1 && G <= TAL_GROUP_MAX, "attn_split (multi): %d problems", G);
+    ArgPack<AttnArgs> p;
+    AttnSplitAux aux;
+    p.n = G;
+    int umax = 0, cbmax = 0;
+    double work = 0.0;
+    for (int i = 0; i < G; ++i) {
+        TAL_CHECK_ARG(attn_small_applicable(g[i].U, g[i].S, hd) && scratch[i] && tickets[i] && g[i].H == g[0].H, "attn_split (multi): problem %d (U=%d S=%d hd=%d) not supported", i, g[i].U, g[i].S, hd);
+        TAL_CHECK_ARG(g[i].ldq % 4 == 0 && g[i].ldk % 4 == 0 && g[i].ldvt % 4 == 0 && g[i].ldvt >= g[i].S, "attn_split (multi): row pitches must be multiples of 4");
+        p.a[i] = g[i];
+        aux.scratch[i] = scratch[i];
+        aux.tickets[i] = tickets[i];
+        umax = g[i].U > umax ? g[i].U : umax;
+        const int cb = split_cb(g[i].S);
+        cbmax = cb > cbmax ? cb : cbmax;
+        work += (double)g[i].H * g[i].U * g[i].S * 8.0;
+    }
+    const size_t lds = (size_t)16 * (cbmax * 16 + 4) * sizeof(float);
+    const dim3 grid((unsigned)((umax + 15) / 16), (unsigned)g[0].H, (unsigned)(G * SPLIT_NCH));
+    ProfScope prof(PROF_OTHER, work, s);
+    switch (hd) {
+        case 128: hipLaunchKernelGGL((attn_split_multi_kernel<128>), grid, dim3(256), lds, s, p, aux); break;
+        case 64: hipLaunchKernelGGL((attn_split_multi_kernel<64>), grid, dim3(256), lds, s, p, aux); break;
+        case 32: hipLaunchKernelGGL((attn_split_multi_kernel<32>), grid, dim3(256), lds, s, p, aux); break;
+        default: hipLaunchKernelGGL((attn_split_multi_kernel<16>), grid, dim3(256), lds, s, p, aux); break;
+    }
+    TAL_CHECK_LAUNCH("attn_split (multi)");
     return TAL_OK;
 }
 

@@ -18,11 +18,10 @@ namespace tal {
 static inline int64_t pad4(int64_t n) { return (n + 3) & ~(int64_t)3; }
 
 // ---- token embedding: emb[tok] -> (proj) -> + pe[u] ---------------------------------------
-__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ emb,
-                                                   const float* __restrict__ proj, const float* __restrict__ pe,
-                                                   float* __restrict__ out, int U, int V, int E0, int D) {
+__device__ __forceinline__ void embed_body(const int64_t* __restrict__ tokens, const float* __restrict__ emb,
+                                           const float* __restrict__ proj, const float* __restrict__ pe,
+                                           float* __restrict__ out, int U, int V, int E0, int D, int row) {
     extern __shared__ float e[];
-    const int row = blockIdx.x;
     const int u = row % U;
     int64_t tok = tokens[row];
     tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);  // validated on the host side; never trusted for addressing
@@ -51,6 +50,25 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
         }
         out[(int64_t)row * D + d] = acc + pe[(int64_t)u * D + d];
     }
+}
+
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ emb,
+                                                   const float* __restrict__ proj, const float* __restrict__ pe,
+                                                   float* __restrict__ out, int U, int V, int E0, int D) {
+    embed_body(tokens, emb, proj, pe, out, U, V, E0, D, blockIdx.x);
+}
+
+// several prefixes in one launch (the merged decode step): blockIdx.y picks the prefix, rows past its length return
+struct EmbedMulti {
+    const int64_t* tokens[TAL_GROUP_MAX];
+    float* out[TAL_GROUP_MAX];
+    int U[TAL_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void embed_multi_kernel(const EmbedMulti m, const float* __restrict__ emb, const float* __restrict__ proj,
+                                                         const float* __restrict__ pe, int V, int E0, int D) {
+    const int i = blockIdx.y;
+    if ((int)blockIdx.x >= m.U[i]) return;
+    embed_body(m.tokens[i], emb, proj, pe, m.out[i], m.U[i], V, E0, D, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void add_positional_kernel(const float* __restrict__ x, const float* __restrict__ pe,
@@ -289,11 +307,28 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restric
 // layer- / head-averaged attention row.  arg max of log_softmax(x) is taken as arg max of x (the same index unless two
 // logits lie within an ulp of each other).
 constexpr int LMP_ROWS = 128;
-__global__ __launch_bounds__(256) void lm_pick_kernel(const float* __restrict__ h, const float* __restrict__ proj_t, int E, int K0,
-                                                     const float* __restrict__ emb, int V, const float* __restrict__ attn,
-                                                     int n_layers, int64_t layer_stride, int H, int64_t head_stride, int S,
-                                                     float* __restrict__ partial, unsigned* __restrict__ ticket_word,
-                                                     float* __restrict__ out, int64_t* __restrict__ token_out, unsigned host_seq) {
+struct LmPickArgs {
+    const float* h;          // last prefix row of the decoder output [E]
+    const float* attn;       // attention rows: attn[l * layer_stride + hh * head_stride + i]
+    int64_t layer_stride, head_stride;
+    int S;
+    float* partial;          // 2 floats per workgroup
+    unsigned* ticket_word;
+    float* out;              // {token, row [S] (, sequence word)}
+    int64_t* token_out;
+    unsigned host_seq;
+};
+__device__ __forceinline__ void lm_pick_body(const LmPickArgs& q, const float* __restrict__ proj_t, int E, int K0,
+                                             const float* __restrict__ emb, int V, int n_layers, int H, const unsigned bx, const unsigned gx) {
+    const float* __restrict__ h = q.h;
+    const float* __restrict__ attn = q.attn;
+    const int64_t layer_stride = q.layer_stride, head_stride = q.head_stride;
+    const int S = q.S;
+    float* __restrict__ partial = q.partial;
+    unsigned* __restrict__ ticket_word = q.ticket_word;
+    float* __restrict__ out = q.out;
+    int64_t* __restrict__ token_out = q.token_out;
+    const unsigned host_seq = q.host_seq;
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [E] h | [K0] t | [128] logits
     float* hs = sm;
     float* ts = sm + E;
@@ -315,7 +350,7 @@ __global__ __launch_bounds__(256) void lm_pick_kernel(const float* __restrict__ 
                 pv[ps][c] = *reinterpret_cast<const f32x4*>(proj_t + (int64_t)(grp + 16 * ps) * 512 + (l16 + 16 * c) * 4);
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
-            const int v = blockIdx.x * LMP_ROWS + grp + 16 * ps;
+            const int v = bx * LMP_ROWS + grp + 16 * ps;
             ev[ps] = *reinterpret_cast<const f32x4*>(emb + (int64_t)(v < V ? v : V - 1) * 64 + l16 * 4);
         }
     }
@@ -374,12 +409,12 @@ __global__ __launch_bounds__(256) void lm_pick_kernel(const float* __restrict__ 
         if (l16 == 0)
 #pragma unroll
             for (int ps = 0; ps < 8; ++ps) {
-                const int v = blockIdx.x * LMP_ROWS + grp + 16 * ps;
+                const int v = bx * LMP_ROWS + grp + 16 * ps;
                 lg[grp + 16 * ps] = v < V ? a[ps] : -INFINITY;
             }
     } else {   // two threads per row, half of K0 each (K0 % 8 == 0)
         const int r = tid >> 1, half = tid & 1, Kh = K0 >> 1;
-        const int v = blockIdx.x * LMP_ROWS + r;
+        const int v = bx * LMP_ROWS + r;
         float a = 0.f;
         if (v < V) {
             const float* er = emb + (int64_t)v * K0 + half * Kh;
@@ -405,14 +440,14 @@ __global__ __launch_bounds__(256) void lm_pick_kernel(const float* __restrict__ 
             if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
         }
         if (lane == 0) {
-            st_agent(&partial[2 * blockIdx.x], best);
-            st_agent(&partial[2 * blockIdx.x + 1], __int_as_float(blockIdx.x * LMP_ROWS + bi));
+            st_agent(&partial[2 * bx], best);
+            st_agent(&partial[2 * bx + 1], __int_as_float(bx * LMP_ROWS + bi));
         }
     }
     __syncthreads();
     if (tid == 0) ticket = take_ticket(ticket_word);
     __syncthreads();
-    if (ticket != gridDim.x - 1) return;
+    if (ticket != gx - 1) return;
     if (tid == 0) reset_ticket(ticket_word);
     // attention row of the new token: mean over layers of (mean over heads), summed in layer / head order.
     // (fixed-trip loops with every load issued first: a run-time-bounded loop of loads is a serial chain of round trips)
@@ -458,15 +493,15 @@ __global__ __launch_bounds__(256) void lm_pick_kernel(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < PJ; ++k) {
             const int j = lane + 64 * k;
-            pvv[k] = j < (int)gridDim.x ? ld_agent(partial + 2 * j) : -INFINITY;
-            pii[k] = j < (int)gridDim.x ? ld_agent(partial + 2 * j + 1) : __int_as_float(0x7fffffff);
+            pvv[k] = j < (int)gx ? ld_agent(partial + 2 * j) : -INFINITY;
+            pii[k] = j < (int)gx ? ld_agent(partial + 2 * j + 1) : __int_as_float(0x7fffffff);
         }
 #pragma unroll
         for (int k = 0; k < PJ; ++k) {                    // ascending workgroup = ascending index: lowest index wins ties
             const int idx = __float_as_int(pii[k]);
             if (pvv[k] > best || (pvv[k] == best && idx < bi)) { best = pvv[k]; bi = idx; }
         }
-        for (int j = lane + 64 * PJ; j < (int)gridDim.x; j += 64) {
+        for (int j = lane + 64 * PJ; j < (int)gx; j += 64) {
             const float v = ld_agent(partial + 2 * j);
             const int idx = __float_as_int(ld_agent(partial + 2 * j + 1));
             if (v > best || (v == best && idx < bi)) { best = v; bi = idx; }
@@ -490,6 +525,16 @@ __global__ __launch_bounds__(256) void lm_pick_kernel(const float* __restrict__ 
         __syncthreads();
         if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(out + 1 + S), host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+__global__ __launch_bounds__(256) void lm_pick_kernel(const LmPickArgs q, const float* __restrict__ proj_t, int E, int K0,
+                                                     const float* __restrict__ emb, int V, int n_layers, int H) {
+    lm_pick_body(q, proj_t, E, K0, emb, V, n_layers, H, blockIdx.x, gridDim.x);
+}
+// the picks of several sessions in one launch: blockIdx.y = session (own hidden row, attention rows, partials, ticket, result)
+__global__ __launch_bounds__(256) void lm_pick_multi_kernel(const ArgPack<LmPickArgs> p, const float* __restrict__ proj_t, int E, int K0,
+                                                           const float* __restrict__ emb, int V, int n_layers, int H) {
+    lm_pick_body(p.a[blockIdx.y], proj_t, E, K0, emb, V, n_layers, H, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, int64_t M, int N,
@@ -684,7 +729,7 @@ static size_t decode_scratch_floats(int U, int S, int E, int H) {
 static int decoder_layer_small(const tal_decoder_layer_w* w, const float* tgt, int B, int U, int S, int E, int H, int FF,
                                const float* tgt_mask, const uint8_t* mem_kpm, const float* ck, const float* cvt, float* out,
                                float* xattn_avg, float* probs_last, const LayerWs& ws, hipStream_t s,
-                               const DecodeScratch* sk = nullptr) {
+                               const DecodeScratch* sk = nullptr, int64_t k_pitch = 0) {
     const int M = B * U, hd = E / H;
     const int64_t U4 = pad4(U), S4 = pad4(S);
     const float qscale = 1.0f / sqrtf((float)hd);
@@ -714,7 +759,7 @@ static int decoder_layer_small(const tal_decoder_layer_w* w, const float* tgt, i
     if (rc) return rc;
     AttnArgs c = {};
     c.q = qc; c.ldq = E; c.q_bs = (int64_t)U * E;
-    c.k = ck; c.ldk = E; c.k_bs = (int64_t)S * E;
+    c.k = ck; c.ldk = k_pitch ? k_pitch : E; c.k_bs = (int64_t)S * c.ldk;      // (k_pitch: the window is a view of an episode-wide K | V table)
     c.vt = cvt; c.ldvt = S4; c.vt_bs = (int64_t)E * S4;
     c.vbias = w->ca_in_b + 2 * E;
     c.mask = nullptr; c.kpm = mem_kpm;
@@ -745,6 +790,96 @@ static int decoder_layer_small(const tal_decoder_layer_w* w, const float* tgt, i
         f2.sk_tickets = sk->tickets + 64;
     }
     return launch_skinny_gemm(f2, 2, s);
+}
+
+// The same layer for the decode steps of G sessions at once (batch 1 each, own prefix length / window / buffers): every launch of
+// decoder_layer_small becomes ONE launch over all sessions (the multi forms of csrc/decode_small.hip), so a step of G sessions
+// costs the 8 dependent launches of one.  A session's rows go through the same kernel bodies with the same arguments as in
+// decoder_layer_small: bit-identical.  All sessions must take the SAME kernel forms there (key-split cross-attention, FFN-2 cut
+// along K): greedy_group_ok checks it.
+struct SessionLayerIo {
+    const float* tgt;        // [U, E]
+    int U, S;
+    const uint8_t* mem_kpm;
+    const float* ck;
+    int64_t k_pitch;         // floats between the window's K rows (E, or the pitch of the episode-wide K | V table)
+    const float* cvt;
+    float* out;
+    float* probs_last;       // [H][S]
+    LayerWs ws;
+    DecodeScratch sk;
+};
+static int decoder_layer_small_multi(const tal_decoder_layer_w* w, const SessionLayerIo* io, int G, int E, int H, int FF, hipStream_t s) {
+    const int hd = E / H;
+    const float qscale = 1.0f / sqrtf((float)hd);
+    SkinnyArgs g[TAL_GROUP_MAX];
+    AttnArgs a[TAL_GROUP_MAX];
+    float* scr[TAL_GROUP_MAX];
+    unsigned* tik[TAL_GROUP_MAX];
+    for (int i = 0; i < G; ++i) {
+        const SessionLayerIo& x = io[i];
+        const int64_t U4 = pad4(x.U);
+        g[i] = skinny(x.tgt, E, w->sa_in_w, w->sa_in_b, nullptr, x.ws.mha.q, 3 * E, x.U, 3 * E, E, qscale);
+        g[i].scale_cols = E;
+        g[i].Yt = x.ws.mha.vt; g[i].vt_begin = 2 * E; g[i].U = x.U; g[i].ldt = U4; g[i].vt_bs = (int64_t)E * U4;
+    }
+    int rc = launch_skinny_gemm_multi(g, G, 3, s);
+    if (rc) return rc;
+    for (int i = 0; i < G; ++i) {
+        const SessionLayerIo& x = io[i];
+        const int64_t U4 = pad4(x.U);
+        float* qkv = x.ws.mha.q;
+        a[i] = AttnArgs{};
+        a[i].q = qkv; a[i].ldq = 3 * E; a[i].q_bs = (int64_t)x.U * 3 * E;
+        a[i].k = qkv + E; a[i].ldk = 3 * E; a[i].k_bs = (int64_t)x.U * 3 * E;
+        a[i].vt = x.ws.mha.vt; a[i].ldvt = U4; a[i].vt_bs = (int64_t)E * U4;
+        a[i].ctx = x.ws.mha.ctx; a[i].ldc = E; a[i].c_bs = (int64_t)x.U * E;
+        a[i].U = x.U; a[i].S = x.U; a[i].H = H;
+    }
+    rc = launch_attn_small_multi(a, G, hd, s);
+    if (rc) return rc;
+    for (int i = 0; i < G; ++i) g[i] = skinny(io[i].ws.mha.ctx, E, w->sa_out_w, w->sa_out_b, io[i].tgt, io[i].ws.x1, E, io[i].U, E, E, w->resweight);
+    rc = launch_skinny_gemm_multi(g, G, 2, s);
+    if (rc) return rc;
+    for (int i = 0; i < G; ++i) g[i] = skinny(io[i].ws.x1, E, w->ca_in_w, w->ca_in_b, nullptr, io[i].ws.mha.q, E, io[i].U, E, E, qscale);
+    rc = launch_skinny_gemm_multi(g, G, 3, s);
+    if (rc) return rc;
+    for (int i = 0; i < G; ++i) {
+        const SessionLayerIo& x = io[i];
+        const int64_t S4 = pad4(x.S);
+        a[i] = AttnArgs{};
+        a[i].q = x.ws.mha.q; a[i].ldq = E; a[i].q_bs = (int64_t)x.U * E;
+        a[i].k = x.ck; a[i].ldk = x.k_pitch; a[i].k_bs = (int64_t)x.S * x.k_pitch;
+        a[i].vt = x.cvt; a[i].ldvt = S4; a[i].vt_bs = (int64_t)E * S4;
+        a[i].vbias = w->ca_in_b + 2 * E;
+        a[i].kpm = x.mem_kpm;
+        a[i].ctx = x.ws.mha.ctx; a[i].ldc = E; a[i].c_bs = (int64_t)x.U * E;
+        a[i].U = x.U; a[i].S = x.S; a[i].H = H;
+        a[i].probs = x.probs_last; a[i].prob_row0 = x.U - 1;
+        scr[i] = x.sk.part;
+        tik[i] = x.sk.tickets;
+    }
+    rc = launch_attn_split_multi(a, scr, tik, G, hd, s);
+    if (rc) return rc;
+    for (int i = 0; i < G; ++i) g[i] = skinny(io[i].ws.mha.ctx, E, w->ca_out_w, w->ca_out_b, io[i].ws.x1, io[i].ws.x2, E, io[i].U, E, E, w->resweight_src);
+    rc = launch_skinny_gemm_multi(g, G, 2, s);
+    if (rc) return rc;
+    for (int i = 0; i < G; ++i) g[i] = skinny(io[i].ws.x2, E, w->lin1_w, w->lin1_b, nullptr, io[i].ws.ff, FF, io[i].U, FF, E, 0.f);
+    rc = launch_skinny_gemm_multi(g, G, 1, s);
+    if (rc) return rc;
+    for (int i = 0; i < G; ++i) {
+        g[i] = skinny(io[i].ws.ff, FF, w->lin2_w, w->lin2_b, io[i].ws.x2, io[i].out, E, io[i].U, E, FF, w->resweight);
+        g[i].ksplit = 4;
+        g[i].sk_part = io[i].sk.part;
+        g[i].sk_tickets = io[i].sk.tickets + 64;
+    }
+    return launch_skinny_gemm_multi(g, G, 2, s);
+}
+
+// does a session's step take, in decoder_layer_small, exactly the kernel forms decoder_layer_small_multi launches?
+static bool greedy_group_ok(int U, int S, int E, int H, int FF) {
+    return small_layer_applicable(1, U, S, E, H, FF, true) && S > 64 && attn_split_tickets(1, U, H) <= 64 &&
+           FF >= 2048 && FF % 256 == 0 && (E / 16) * ((U + 31) / 32) <= TAL_GREEDY_TICKETS - 64;
 }
 
 }  // namespace tal
@@ -790,10 +925,24 @@ extern "C" size_t tal_decoder_layer_workspace_bytes(int B, int U, int S, int E, 
     return carve(nullptr, B, U, S, E, H, FF).total_floats * sizeof(float);
 }
 
+static int decoder_layer_pitched(const tal_decoder_layer_w* w, const float* tgt, int B, int U, const float* mem,
+                                 int S, int E, int H, int FF, const float* tgt_mask, const uint8_t* mem_kpm,
+                                 const float* k_cache, const float* vt_cache, float* out, float* xattn_avg,
+                                 void* workspace, size_t workspace_bytes, void* stream, int64_t k_pitch);
+
 extern "C" int tal_decoder_layer_fwd(const tal_decoder_layer_w* w, const float* tgt, int B, int U, const float* mem,
                                      int S, int E, int H, int FF, const float* tgt_mask, const uint8_t* mem_kpm,
                                      const float* k_cache, const float* vt_cache, float* out, float* xattn_avg,
                                      void* workspace, size_t workspace_bytes, void* stream) {
+    return decoder_layer_pitched(w, tgt, B, U, mem, S, E, H, FF, tgt_mask, mem_kpm, k_cache, vt_cache, out, xattn_avg, workspace,
+                                 workspace_bytes, stream, 0);
+}
+
+// k_pitch != 0: k_cache is a window of an episode-wide K | V table (rows k_pitch floats apart; batch 1)
+static int decoder_layer_pitched(const tal_decoder_layer_w* w, const float* tgt, int B, int U, const float* mem,
+                                 int S, int E, int H, int FF, const float* tgt_mask, const uint8_t* mem_kpm,
+                                 const float* k_cache, const float* vt_cache, float* out, float* xattn_avg,
+                                 void* workspace, size_t workspace_bytes, void* stream, int64_t k_pitch) {
     TAL_CHECK_ARG(w && tgt && out && workspace, "tal_decoder_layer_fwd: null pointer");
     TAL_CHECK_ARG(w->sa_in_w && w->sa_in_b && w->sa_out_w && w->sa_out_b && w->ca_in_w && w->ca_in_b && w->ca_out_w &&
                       w->ca_out_b && w->lin1_w && w->lin1_b && w->lin2_w && w->lin2_b,
@@ -801,6 +950,7 @@ extern "C" int tal_decoder_layer_fwd(const tal_decoder_layer_w* w, const float* 
     TAL_CHECK_ARG(B > 0 && U > 0 && S > 0 && E > 0 && H > 0 && FF > 0 && E % H == 0 && (E / H) % 4 == 0 && FF % 4 == 0,
                   "tal_decoder_layer_fwd: bad shape B=%d U=%d S=%d E=%d H=%d FF=%d", B, U, S, E, H, FF);
     TAL_CHECK_ARG(mem || (k_cache && vt_cache), "tal_decoder_layer_fwd: need the memory or its cached K / V^T");
+    TAL_CHECK_ARG(!k_pitch || (B == 1 && k_cache && k_pitch >= E && k_pitch % 4 == 0), "tal_decoder_layer_fwd: a pitched K window needs batch 1");
     if (workspace_bytes < tal_decoder_layer_workspace_bytes(B, U, S, E, H, FF)) {
         set_error("tal_decoder_layer_fwd: workspace %zu < %zu bytes", workspace_bytes,
                   tal_decoder_layer_workspace_bytes(B, U, S, E, H, FF));
@@ -809,7 +959,7 @@ extern "C" int tal_decoder_layer_fwd(const tal_decoder_layer_w* w, const float* 
     hipStream_t s = (hipStream_t)stream;
     LayerWs ws = carve(reinterpret_cast<float*>(workspace), B, U, S, E, H, FF);
     if (small_layer_applicable(B, U, S, E, H, FF, k_cache && vt_cache))
-        return decoder_layer_small(w, tgt, B, U, S, E, H, FF, tgt_mask, mem_kpm, k_cache, vt_cache, out, xattn_avg, nullptr, ws, s);
+        return decoder_layer_small(w, tgt, B, U, S, E, H, FF, tgt_mask, mem_kpm, k_cache, vt_cache, out, xattn_avg, nullptr, ws, s, nullptr, k_pitch);
     // self attention over the prefix: q|k in one launch, V^T, scores/softmax/PV, out-proj + ReZero
     int rc = project_q_or_qk(w->sa_in_w, w->sa_in_b, tgt, (int64_t)B * U, E, H, 2, ws.mha.q, s);
     if (rc) return rc;
@@ -831,7 +981,7 @@ extern "C" int tal_decoder_layer_fwd(const tal_decoder_layer_w* w, const float* 
     }
     rc = project_q_or_qk(w->ca_in_w, w->ca_in_b, ws.x1, (int64_t)B * U, E, H, 1, ws.mha.q, s);
     if (rc) return rc;
-    rc = mha_core(w->ca_in_b, w->ca_out_w, w->ca_out_b, ws.mha.q, E, ck, E, cvt, pad, B, U, S, E, H, nullptr, mem_kpm,
+    rc = mha_core(w->ca_in_b, w->ca_out_w, w->ca_out_b, ws.mha.q, E, ck, (k_pitch && ck == k_cache) ? k_pitch : E, cvt, pad, B, U, S, E, H, nullptr, mem_kpm,
                   ws.x1, w->resweight_src, ws.x2, xattn_avg, ws.mha, s);
     if (rc) return rc;
     // feed-forward
@@ -941,6 +1091,7 @@ extern "C" int tal_greedy_step_poll(const tal_greedy_ctx* c, int wait_ms) {
     TAL_CHECK_ARG(c && c->picked_host && c->S > 0 && wait_ms >= 0, "tal_greedy_step_poll: bad argument");
     volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(c->picked_host + 1 + c->S);
     const unsigned seq = c->seq;
+    if (seq == 0) return 0;          // no host-direct step has been issued from this context yet (0 is never a sequence value)
     if (*flag != seq && wait_ms > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0; *flag != seq; ++spins)
@@ -960,7 +1111,10 @@ extern "C" int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int
                   (long long)history_start, (long long)n_gen, c->max_len);
     TAL_CHECK_ARG(sync >= 0 && sync <= 3, "tal_greedy_step_fwd: sync=%d", sync);
     TAL_CHECK_ARG(!sync || c->picked_host, "tal_greedy_step_fwd: sync needs the pinned host buffer");
-    TAL_CHECK_ARG(sync != 3 || c->tickets, "tal_greedy_step_fwd: sync 3 (result written to pinned memory, polled by the caller) needs the merged kernels (tickets)");
+    TAL_CHECK_ARG(sync != 3 || (c->tickets && c->E % 16 == 0 && (c->E0 > 0 ? c->E0 : c->E) % 8 == 0 && (reinterpret_cast<uintptr_t>(c->emb) & 15) == 0 &&
+                                (!c->proj_t || (reinterpret_cast<uintptr_t>(c->proj_t) & 15) == 0)),
+                  "tal_greedy_step_fwd: sync 3 (result written to pinned memory, polled by the caller) needs the merged LM-head + pick kernel "
+                  "(tickets, E %% 16 == 0, embedding width %% 8 == 0, 16-byte aligned emb / proj_t): nothing else writes the sequence word");
     const int U = (int)U64;
     if (c->workspace_bytes < tal_greedy_step_workspace_bytes(U, S, E, H, FF, V, E0, L)) {
         set_error("tal_greedy_step_fwd: workspace %zu < %zu bytes", c->workspace_bytes, tal_greedy_step_workspace_bytes(U, S, E, H, FF, V, E0, L));
@@ -988,10 +1142,10 @@ extern "C" int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int
         TAL_CHECK_ARG(c->k_cache[l] && c->vt_cache[l], "tal_greedy_step_fwd: layer %d has no cached K / V^T", l);
         if (small)
             rc = decoder_layer_small(&c->layers[l], cur, 1, U, S, E, H, FF, nullptr, c->mem_kpm, c->k_cache[l], c->vt_cache[l], h1,
-                                     nullptr, probs + (size_t)l * H * S, ws, s, c->tickets ? &sk : nullptr);
+                                     nullptr, probs + (size_t)l * H * S, ws, s, c->tickets ? &sk : nullptr, c->k_pitch);
         else
-            rc = tal_decoder_layer_fwd(&c->layers[l], cur, 1, U, nullptr, S, E, H, FF, nullptr, c->mem_kpm, c->k_cache[l],
-                                       c->vt_cache[l], h1, avg + (size_t)l * U * S, base, ws.total_floats * sizeof(float), stream);
+            rc = decoder_layer_pitched(&c->layers[l], cur, 1, U, nullptr, S, E, H, FF, nullptr, c->mem_kpm, c->k_cache[l],
+                                       c->vt_cache[l], h1, avg + (size_t)l * U * S, base, ws.total_floats * sizeof(float), stream, c->k_pitch);
         if (rc) return rc;
         cur = h1;
     }
@@ -1009,16 +1163,23 @@ extern "C" int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int
             return TAL_EINVAL;
         }
         c->picked_host_dev = reinterpret_cast<float*>(alias);
+        reinterpret_cast<volatile unsigned*>(c->picked_host)[1 + S] = 0u;      // (a recycled buffer may hold an old sequence value)
     }
     if (host_direct && ++c->seq == 0) ++c->seq;         // (0 is the value of a buffer nobody has written yet)
     const unsigned seq = host_direct ? c->seq : 0u;
     if (c->tickets && E % 16 == 0 && K0 % 8 == 0 && (reinterpret_cast<uintptr_t>(c->emb) & 15) == 0 &&
         (!c->proj_t || (reinterpret_cast<uintptr_t>(c->proj_t) & 15) == 0)) {
         const float* rows = small ? probs : avg + (size_t)(U - 1) * S;
-        hipLaunchKernelGGL(lm_pick_kernel, dim3((unsigned)cdiv(V, LMP_ROWS)), dim3(256), (size_t)(E + K0 + LMP_ROWS) * sizeof(float), s, hl,
-                           E0 > 0 ? c->proj_t : nullptr, E, K0, c->emb, V, rows, L, small ? (int64_t)H * S : (int64_t)U * S,
-                           small ? H : 1, small ? (int64_t)S : (int64_t)0, S, pick_part, c->tickets + (TAL_GREEDY_TICKETS - 1),
-                           host_direct ? c->picked_host_dev : c->picked_dev, c->tokens + n_gen, host_direct ? seq : 0u);
+        LmPickArgs q = {};
+        q.h = hl; q.attn = rows;
+        q.layer_stride = small ? (int64_t)H * S : (int64_t)U * S;
+        q.head_stride = small ? (int64_t)S : (int64_t)0;
+        q.S = S; q.partial = pick_part; q.ticket_word = c->tickets + (TAL_GREEDY_TICKETS - 1);
+        q.out = host_direct ? c->picked_host_dev : c->picked_dev;
+        q.token_out = c->tokens + n_gen;
+        q.host_seq = host_direct ? seq : 0u;
+        hipLaunchKernelGGL(lm_pick_kernel, dim3((unsigned)cdiv(V, LMP_ROWS)), dim3(256), (size_t)(E + K0 + LMP_ROWS) * sizeof(float), s, q,
+                           E0 > 0 ? c->proj_t : nullptr, E, K0, c->emb, V, L, small ? H : 1);
         TAL_CHECK_LAUNCH("tal_greedy_step_fwd(lm head + pick)");
         if (sync == 3) return TAL_OK;
         if (host_direct) {
@@ -1054,4 +1215,302 @@ extern "C" int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int
         }
     }
     return TAL_OK;
+}
+
+// ---- several sessions per launch -----------------------------------------------------------------------------------------
+extern "C" int tal_greedy_group_ok(const tal_greedy_ctx* c, int64_t history_start, int64_t n_gen) {
+    if (!c || !c->tickets || !c->picked_host) return 0;
+    const int64_t U = n_gen - history_start;
+    if (history_start < 0 || U < 1 || U > c->max_len) return 0;
+    const int K0 = c->E0 > 0 ? c->E0 : c->E;
+    if (!(c->E % 16 == 0 && K0 % 8 == 0 && (reinterpret_cast<uintptr_t>(c->emb) & 15) == 0 && (!c->proj_t || (reinterpret_cast<uintptr_t>(c->proj_t) & 15) == 0)))
+        return 0;
+    return greedy_group_ok((int)U, c->S, c->E, c->H, c->FF) ? 1 : 0;
+}
+
+extern "C" int tal_greedy_step_multi_fwd(tal_greedy_ctx* const* ctxs, const int64_t* history_start, const int64_t* n_gen, int G, void* stream) {
+    TAL_CHECK_ARG(ctxs && history_start && n_gen && G >= 1 && G <= TAL_GROUP_MAX, "tal_greedy_step_multi_fwd: 1..%d sessions", TAL_GROUP_MAX);
+    const tal_greedy_ctx* c0 = ctxs[0];
+    TAL_CHECK_ARG(c0, "tal_greedy_step_multi_fwd: null context");
+    const int E = c0->E, H = c0->H, FF = c0->FF, V = c0->V, E0 = c0->E0, L = c0->n_layers, K0 = E0 > 0 ? E0 : E;
+    hipStream_t s = (hipStream_t)stream;
+    SessionLayerIo io[TAL_GROUP_MAX];
+    float* h0[TAL_GROUP_MAX];
+    float* h1[TAL_GROUP_MAX];
+    float* probs[TAL_GROUP_MAX];
+    float* pick_part[TAL_GROUP_MAX];
+    EmbedMulti em = {};
+    int umax = 0;
+    for (int i = 0; i < G; ++i) {
+        tal_greedy_ctx* c = ctxs[i];
+        TAL_CHECK_ARG(c && c->layers && c->emb && c->pe && c->k_cache && c->vt_cache && c->tokens && c->workspace && c->picked_dev && c->picked_host && c->tickets,
+                      "tal_greedy_step_multi_fwd: session %d: null pointer", i);
+        TAL_CHECK_ARG(c->layers == c0->layers && c->E == E && c->H == H && c->FF == FF && c->V == V && c->E0 == E0 && c->n_layers == L &&
+                          c->emb == c0->emb && c->proj == c0->proj && c->proj_t == c0->proj_t && c->pe == c0->pe && c->max_len == c0->max_len,
+                      "tal_greedy_step_multi_fwd: session %d decodes with another model", i);
+        for (int j = 0; j < i; ++j)
+            TAL_CHECK_ARG(ctxs[j] != c && ctxs[j]->workspace != c->workspace && ctxs[j]->tickets != c->tickets,
+                          "tal_greedy_step_multi_fwd: sessions %d and %d share a context, workspace or tickets", j, i);
+        TAL_CHECK_ARG(tal_greedy_group_ok(c, history_start[i], n_gen[i]),
+                      "tal_greedy_step_multi_fwd: session %d (prefix [%lld, %lld), window %d) does not take the merged kernels' forms: step it alone",
+                      i, (long long)history_start[i], (long long)n_gen[i], c->S);
+        const int U = (int)(n_gen[i] - history_start[i]), S = c->S;
+        if (c->workspace_bytes < tal_greedy_step_workspace_bytes(U, S, E, H, FF, V, E0, L)) {
+            set_error("tal_greedy_step_multi_fwd: session %d: workspace %zu < %zu bytes", i, c->workspace_bytes, tal_greedy_step_workspace_bytes(U, S, E, H, FF, V, E0, L));
+            return TAL_ENOMEM;
+        }
+        // the same carving of the session's workspace as tal_greedy_step_fwd
+        float* base = reinterpret_cast<float*>(c->workspace);
+        LayerWs ws = carve(base, 1, U, S, E, H, FF);
+        float* p = base + ws.total_floats;
+        h0[i] = p; p += up64((size_t)U * E);
+        h1[i] = p; p += up64((size_t)U * E);
+        p += up64((size_t)L * U * S);                      // (avg: the batched-GEMM layer's rows, unused here)
+        probs[i] = p; p += up64((size_t)L * H * S);
+        p += up64((size_t)(E0 > 0 ? E0 : E));
+        p += up64((size_t)V);
+        DecodeScratch sk = {p, c->tickets};
+        p += up64(decode_scratch_floats(U, S, E, H));
+        pick_part[i] = p;
+        io[i].U = U; io[i].S = S; io[i].mem_kpm = c->mem_kpm; io[i].ws = ws; io[i].sk = sk;
+        em.tokens[i] = c->tokens + history_start[i];
+        em.out[i] = h0[i];
+        em.U[i] = U;
+        umax = U > umax ? U : umax;
+        if (!c->picked_host_dev) {
+            void* alias = nullptr;
+            if (hipHostGetDevicePointer(&alias, c->picked_host, 0) != hipSuccess || !alias) {
+                set_error("tal_greedy_step_multi_fwd: session %d: picked_host is not mapped pinned host memory (%s)", i, hipGetErrorString(hipGetLastError()));
+                return TAL_EINVAL;
+            }
+            c->picked_host_dev = reinterpret_cast<float*>(alias);
+            reinterpret_cast<volatile unsigned*>(c->picked_host)[1 + S] = 0u;
+        }
+    }
+    TAL_CHECK_ARG(K0 <= 8192, "tal_greedy_step_multi_fwd: embedding width %d too large", K0);
+    hipLaunchKernelGGL(embed_multi_kernel, dim3((unsigned)umax, (unsigned)G), dim3(256), (size_t)K0 * sizeof(float), s, em, c0->emb,
+                       E0 > 0 ? c0->proj : nullptr, c0->pe, V, K0, E);
+    TAL_CHECK_LAUNCH("tal_greedy_step_multi_fwd(embed)");
+    for (int l = 0; l < L; ++l) {
+        for (int i = 0; i < G; ++i) {
+            const tal_greedy_ctx* c = ctxs[i];
+            TAL_CHECK_ARG(c->k_cache[l] && c->vt_cache[l], "tal_greedy_step_multi_fwd: session %d, layer %d has no cached K / V^T", i, l);
+            io[i].tgt = l == 0 ? h0[i] : h1[i];
+            io[i].out = h1[i];
+            io[i].ck = c->k_cache[l];
+            io[i].k_pitch = c->k_pitch ? c->k_pitch : E;
+            io[i].cvt = c->vt_cache[l];
+            io[i].probs_last = probs[i] + (size_t)l * H * io[i].S;
+        }
+        const int rc = decoder_layer_small_multi(&c0->layers[l], io, G, E, H, FF, s);
+        if (rc) return rc;
+    }
+    ArgPack<LmPickArgs> pk;
+    pk.n = G;
+    for (int i = 0; i < G; ++i) {
+        tal_greedy_ctx* c = ctxs[i];
+        if (++c->seq == 0) ++c->seq;
+        LmPickArgs& q = pk.a[i];
+        q = LmPickArgs{};
+        q.h = h1[i] + (size_t)(io[i].U - 1) * E;
+        q.attn = probs[i];
+        q.layer_stride = (int64_t)H * io[i].S;
+        q.head_stride = (int64_t)io[i].S;
+        q.S = io[i].S;
+        q.partial = pick_part[i];
+        q.ticket_word = c->tickets + (TAL_GREEDY_TICKETS - 1);
+        q.out = c->picked_host_dev;
+        q.token_out = c->tokens + n_gen[i];
+        q.host_seq = c->seq;
+    }
+    hipLaunchKernelGGL(lm_pick_multi_kernel, dim3((unsigned)cdiv(V, LMP_ROWS), (unsigned)G), dim3(256), (size_t)(E + K0 + LMP_ROWS) * sizeof(float), s, pk,
+                       E0 > 0 ? c0->proj_t : nullptr, E, K0, c0->emb, V, L, H);
+    TAL_CHECK_LAUNCH("tal_greedy_step_multi_fwd(lm head + pick)");
+    return TAL_OK;
+}
+
+// ---- windows of an episode-wide K | V table -----------------------------------------------------------------------------------
+// The cross-attention K and V of an encoder frame do not depend on the window it is seen through, so a session projects the WHOLE
+// episode once (one dense layer per decoder layer: enc [T', E] x in_proj_weight[E : 3E]^T -> table [T', 2E] = K | V per frame;
+// 737 MB per hour of audio for the reference's 4 x 512 decoder) and a window is a VIEW: K rows are read in place (pitch 2E), the
+// key-padding bytes too; only V^T -- the P.V kernels want V transposed, 16-byte aligned at an arbitrary first frame -- is
+// materialised, by one small transposing launch for all layers.  A window move costs that one launch and no host work beyond
+// rewriting the context's pointers, instead of 12 launches (K, memset, V^T per layer) and fresh buffers.
+struct WindowVt {
+    const float* kv[8];
+    float* vt[8];
+};
+__global__ __launch_bounds__(256) void window_vt_kernel(const WindowVt p, int64_t frame0, int S, int S4, int E, int64_t kv_pitch) {
+    __shared__ float t[32][33];
+    const int l = blockIdx.z, s0 = blockIdx.x * 32, e0 = blockIdx.y * 32;
+    const float* src = p.kv[l] + E;                   // the V half of a table row
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int sidx = s0 + i, e = e0 + threadIdx.x;
+        t[i][threadIdx.x] = (sidx < S && e < E) ? src[(frame0 + sidx) * kv_pitch + e] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int e = e0 + i, sidx = s0 + threadIdx.x;
+        if (e < E && sidx < S4) p.vt[l][(int64_t)e * S4 + sidx] = t[threadIdx.x][i];     // (pad columns S .. S4: zeros)
+    }
+}
+
+extern "C" int tal_window_vt_fwd(const float* const* kv_all, int n_layers, int64_t frame0, int S, int E, int64_t kv_pitch,
+                                 float* const* vt, void* stream) {
+    TAL_CHECK_ARG(kv_all && vt && n_layers >= 1 && n_layers <= 8 && frame0 >= 0 && S >= 1 && E >= 1 && kv_pitch >= 2 * (int64_t)E,
+                  "tal_window_vt_fwd: bad argument");
+    WindowVt p = {};
+    for (int l = 0; l < n_layers; ++l) {
+        TAL_CHECK_ARG(kv_all[l] && vt[l], "tal_window_vt_fwd: layer %d: null pointer", l);
+        p.kv[l] = kv_all[l];
+        p.vt[l] = vt[l];
+    }
+    const int S4 = (int)pad4(S);
+    hipLaunchKernelGGL(window_vt_kernel, dim3((unsigned)cdiv(S4, 32), (unsigned)cdiv(E, 32), (unsigned)n_layers), dim3(32, 8), 0,
+                       (hipStream_t)stream, p, frame0, S, S4, E, kv_pitch);
+    TAL_CHECK_LAUNCH("tal_window_vt_fwd");
+    return TAL_OK;
+}
+
+// point a context at the window [frame0, frame0 + c->S) of its episode-wide table (c->kv_all): K / key-padding views + V^T launch
+extern "C" int tal_greedy_set_window(tal_greedy_ctx* c, int64_t frame0, void* stream) {
+    TAL_CHECK_ARG(c && c->kv_all && c->k_cache && c->vt_cache && c->kv_pitch >= 2 * (int64_t)c->E && c->k_pitch == c->kv_pitch,
+                  "tal_greedy_set_window: the context has no episode-wide K | V table");
+    TAL_CHECK_ARG(frame0 >= 0 && frame0 + c->S <= c->enc_frames, "tal_greedy_set_window: window [%lld, %lld) outside the episode's %lld frames",
+                  (long long)frame0, (long long)(frame0 + c->S), (long long)c->enc_frames);
+    const float** kc = const_cast<const float**>(c->k_cache);             // (the caller's array: n_layers mutable slots)
+    for (int l = 0; l < c->n_layers; ++l) kc[l] = c->kv_all[l] + frame0 * c->kv_pitch;
+    c->mem_kpm = c->kpm_all ? c->kpm_all + frame0 : nullptr;
+    return tal_window_vt_fwd(c->kv_all, c->n_layers, frame0, c->S, c->E, c->kv_pitch, const_cast<float* const*>(c->vt_cache), stream);
+}
+
+// ---- host side of the sliding-window loop (System.generate_unaligned, tal/asr/system.py:389-521) ----------------------------
+extern "C" int tal_unaligned_consume(tal_unaligned_state* st, int64_t token, const float* attn, int S) {
+    TAL_CHECK_ARG(st && st->gen && st->rec_chunk_start && st->rec_attn && st->rec_len && attn, "tal_unaligned_consume: null pointer");
+    TAL_CHECK_ARG(S >= 1 && S <= st->rec_stride && st->n >= 1 && st->n < st->gen_cap && st->n_rec < st->rec_cap && st->n_rec == st->n - 1,
+                  "tal_unaligned_consume: buffers full or inconsistent (n=%lld of %lld, records %lld of %lld, S=%d of %d)", (long long)st->n,
+                  (long long)st->gen_cap, (long long)st->n_rec, (long long)st->rec_cap, S, st->rec_stride);
+    int64_t n = st->n, history_start = st->history_start, chunk_start = st->chunk_start;
+    const int64_t hist_len = n - history_start, chunk_size = st->chunk_size;
+    const int64_t chunk_before = chunk_start;
+    int flags = 0;
+    st->gen[n++] = token;
+    // record: window start (rewritten below, as the reference's aliased tensor is) + the attention row
+    int64_t rec = st->n_rec++;
+    st->rec_chunk_start[rec] = chunk_start;
+    st->rec_len[rec] = S;
+    float* row = st->rec_attn + rec * (int64_t)st->rec_stride;
+    // progress = sum_i attn[i] * (i / S): float32 products (system.py:405-408), summed in double and rounded once
+    double acc = 0.0;
+    const float fS = (float)S;
+    for (int i = 0; i < S; ++i) {
+        row[i] = attn[i];
+        acc += (double)(attn[i] * ((float)i / fS));
+    }
+    const double progress = (double)(float)acc;
+    if (progress > st->highest_progress) {
+        st->num_no_improve = 0;
+        if (st->window_time > 5) st->highest_progress = progress;
+    } else {
+        st->num_no_improve += 1;
+    }
+    const bool stalling = st->num_no_improve >= st->stall_patience;
+    const bool repeating = tal_ngram_repeat_count(st->gen + history_start, hist_len, st->rep_n) > (int64_t)st->rep_n * 2;
+    const bool last_chunk = st->encoder_len - chunk_start <= chunk_size;
+    const bool reset = stalling || repeating;
+    bool kept = true;
+    if (!last_chunk) {
+        if (reset) {
+            chunk_start += st->skip_frames;
+            if (repeating) {
+                const int64_t back = 2 * (int64_t)st->rep_n - 1;
+                n -= back;
+                st->n_rec -= back;
+                kept = false;                              // this step's record is among the ones rolled back
+            }
+            st->gen[n - 1] = st->eos;
+            flags |= TAL_UNALIGNED_PREFIX_REWRITTEN;
+            history_start = n - 1;
+            st->highest_progress = 0.0;
+            st->window_time = 0;
+        } else if (progress > st->thresh_prct) {
+            const int64_t history_size = n - history_start;
+            chunk_start += st->shift_frames;
+            history_start += (int64_t)floorf(st->del_prct * (float)(history_size - 1));
+            st->highest_progress = 0.0;
+            st->window_time = 0;
+        }
+    }
+    if (kept) st->rec_chunk_start[rec] = chunk_start;     // the post-advance, pre-clamp value (system.py:400,441,468)
+    if (chunk_start > st->encoder_len - chunk_size) chunk_start = st->encoder_len - chunk_size;
+    const int64_t floor_hist = n - st->max_positions > 0 ? n - st->max_positions : 0;
+    if (history_start < floor_hist) history_start = floor_hist;
+    TAL_CHECK_ARG(history_start < n && n - history_start <= st->max_positions && st->n_rec == n - 1,
+                  "tal_unaligned_consume: invalid history start %lld of %lld tokens", (long long)history_start, (long long)n);
+    st->window_time += 1;
+    st->n = n;
+    st->history_start = history_start;
+    st->chunk_start = chunk_start;
+    st->it += 1;
+    if (chunk_start != chunk_before) flags |= TAL_UNALIGNED_WINDOW_MOVED;
+    if ((reset && last_chunk) || st->it >= st->max_iters) flags |= TAL_UNALIGNED_DONE;
+    if (n + 1 >= st->gen_cap || st->n_rec + 1 >= st->rec_cap) flags |= TAL_UNALIGNED_GROW;
+    st->flags |= flags;
+    return flags;
+}
+
+extern "C" int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greedy_ctx* const* ctxs, const int64_t* dev_cap, int G,
+                                       int max_steps, void* stream) {
+    TAL_CHECK_ARG(st && ctxs && dev_cap && G >= 1 && G <= TAL_GROUP_MAX && max_steps >= 1, "tal_unaligned_group_run: bad argument");
+    int64_t hs[TAL_GROUP_MAX], ng[TAL_GROUP_MAX];
+    for (int step = 0; step < max_steps; ++step) {
+        bool go = true;
+        for (int i = 0; i < G; ++i) {
+            TAL_CHECK_ARG(st[i] && ctxs[i], "tal_unaligned_group_run: null session %d", i);
+            // what the control flow asked for and the library can do itself: the window as a view of the episode-wide K | V
+            // table, the rewritten prefix from the (pinned) host token stream
+            if ((st[i]->flags & TAL_UNALIGNED_WINDOW_MOVED) && !(st[i]->flags & TAL_UNALIGNED_DONE) && ctxs[i]->kv_all && st[i]->chunk_start >= 0 &&
+                st[i]->chunk_start + ctxs[i]->S <= ctxs[i]->enc_frames) {
+                const int rc = tal_greedy_set_window(ctxs[i], st[i]->chunk_start, stream);
+                if (rc) return rc;
+                st[i]->flags &= ~TAL_UNALIGNED_WINDOW_MOVED;
+            }
+            if ((st[i]->flags & TAL_UNALIGNED_PREFIX_REWRITTEN) && !(st[i]->flags & (TAL_UNALIGNED_DONE | TAL_UNALIGNED_WINDOW_MOVED)) && st[i]->gen_pinned &&
+                st[i]->n <= dev_cap[i]) {
+                if (hipMemcpyAsync(ctxs[i]->tokens, st[i]->gen, (size_t)st[i]->n * sizeof(int64_t), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+                    set_error("tal_unaligned_group_run: prefix upload failed: %s", hipGetErrorString(hipGetLastError()));
+                    return TAL_EHIP;
+                }
+                st[i]->flags &= ~TAL_UNALIGNED_PREFIX_REWRITTEN;
+            }
+            if (st[i]->flags) { go = false; continue; }
+            if (st[i]->n + 1 >= st[i]->gen_cap || st[i]->n_rec + 1 >= st[i]->rec_cap || st[i]->n + 1 > dev_cap[i]) {
+                st[i]->flags |= TAL_UNALIGNED_GROW;
+                go = false;
+            } else if (!tal_greedy_group_ok(ctxs[i], st[i]->history_start, st[i]->n)) {
+                st[i]->flags |= TAL_UNALIGNED_ALONE;
+                go = false;
+            }
+            hs[i] = st[i]->history_start;
+            ng[i] = st[i]->n;
+        }
+        if (!go) return step;
+        int rc = tal_greedy_step_multi_fwd(ctxs, hs, ng, G, stream);
+        if (rc) return rc;
+        bool flagged = false;
+        for (int i = 0; i < G; ++i) {
+            const int got = tal_greedy_step_poll(ctxs[i], 20000);
+            if (got != 1) {
+                const hipError_t e = hipStreamSynchronize((hipStream_t)stream);      // nothing may stay in flight behind an error
+                set_error("tal_unaligned_group_run: session %d: no result after 20 s (stream after the wait: %s)", i, hipGetErrorString(e));
+                return TAL_EHIP;
+            }
+            const float* ph = ctxs[i]->picked_host;
+            rc = tal_unaligned_consume(st[i], (int64_t)__builtin_bit_cast(int32_t, ph[0]), ph + 1, ctxs[i]->S);
+            if (rc < 0) return rc;
+            flagged = flagged || st[i]->flags != 0;
+        }
+        if (flagged) return step + 1;
+    }
+    return max_steps;
 }

@@ -97,7 +97,32 @@ class _GreedySession:
         self.ctx.vt_cache = C.cast(self._kv[1], C.c_void_p)
         self._kpm = D._kpm_u8(mask, 1, mem.shape[1], self.dev)
         self.ctx.mem_kpm = None if self._kpm is None else self._kpm.data_ptr()
-        S = mem.shape[1]
+        self.ctx.k_pitch = 0
+        self.ctx.kv_all = None
+        self._size_for(mem.shape[1])
+
+    def set_episode(self, kv_all, kpm_all, S):
+        """Windows as VIEWS of an episode-wide K | V table (include/tal_asrd.h, tal_greedy_ctx.kv_all): kv_all = one [T', 2E]
+        tensor per decoder layer (K | V of every encoder frame), kpm_all = uint8 [T'] key-padding bytes or None, S = window
+        length.  Afterwards `set_window_frame(frame0)` moves the window with one small launch and no allocation."""
+        c = self.ctx
+        n = c.n_layers
+        self._episode = (kv_all, kpm_all)
+        self._kv_arr = (C.c_void_p * n)(*[t.data_ptr() for t in kv_all])
+        self._vt = [torch.empty(c.E, self.lib.tal_pad4(S), dtype=torch.float32, device=self.dev) for _ in range(n)]
+        self._k_arr = (C.c_void_p * n)()
+        self._vt_arr = (C.c_void_p * n)(*[t.data_ptr() for t in self._vt])
+        c.kv_all = C.cast(self._kv_arr, C.c_void_p)
+        c.kpm_all = None if kpm_all is None else kpm_all.data_ptr()
+        c.enc_frames, c.kv_pitch, c.k_pitch = kv_all[0].shape[0], kv_all[0].shape[1], kv_all[0].shape[1]
+        c.k_cache = C.cast(self._k_arr, C.c_void_p)
+        c.vt_cache = C.cast(self._vt_arr, C.c_void_p)
+        self._size_for(S)
+
+    def set_window_frame(self, frame0):
+        N.check(self.lib.tal_greedy_set_window(self._ctx_ref, int(frame0), self._stream), "tal_greedy_set_window")
+
+    def _size_for(self, S):
         if S != self.S:
             c = self.ctx
             self.S = c.S = S
@@ -133,6 +158,183 @@ class _GreedySession:
         return int(self.picked_np[:1].view(np.int32)[0]), self.picked_np[1:].copy()
 
 
+class _UnalignedRun:
+    """One episode's sliding-window greedy decode (System.generate_unaligned, tal/asr/system.py:254-524) as a state machine, so that
+    the same decisions drive a session decoded alone and a session decoded in a group whose steps share their launches
+    (System.transcribe_unaligned_many):
+
+        while not run.done:
+            run.prepare()                        # window / prefix state on the device for the next step
+            token, attn = <one decode step>      # run.step_alone(), or merged steps of several runs (tal_unaligned_group_run)
+            run.consume(token, attn)             # the reference's control flow on {token, attention row}
+
+    The control flow itself (system.py:389-521) is ONE implementation, the C host helper tal_unaligned_consume on a plain state
+    struct (`self.st`): the loop body runs ~5,700 times per hour of audio beside a ~0.3 ms GPU step, and for a group of sessions
+    the library runs step -> poll -> consume without coming back here until a session needs its window moved, its prefix
+    uploaded, more room, or is finished.  Token stream and alignment records live in flat numpy buffers the struct points to."""
+
+    def __init__(self, system, audio_x, generated, audio_lens, chunk_size=357, max_iters=1000000, max_positions=None,
+                 thresh_prct=0.5, shift_prct=0.25, stall_patience=25, rep_n=5, skip_prct=0.1):
+        model = system.model
+        if generated.size(0) != 1:
+            raise ValueError("generate_unaligned handles one episode at a time (system.py:331,411 call .item())")
+        self.system, self.model = system, model
+        self.dev = dev = audio_x.device
+        self.chunk_size = chunk_size
+        self.max_positions = model.max_positions if max_positions is None else max_positions
+        audio_x = audio_x.half()                        # system.py:285
+        with system._lock:
+            encoder_out = model.encode(audio_x, audio_lens)
+        self.enc, self.mask = encoder_out["encoder_out"], encoder_out["encoder_padding_mask"]
+        prime = generated.detach().cpu().numpy().astype(np.int64)[0]
+        self.st = st = N.UnalignedState()
+        self._st_ref = C.byref(st)
+        self._gen_t = torch.empty(max(self.HOST_TOKENS0, 2 * prime.size), dtype=torch.int64).pin_memory()    # (pinned: the library uploads
+        self.gen = self._gen_t.numpy()                                                                          #  a rewritten prefix itself)
+        self.gen[:prime.size] = prime
+        cap = self.gen.size
+        self.rec_cs = np.empty(cap, dtype=np.int64)               # chunk_start as recorded by the reference
+        self.rec_attn = np.empty((cap, chunk_size), dtype=np.float32)   # attention rows (a window never exceeds chunk_size frames)
+        self.rec_len = np.empty(cap, dtype=np.int32)
+        self._point_buffers()
+        st.n = prime.size
+        st.encoder_len = int((~self.mask).sum(dim=-1).cpu().item())
+        st.eos, st.max_iters = system.tokenizer.eos_token_id, max_iters
+        st.chunk_size, st.max_positions, st.stall_patience, st.rep_n = chunk_size, self.max_positions, stall_patience, rep_n
+        st.skip_frames, st.shift_frames = int(chunk_size * skip_prct), int(chunk_size * shift_prct)
+        st.del_prct = float(np.float32(shift_prct / thresh_prct))
+        st.thresh_prct = thresh_prct
+        st.flags = N.UNALIGNED_DONE if max_iters <= 0 else 0
+        st.gen_pinned = 1
+        self.window_key, self.window = None, None
+        # K | V of every encoder frame for every decoder layer, once per episode (windows become views: _GreedySession.set_episode)
+        # -- whenever whole windows fit the episode; shorter episodes (python-slice windows that wrap) project window by window
+        self.kv_all = self.kpm_all = None
+        if self.enc.shape[1] >= chunk_size and st.encoder_len >= chunk_size and self.EPISODE_TABLE:
+            E = self.enc.shape[2]
+            self.kv_all = []
+            for layer in model.decoder.layers:
+                at = layer.multihead_attn
+                bias = torch.cat([at.in_proj_bias.detach()[E:2 * E], torch.zeros(E, dtype=torch.float32, device=dev)])   # (V's bias is added after P.V)
+                self.kv_all.append(ops.linear(self.enc[0], at.in_proj_weight.detach()[E:3 * E], bias))
+            self.kpm_all = self.mask[0].to(torch.uint8).contiguous()
+        self.gen_dev = torch.empty(max(self.DEV_TOKENS0, 2 * prime.size), dtype=torch.int64, device=dev)
+        self.dev_len = -1                # how many tokens of the device copy of the stream are current (-1: none)
+        self.session, self.session_window = None, None
+        self._consume = N.lib().tal_unaligned_consume
+
+    HOST_TOKENS0, DEV_TOKENS0 = 4096, 1024      # initial capacities of the token stream (host / device); both grow by doubling
+    EPISODE_TABLE = True                        # False: every window is projected on its own (tal_cross_kv_fwd), as in round 3
+
+    def _point_buffers(self):
+        st = self.st
+        st.gen, st.gen_cap = self.gen.ctypes.data, self.gen.size
+        st.rec_chunk_start, st.rec_attn, st.rec_len = self.rec_cs.ctypes.data, self.rec_attn.ctypes.data, self.rec_len.ctypes.data
+        st.rec_cap, st.rec_stride = self.rec_cs.size, self.rec_attn.shape[1]
+
+    n = property(lambda self: self.st.n)
+    history_start = property(lambda self: self.st.history_start)
+    it = property(lambda self: self.st.it)
+    done = property(lambda self: bool(self.st.flags & N.UNALIGNED_DONE))
+
+    # -- the device side of the next step
+    def prepare(self):
+        """Bring the session up to date with what the control flow decided (st.flags): room in the buffers; the encoder window
+        [chunk_start, chunk_start + chunk_size) -- python slice semantics as in the reference's slice_tensor, re-materialised
+        only when it moves, so that the cross-attention K / V^T cache of every layer keeps hitting --; the device copy of the
+        prefix (the kernel that picks a token appends it; the host copy is uploaded again only after a roll-back / forced EOS
+        rewrote it)."""
+        st = self.st
+        n_gen, chunk_start = st.n, st.chunk_start
+        assert n_gen - st.history_start <= self.max_positions, "Cannot exceed max context length"
+        if st.flags & N.UNALIGNED_PREFIX_REWRITTEN:
+            self.dev_len = -1
+        elif self.dev_len >= 0:
+            self.dev_len = n_gen               # (every token since the last upload was appended on the device by its step)
+        if n_gen + 2 >= self.gen.size:         # grow: token stream and records together
+            k = self.gen.size
+            grown = torch.empty(2 * k, dtype=torch.int64).pin_memory()
+            grown.numpy()[:k] = self.gen
+            self._gen_t, self.gen = grown, grown.numpy()
+            self.rec_cs = np.concatenate([self.rec_cs, np.empty(k, dtype=np.int64)])
+            self.rec_attn = np.concatenate([self.rec_attn, np.empty((k, self.rec_attn.shape[1]), dtype=np.float32)])
+            self.rec_len = np.concatenate([self.rec_len, np.empty(k, dtype=np.int32)])
+            self._point_buffers()
+        view = self.kv_all is not None and st.it > 0 and 0 <= chunk_start and chunk_start + self.chunk_size <= self.enc.shape[1]
+        if self.window_key != chunk_start and not view:
+            sl = slice(chunk_start, chunk_start + self.chunk_size)
+            self.window = {"encoder_out": self.enc[:, sl].contiguous(), "encoder_padding_mask": self.mask[:, sl].contiguous()}
+            self.window_key = chunk_start
+        if self.gen_dev.numel() < n_gen + 2:
+            self.gen_dev = torch.empty(2 * (n_gen + 2), dtype=torch.int64, device=self.dev)
+            self.dev_len = -1
+        if self.dev_len != n_gen:
+            self.gen_dev[:n_gen] = torch.from_numpy(self.gen[:n_gen])
+            self.dev_len = n_gen
+        if st.it > 0:
+            # every step but the first is ONE C call (tal_greedy_step_fwd, or tal_greedy_step_multi_fwd with other sessions):
+            # embed -> decoder stack on the window's cached K / V^T -> LM head of the last position -> pick + append on the
+            # device -> {token, attention row} in pinned host memory
+            if self.session is None:
+                self.session = _GreedySession(self.model, self.gen_dev, self.max_positions)
+            if self.session.gen_dev is not self.gen_dev:
+                self.session.set_tokens(self.gen_dev)
+            if view:
+                if self.session.ctx.kv_all is None:
+                    self.session.set_episode(self.kv_all, self.kpm_all, self.chunk_size)
+                    self.session_window = None
+                if self.session_window != chunk_start:
+                    self.session.set_window_frame(chunk_start)
+                    self.session_window = self.window_key = chunk_start
+            elif self.session_window is not self.window:
+                self.session.set_window(self.window)
+                self.session_window = self.window
+        st.flags &= N.UNALIGNED_DONE
+
+    def can_merge(self):
+        """May the next step run inside a merged launch (tal_greedy_group_ok)?  Never the first step (module API)."""
+        return self.st.it > 0 and bool(self.session.lib.tal_greedy_group_ok(self.session._ctx_ref, self.st.history_start, self.st.n))
+
+    def step_alone(self):
+        """The step on this session's own launches -> (token, attention row)."""
+        st = self.st
+        if st.it > 0:
+            return self.session.step(st.history_start, st.n)
+        # first step through the module API: validates the priming tokens (nn.Embedding raises on out-of-range
+        # ids) and the logits (system.py:363-364)
+        model, dev, n_gen = self.model, self.dev, st.n
+        y = self.gen_dev[st.history_start:n_gen].view(1, -1)
+        with self.system._lock:     # (the module API leaves its attention weights on the decoder module)
+            logits = asr_decode(model, y, self.window, causal=False, last_only=True, check_tokens=True)  # [1, V]
+            all_w = model.decoder.src_attn_weights_all                              # [n_layers, B, U, S]
+        if bool(torch.isnan(logits).any()):
+            raise Exception("Logits contain nans!")
+        # token = argmax(log_softmax(logits)) and the attention of the new token averaged over layers (heads
+        # are already averaged by the softmax kernel): one launch, one D2H copy (system.py:366-399 does the
+        # same arithmetic with a log_softmax, an argmax, a .cpu() per quantity and a numpy mean)
+        S_w = all_w.shape[-1]
+        picked = torch.empty(1 + S_w, dtype=torch.float32, device=dev)
+        N.check(N.lib().tal_greedy_pick_fwd(N.ptr(logits), logits.shape[-1], N.ptr(all_w[0, 0, -1]), all_w.shape[0],
+                                            all_w.stride(0), S_w, N.ptr(picked), N.ptr(self.gen_dev[n_gen:]),
+                                            N.stream_handle()), "tal_greedy_pick_fwd")
+        picked = picked.cpu().numpy()
+        return int(picked[:1].view(np.int32)[0]), np.ascontiguousarray(picked[1:], dtype=np.float32)
+
+    def consume(self, token, attn):
+        """The reference's control flow on the step's result (system.py:389-521): tal_unaligned_consume."""
+        rc = self._consume(self._st_ref, int(token), attn.ctypes.data, attn.shape[0])
+        if rc < 0:
+            N.check(rc, "tal_unaligned_consume")
+
+    def result(self):
+        n, k = self.st.n, self.st.n_rec
+        out = torch.from_numpy(self.gen[:n].copy()).view(1, -1).to(self.dev)
+        cs_t = torch.from_numpy(self.rec_cs[:k].copy())
+        lens = self.rec_len[:k]
+        rows = torch.from_numpy(self.rec_attn[:k].copy())
+        return out, [(cs_t[i:i + 1], rows[i:i + 1, :int(lens[i])]) for i in range(k)]
+
+
 class System:
     """Holds the model and the decode-time arguments the reference reads from `self.args`
     (spk_weight, lm_weight) and `self.tokenizer` (eos_token_id)."""
@@ -149,21 +351,27 @@ class System:
 
     # ------------------------------------------------------------------ several episodes in flight
     @torch.no_grad()
-    def transcribe_unaligned_many(self, episodes, streams=8, **kw):
-        """`transcribe_unaligned` over a list of episodes with up to `streams` decode sessions in flight -- the loop the
-        reference runs this path in (tal/asr/system.py:625-742 per test item, one after the other): each session is the
-        ordinary sliding-window decode on its own HIP stream with its own context (prefix buffer, workspace, window K / V^T,
-        pinned result word); they share the weights.  One host thread per session: the per-token C call runs without the
-        interpreter lock, so the launch work of the sessions overlaps, and a decode step (a chain of ~35 small dependent
-        kernels on a few dozen CUs) of one session runs beside the others' on the chip.  An episode's waveform is uploaded
-        on its session's stream (pinned host memory: the copy runs under the other sessions' compute).
+    def transcribe_unaligned_many(self, episodes, streams=8, group=1, **kw):
+        """`transcribe_unaligned` over a list of episodes with several decode sessions in flight -- the loop the reference runs
+        this path in (tal/asr/system.py:625-742 per test item, one after the other).  Each session is the ordinary sliding-window
+        decode with its own context (prefix buffer, workspace, window K / V^T, pinned result word); they share the weights.
 
-        `streams` = 8: the device executes at most four kernels at a time (its four hardware queues), and which streams share a
-        queue is not under the caller's control -- eight streams fill the four queues whatever the assignment, four may land two
-        to a queue (2.5x against 3.0x measured; scripts/ubench/launch_rate.hip, profiles/r3_ubench_launch_rate.txt).
+        group == 1: one host thread, one HIP stream and one chain of launches per session, `streams` of them: the per-token C call
+        runs without the interpreter lock, so the launch work of the sessions overlaps, and a decode step (a chain of ~35 small
+        dependent kernels on a few dozen CUs) of one session runs beside the others' on the chip.  The device executes at most
+        four kernels at a time (its four hardware queues): 3.0x one session at eight streams, a ceiling of 3.9x
+        (scripts/ubench/launch_rate.hip, profiles/r3_ubench_launch_rate.txt).
+
+        group > 1: `streams` host threads, each advancing `group` (<= 8) sessions IN STEP through SHARED launches
+        (tal_greedy_step_multi_fwd: one chain of 34 launches per generated token of every session of the group, each launch
+        running the single-session kernel body per session).  A session whose next step does not take the merged kernels' forms
+        (first step, prefix beyond 192 tokens, window of 64 frames or fewer) takes that step on launches of its own, in the same
+        stream.  While one thread runs the host-side control flow on its group's results, the other threads' steps keep the GPU busy.
+
+        An episode's waveform is uploaded on its session's stream (pinned host memory: the copy runs under the other sessions' compute).
 
         episodes: list of (audio [1, L] float tensor -- host (pinned or not) or device --, audio_lens LongTensor [1]).
-        Returns [(utterance dicts, generated, alignments)] in episode order, identical to the solo runs."""
+        Returns [(utterance dicts, generated, alignments)] in episode order, identical to the solo runs in either mode."""
         if not episodes:
             return []
         dev = next(self.model.parameters()).device
@@ -200,7 +408,61 @@ class System:
                         errors.append((i, e))
                         return
 
-        threads = [threading.Thread(target=worker, daemon=True) for _ in range(max(1, min(int(streams), len(episodes))))]
+        group = max(1, min(int(group), N.TAL_GROUP_MAX))
+        lib = N.lib()
+
+        def group_worker():
+            stream = torch.cuda.Stream(device=dev)
+            slots = []                       # [episode index, _UnalignedRun]
+            G8 = N.TAL_GROUP_MAX
+            st_arr, ctx_arr, cap_arr = (C.POINTER(N.UnalignedState) * G8)(), (C.POINTER(N.GreedyCtx) * G8)(), (C.c_int64 * G8)()
+            i = -1
+            with torch.cuda.device(dev), torch.cuda.stream(stream):
+                handle = N.stream_handle()
+                try:
+                    while True:
+                        while len(slots) < group and not errors:          # refill the free slots
+                            with take:
+                                i = nxt[0]
+                                nxt[0] += 1
+                            if i >= len(episodes):
+                                break
+                            audio, lens = episodes[i]
+                            x = audio.to(dev, non_blocking=True)
+                            prime = torch.full((1, 1), self.tokenizer.eos_token_id, dtype=torch.int64, device=dev)
+                            slots.append([i, _UnalignedRun(self, x, prime, lens, 357, **kw)])
+                        for sl in slots:
+                            if sl[1].done:
+                                results[sl[0]] = self._episode_utterances(*sl[1].result())
+                        slots = [sl for sl in slots if not sl[1].done]
+                        if not slots or errors:
+                            break
+                        runs = [sl[1] for sl in slots]
+                        merged, alone = [], []
+                        for r in runs:
+                            if r.st.flags or r.st.it == 0 or r.session is None:
+                                r.prepare()               # (whatever the control flow asked for: window, prefix upload, room)
+                            (merged if r.can_merge() else alone).append(r)
+                        if len(merged) < 2:
+                            alone, merged = alone + merged, []
+                        for r in alone:                   # first steps, and steps the merged launches do not take
+                            r.prepare()                   # (room for the appended token: nothing else checks it on this path)
+                            r.consume(*r.step_alone())
+                        if merged:
+                            for k, r in enumerate(merged):
+                                st_arr[k], ctx_arr[k], cap_arr[k] = C.pointer(r.st), C.pointer(r.session.ctx), r.gen_dev.numel()
+                            rc = lib.tal_unaligned_group_run(st_arr, ctx_arr, cap_arr, len(merged), 4 if alone else 64, handle)
+                            if rc < 0:
+                                N.check(rc, "tal_unaligned_group_run")
+                    stream.synchronize()
+                except BaseException as e:      # noqa: B902 -- reported to the caller below
+                    errors.append((i, e))
+
+        if group > 1:
+            n_threads = max(1, min(int(streams), (len(episodes) + group - 1) // group))
+            threads = [threading.Thread(target=group_worker, daemon=True) for _ in range(n_threads)]
+        else:
+            threads = [threading.Thread(target=worker, daemon=True) for _ in range(max(1, min(int(streams), len(episodes))))]
         for t in threads:
             t.start()
         for t in threads:
@@ -221,6 +483,10 @@ class System:
         if prime is None:
             prime = torch.full((1, 1), self.tokenizer.eos_token_id, dtype=torch.int64, device=audio_x.device)
         generated, alignments = self.generate_unaligned(audio_x, prime, audio_lens, chunk_size=357, **kw)
+        return self._episode_utterances(generated, alignments)
+
+    def _episode_utterances(self, generated, alignments):
+        """(generated, alignments) of generate_unaligned -> (utterance dicts, generated, alignments), system.py:686-707."""
         hyp = generated[0]
         if hyp is None or len(hyp) <= 1:
             return [], generated, alignments
@@ -323,146 +589,9 @@ class System:
         """system.py:254-524 (designed for batch 1: it calls .item() on per-batch tensors).
         Returns (generated [1, N] LongTensor on the input device, alignments: list of
         (chunk_start LongTensor[1], attention [1, S] CPU tensor) per generated token)."""
-        model = self.model
-        if generated.size(0) != 1:
-            raise ValueError("generate_unaligned handles one episode at a time (system.py:331,411 call .item())")
-        dev = audio_x.device
-        max_positions = model.max_positions if max_positions is None else max_positions
-        audio_x = audio_x.half()                        # system.py:285
-        with self._lock:
-            encoder_out = model.encode(audio_x, audio_lens)
-        enc, mask = encoder_out["encoder_out"], encoder_out["encoder_padding_mask"]
-        encoder_len = int((~mask).sum(dim=-1).cpu().item())
-        eos = self.tokenizer.eos_token_id
-        # Host bookkeeping in flat buffers (the loop body runs ~5000 times per hour of audio next to a ~0.3 ms GPU step):
-        # the token stream in a numpy array of length n, the alignment records as two parallel lists.
-        prime = generated.detach().cpu().numpy().astype(np.int64)[0]
-        gen = np.empty(max(4096, 2 * prime.size), dtype=np.int64)
-        n = prime.size
-        gen[:n] = prime
-        rec_cs, rec_attn = [], []            # chunk_start as recorded by the reference; attention row
-        chunk_start = 0
-        history_start = 0
-        highest_progress = 0
-        num_no_improve = 0
-        window_time = 0
-        window_key, window = None, None
-        gen_dev = torch.empty(max(1024, 2 * n), dtype=torch.int64, device=dev)
-        dev_len = -1
-        session, session_window = None, None
-        ngram_count = N.lib().tal_ngram_repeat_count
-        gen_addr = gen.ctypes.data
-        attn_range, attn_range_S = None, -1
-        for it in range(max_iters):
-            hist_len = n - history_start             # the model input of this step (before the new token is appended)
-            assert hist_len <= max_positions, "Cannot exceed max context length"
-            # encoder window [chunk_start, chunk_start + chunk_size) -- python slice semantics as in the
-            # reference's slice_tensor; re-materialised only when the window moves so that the
-            # cross-attention K / V^T cache of every layer keeps hitting
-            if window_key != chunk_start:
-                sl = slice(chunk_start, chunk_start + chunk_size)
-                window = {"encoder_out": enc[:, sl].contiguous(), "encoder_padding_mask": mask[:, sl].contiguous()}
-                window_key = chunk_start
-            # the prefix lives on the device: the kernel that picks a token appends it, and the host copy is
-            # uploaded again only after the control flow below rewrote it (roll-back, forced EOS)
-            n_gen = n
-            if gen_dev.numel() < n_gen + 1:
-                gen_dev = torch.empty(2 * (n_gen + 1), dtype=torch.int64, device=dev)
-                dev_len = -1
-            if gen.size < n_gen + 1:
-                gen = np.concatenate([gen, np.empty(gen.size, dtype=np.int64)])
-                gen_addr = gen.ctypes.data
-            if dev_len != n_gen:
-                gen_dev[:n_gen] = torch.from_numpy(gen[:n_gen])
-                dev_len = n_gen
-            if it == 0:
-                # first step through the module API: validates the priming tokens (nn.Embedding raises on out-of-range
-                # ids) and the logits (system.py:363-364)
-                y = gen_dev[history_start:n_gen].view(1, -1)
-                with self._lock:     # (the module API leaves its attention weights on the decoder module)
-                    logits = asr_decode(model, y, window, causal=False, last_only=True, check_tokens=True)  # [1, V]
-                    all_w = model.decoder.src_attn_weights_all                              # [n_layers, B, U, S]
-                if bool(torch.isnan(logits).any()):
-                    raise Exception("Logits contain nans!")
-                # token = argmax(log_softmax(logits)) and the attention of the new token averaged over layers (heads
-                # are already averaged by the softmax kernel): one launch, one D2H copy (system.py:366-399 does the
-                # same arithmetic with a log_softmax, an argmax, a .cpu() per quantity and a numpy mean)
-                S_w = all_w.shape[-1]
-                picked = torch.empty(1 + S_w, dtype=torch.float32, device=dev)
-                N.check(N.lib().tal_greedy_pick_fwd(N.ptr(logits), logits.shape[-1], N.ptr(all_w[0, 0, -1]), all_w.shape[0],
-                                                    all_w.stride(0), S_w, N.ptr(picked), N.ptr(gen_dev[n_gen:]),
-                                                    N.stream_handle()), "tal_greedy_pick_fwd")
-                picked = picked.cpu().numpy()
-                token = int(picked[:1].view(np.int32)[0])
-                attn = picked[1:].astype(np.float32)
-            else:
-                # every later step is ONE C call (tal_greedy_step_fwd): embed -> decoder stack on the window's cached
-                # K / V^T -> LM head of the last position -> pick + append on the device -> {token, attention row}
-                # in pinned host memory
-                if session is None:
-                    session = _GreedySession(model, gen_dev, max_positions)
-                if session.gen_dev is not gen_dev:
-                    session.set_tokens(gen_dev)
-                if session_window is not window:
-                    session.set_window(window)
-                    session_window = window
-                token, attn = session.step(history_start, n_gen)
-            gen[n] = token
-            n += 1
-            dev_len = n
-            rec_cs.append(chunk_start)
-            rec_attn.append(attn)
-            assert len(rec_cs) == n - 1
-            S = attn.shape[0]
-            if S != attn_range_S:
-                attn_range, attn_range_S = (np.arange(S, dtype=np.float32) / np.float32(S)).astype(np.float32), S
-            prct_progress = float(np.sum(attn * attn_range, dtype=np.float32))
-            if prct_progress > highest_progress:
-                num_no_improve = 0
-                if window_time > 5:
-                    highest_progress = prct_progress
-            else:
-                num_no_improve += 1
-            is_stalling = num_no_improve >= stall_patience
-            # ngram_repeat_mask(model_input, rep_n).sum() over the step's input (tal/asr/util.py:5-17, system.py:418-421)
-            rep_count = ngram_count(gen_addr + 8 * history_start, hist_len, rep_n)
-            is_repeating = rep_count > rep_n * 2
-            is_last_chunk = encoder_len - chunk_start <= chunk_size
-            reset_window = is_stalling or is_repeating
-            record_kept = True
-            if not is_last_chunk:
-                if reset_window:
-                    chunk_start += int(chunk_size * skip_prct)
-                    if is_repeating:
-                        rollback = 2 * rep_n
-                        n -= rollback - 1
-                        del rec_cs[-(rollback - 1):]
-                        del rec_attn[-(rollback - 1):]
-                        record_kept = False            # this step's record is among the ones rolled back
-                    gen[n - 1] = eos
-                    dev_len = -1                   # the device copy of the prefix is stale
-                    history_start = n - 1
-                    highest_progress = 0
-                    window_time = 0
-                elif prct_progress > thresh_prct:
-                    history_size = n - history_start
-                    chunk_start += int(chunk_size * shift_prct)
-                    history_start += int(np.floor(np.float32(shift_prct / thresh_prct) * np.float32(history_size - 1)))
-                    highest_progress = 0
-                    window_time = 0
-            # The reference stores the chunk_start *tensor object* in `alignments` and then advances it in
-            # place (system.py:400,441,468), so the recorded value is the post-advance, pre-clamp one.
-            if record_kept:
-                rec_cs[-1] = chunk_start
-            chunk_start = min(chunk_start, encoder_len - chunk_size)
-            history_start = max(history_start, max(n - max_positions, 0))
-            assert history_start < n, ("Invalid history start index", history_start, n)
-            assert n - history_start <= max_positions, ("Exceed max positions", history_start, n)
-            window_time += 1
-            if reset_window and is_last_chunk:
-                break
-        out = torch.from_numpy(gen[:n].copy()).view(1, -1).to(dev)
-        rows = torch.from_numpy(np.stack(rec_attn)) if len({a.shape[0] for a in rec_attn}) == 1 else None
-        cs_t = torch.tensor(rec_cs, dtype=torch.int64)
-        return out, [(cs_t[i:i + 1], rows[i:i + 1] if rows is not None else torch.from_numpy(rec_attn[i]).unsqueeze(0))
-                     for i in range(len(rec_cs))]
+        run = _UnalignedRun(self, audio_x, generated, audio_lens, chunk_size, max_iters, max_positions, thresh_prct, shift_prct,
+                            stall_patience, rep_n, skip_prct)
+        while not run.done:
+            run.prepare()
+            run.consume(*run.step_alone())
+        return run.result()

@@ -48,7 +48,34 @@ def test_struct_layout_matches_header():
     expect += 8                              # flags + pad
     assert C.sizeof(_native.TdsDesc) == expect
     assert _native.TdsDesc.flags.offset == expect - 8
-    assert C.sizeof(_native.GreedyCtx) == 8 + 8 * 4 + 8 * 8 + 8 + 8 + 3 * 8 + 8 + 8    # pointer, 8 ints, 8 pointers, workspace + size, 3 pointers, device alias, seq + pad
+    assert C.sizeof(_native.GreedyCtx) == 8 + 8 * 4 + 8 * 8 + 8 + 8 + 3 * 8 + 8 + 8 + 5 * 8    # pointer, 8 ints, 8 pointers, workspace + size, 3 pointers, device alias, seq + pad, pitch + episode table
+
+
+def test_struct_layouts_against_the_c_compiler(tmp_path):
+    """Every struct of include/tal_asrd.h as gcc lays it out (sizeof + the offset of every field) against its ctypes mirror."""
+    import ctypes as C
+    import subprocess
+    from tal_asrd_amd import _native
+    pairs = {"tal_tds_block_w": _native.TdsBlockW, "tal_tds_desc": _native.TdsDesc, "tal_decoder_layer_w": _native.DecoderLayerW,
+             "tal_greedy_ctx": _native.GreedyCtx, "tal_unaligned_state": _native.UnalignedState}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tal_asrd.h"', 'int main(void) {']
+    for cname, mirror in pairs.items():
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in mirror._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        cname, fname, val = ln.split()
+        got[(cname, fname)] = int(val)
+    for cname, mirror in pairs.items():
+        assert got[(cname, "sizeof")] == C.sizeof(mirror), cname
+        for fname, _ in mirror._fields_:
+            assert got[(cname, fname)] == getattr(mirror, fname).offset, (cname, fname)
 
 
 def test_error_path_no_gpu_needed():

@@ -110,9 +110,10 @@ def test_episode_wder_identical(episode):
 
 
 def test_sessions_in_flight_reproduce_their_solo_runs(asr_weights):
-    """System.transcribe_unaligned_many: several decode sessions on their own HIP streams, sharing one set of weights, driven
-    by one host thread each.  Every episode's token stream, window starts and attention rows equal its solo run exactly
-    (the sessions share nothing but read-only weights), whatever the number of sessions in flight."""
+    """System.transcribe_unaligned_many: several decode sessions sharing one set of weights -- on their own HIP streams and
+    launches (one host thread each), or in groups whose steps share their launches (every launch runs the single-session
+    kernel body per session).  Every episode's token stream, window starts and attention rows equal its solo run EXACTLY,
+    whatever the number of sessions in flight and however they are grouped."""
     from tal_asrd_amd import ASRModel, synth
     from tal_asrd_amd.system import System
     from tal_asrd_amd.tokenizer import SynthTokenizer
@@ -125,8 +126,10 @@ def test_sessions_in_flight_reproduce_their_solo_runs(asr_weights):
         a = synth.synth_audio_batch(1, L, 2469 + k).astype(np.float16).astype(np.float32)
         eps.append((torch.from_numpy(a).pin_memory(), torch.tensor([L])))
     solo = [system.transcribe_unaligned(a.to(dev), lens) for a, lens in eps]
-    for streams in (2, 5):
-        many = system.transcribe_unaligned_many(eps, streams=streams)
+    # (streams, group): one chain of launches per session on its own stream | sessions advanced in step through SHARED launches
+    # (tal_greedy_step_multi_fwd): five in one group; groups of two and three on two threads, slots refilled as episodes end
+    for streams, group in ((2, 1), (5, 1), (1, 8), (2, 2), (2, 3)):
+        many = system.transcribe_unaligned_many(eps, streams=streams, group=group)
         assert len(many) == len(solo)
         for (u1, g1, al1), (u2, g2, al2) in zip(solo, many):
             assert torch.equal(g1.cpu(), g2.cpu())
@@ -135,3 +138,62 @@ def test_sessions_in_flight_reproduce_their_solo_runs(asr_weights):
                 assert torch.equal(a1, a2)
             assert [u["utterance"] for u in u1] == [u["utterance"] for u in u2]
     assert sum(g.shape[1] for _, g, _ in solo) > 300          # the episodes do generate
+    # ... with buffers that have to grow on the way (token stream on the host and on the device), alone and in groups
+    from tal_asrd_amd import system as S_
+    keep = S_._UnalignedRun.HOST_TOKENS0, S_._UnalignedRun.DEV_TOKENS0
+    S_._UnalignedRun.HOST_TOKENS0, S_._UnalignedRun.DEV_TOKENS0 = 48, 24
+    try:
+        for streams, group in ((1, 1), (1, 8), (3, 2)):
+            many = system.transcribe_unaligned_many(eps, streams=streams, group=group)
+            for (u1, g1, al1), (u2, g2, al2) in zip(solo, many):
+                assert torch.equal(g1.cpu(), g2.cpu()) and all(torch.equal(a1, a2) and int(c1[0]) == int(c2[0]) for (c1, a1), (c2, a2) in zip(al1, al2))
+    finally:
+        S_._UnalignedRun.HOST_TOKENS0, S_._UnalignedRun.DEV_TOKENS0 = keep
+    # windows as views of the episode-wide K | V table (the default) against windows projected one by one (round 3's form): the
+    # same tokens and window starts; K / V come out of differently shaped dense launches, so attention rows agree to rounding
+    S_._UnalignedRun.EPISODE_TABLE = False
+    try:
+        per_window = [system.transcribe_unaligned(a.to(dev), lens) for a, lens in eps[:3]]
+    finally:
+        S_._UnalignedRun.EPISODE_TABLE = True
+    for (u1, g1, al1), (u2, g2, al2) in zip(solo, per_window):
+        assert torch.equal(g1.cpu(), g2.cpu()) and [int(c[0]) for c, _ in al1] == [int(c[0]) for c, _ in al2]
+        assert max(float((a1 - a2).abs().max()) for (_, a1), (_, a2) in zip(al1, al2)) < 1e-5
+
+
+def test_merged_step_equals_solo_step_bit_for_bit(asr_weights):
+    """tal_greedy_step_multi_fwd against tal_greedy_step_fwd on the same states: three sessions with prefixes of 1, 17 and 40
+    tokens (one / two M tiles per workgroup in the skinny GEMMs; 1-3 query blocks) on different windows -- token, attention
+    row and the appended device token identical; a session whose step the merged launches cannot take (prefix of 200 tokens)
+    is reported by tal_greedy_group_ok and refused by the merged call."""
+    import ctypes as C
+    from tal_asrd_amd import ASRModel, synth, _native as N
+    from tal_asrd_amd.system import System, _GreedySession
+    dev = torch.device("cuda:0")
+    asr = _load(ASRModel("2x", num_speakers=6008, vocab_size=10000, use_speaker_head=True), asr_weights, dev)
+    L = 60 * 16000
+    audio = torch.from_numpy(synth.synth_audio_batch(1, L, 99)).to(dev)
+    enc = asr.encode(audio.half(), torch.tensor([L]))
+    rng = np.random.default_rng(5)
+    lib = N.lib()
+    sessions, solo = [], []
+    for k, U in enumerate((1, 17, 40, 200)):
+        toks = torch.from_numpy(rng.integers(3, 10000, size=U + 8).astype(np.int64)).to(dev)
+        s = _GreedySession(asr, toks, 512)
+        sl = slice(40 * k, 40 * k + 357)
+        s.set_window({"encoder_out": enc["encoder_out"][:, sl].contiguous(), "encoder_padding_mask": enc["encoder_padding_mask"][:, sl].contiguous()})
+        sessions.append((s, U))
+        solo.append(s.step(0, U) + (int(toks[U]),))
+    assert [lib.tal_greedy_group_ok(s._ctx_ref, 0, U) for s, U in sessions] == [1, 1, 1, 0]
+    ctxs = (C.POINTER(N.GreedyCtx) * 8)(*[C.pointer(s.ctx) for s, _ in sessions])
+    hs = (C.c_int64 * 8)(0, 0, 0, 0)
+    ng = (C.c_int64 * 8)(*[U for _, U in sessions])
+    assert lib.tal_greedy_step_multi_fwd(ctxs, hs, ng, 4, N.stream_handle()) != 0 and b"step it alone" in lib.tal_last_error()
+    for rep in range(2):
+        for s, U in sessions[:3]:
+            s.gen_dev[U] = -1
+        N.check(lib.tal_greedy_step_multi_fwd(ctxs, hs, ng, 3, N.stream_handle()), "tal_greedy_step_multi_fwd")
+        for (s, U), (tok, row, appended) in zip(sessions[:3], solo):
+            assert s.ready(20000)
+            t2, r2 = s.result()
+            assert t2 == tok and np.array_equal(r2, row) and int(s.gen_dev[U]) == appended

@@ -38,3 +38,67 @@ def test_native_ngram_repeat_count_matches_mask_sum():
         row = rng.randint(0, 3, size=L).astype(np.int64)
         want = int(ngram_repeat_mask([row.tolist()], n).sum()) if L else 0
         assert lib.tal_ngram_repeat_count(row.ctypes.data, L, n) == want
+
+
+def _unaligned_state(prime, encoder_len, chunk_size=357, max_iters=1000000, max_positions=512, thresh_prct=0.5, shift_prct=0.25,
+                     stall_patience=25, rep_n=5, skip_prct=0.1, eos=1, cap=4096):
+    import numpy as np
+    from tal_asrd_amd import _native as N
+    st = N.UnalignedState()
+    bufs = {"gen": np.zeros(cap, np.int64), "cs": np.zeros(cap, np.int64), "attn": np.zeros((cap, chunk_size), np.float32), "len": np.zeros(cap, np.int32)}
+    bufs["gen"][:len(prime)] = prime
+    st.gen, st.gen_cap, st.n = bufs["gen"].ctypes.data, cap, len(prime)
+    st.rec_chunk_start, st.rec_attn, st.rec_len = bufs["cs"].ctypes.data, bufs["attn"].ctypes.data, bufs["len"].ctypes.data
+    st.rec_cap, st.rec_stride = cap, chunk_size
+    st.encoder_len, st.eos, st.max_iters = encoder_len, eos, max_iters
+    st.chunk_size, st.max_positions, st.stall_patience, st.rep_n = chunk_size, max_positions, stall_patience, rep_n
+    st.skip_frames, st.shift_frames = int(chunk_size * skip_prct), int(chunk_size * shift_prct)
+    st.del_prct, st.thresh_prct = float(np.float32(shift_prct / thresh_prct)), thresh_prct
+    return st, bufs
+
+
+def test_unaligned_consume_follows_the_pinned_control_flow():
+    """tal_unaligned_consume -- the product's ONE implementation of System.generate_unaligned's per-token decisions
+    (tal/asr/system.py:389-521), a C host helper -- driven with the raw (token, attention row) of every step of the oracle's
+    run on the two recorded episodes (the oracle reproduces the trajectories recorded from the reference,
+    tests/test_oracle_golden.py): after EVERY step the window start, history start and stream length agree, the flags say
+    exactly when the window moved / the prefix was rewritten / the episode ended, and the final token stream, recorded window
+    starts and attention rows equal the fixture's."""
+    import ctypes as C
+    import json
+    import os
+    import numpy as np
+    from oracle import tal_oracle as O
+    from tal_asrd_amd import synth, _native as N
+    from tests.conftest import GOLDEN, golden
+    lib = N.lib()
+    keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))["ASRModel_2x_spk"]
+    sd = synth.fill_state_dict({k: tuple(s) for k, s in keys})
+    for name in ("flow_unaligned_short", "flow_unaligned"):
+        g = golden(name)
+        L = int(g["audio_len"])
+        enc_len = O.tds_total_out_len(O.num_frames(L))
+        st, bufs = _unaligned_state([1], enc_len, max_iters=int(g["max_iters"]))
+        seen = {"steps": 0, "prev_win": 0}
+
+        def on_step(token, row, win, hist, ntok, finished):
+            row = np.ascontiguousarray(row, dtype=np.float32)
+            st.flags = 0
+            flags = lib.tal_unaligned_consume(C.byref(st), token, row.ctypes.data, row.shape[0])
+            assert flags >= 0, lib.tal_last_error()
+            assert (st.chunk_start, st.history_start, st.n) == (win, hist, ntok), (seen["steps"], st.chunk_start, win, st.history_start, hist, st.n, ntok)
+            assert bool(flags & N.UNALIGNED_WINDOW_MOVED) == (win != seen["prev_win"])
+            assert bool(flags & N.UNALIGNED_DONE) == (bool(finished) or seen["steps"] + 1 >= int(g["max_iters"]))
+            seen["prev_win"] = win
+            seen["steps"] += 1
+        toks, starts, rows = O.generate_unaligned(synth.synth_audio_batch(1, L, int(g["audio_seed"])), [[1]], [L], sd,
+                                                  max_iters=int(g["max_iters"]), stall_patience=25, on_step=on_step)
+        assert seen["steps"] > 30
+        np.testing.assert_array_equal(bufs["gen"][:st.n], g["generated"][0])
+        np.testing.assert_array_equal(bufs["cs"][:st.n_rec], g["chunk_start"])
+        lens = bufs["len"][:st.n_rec]
+        if "attn" in g.files:
+            np.testing.assert_allclose(bufs["attn"][:st.n_rec], g["attn"], atol=1e-5, rtol=0)
+        else:
+            assert lens.tolist() == g["attn_len"].tolist()
+            np.testing.assert_allclose(np.concatenate([bufs["attn"][i, :lens[i]] for i in range(st.n_rec)]), g["attn_flat"], atol=1e-5, rtol=0)

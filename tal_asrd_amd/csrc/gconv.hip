@@ -888,8 +888,28 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
 // An output's chain of MFMAs depends on its shift s = (t - tile start) % 8 only, and tile starts are multiples of 64: long
 // (256) and short (64) tiles give bit-identical results.  Channels 16, 17 differ from gconv_mfma_kernel's in the last bits
 // (other grouping of the products into K chunks), channels 0-15 are the same chains.
+// (ablation build -DGC_TIMELINE: lane 0 of every wave of the first 4096 workgroups stamps the 100 MHz wall clock at the phase
+//  boundaries; scripts/gconv_timeline.py reads them through tal_debug_gconv_timeline.  Not part of the product library.)
+#ifdef GC_TIMELINE
+__device__ unsigned long long g_gc_timeline[8 * 4 * 4096];
+#define GC_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                             \
+            g_gc_timeline[((i) * 4 + (threadIdx.x >> 6)) * 4096 + blockIdx.x] = wall_clock64();       \
+    } while (0)
+#else
+#define GC_STAMP(i)
+#endif
+
 constexpr int S18_NKA = 18;      // K chunks of the shifted tile: (21 + 7) rows x 20 halves = 560 -> 576
 constexpr int S18_SH = 8;        // shifts per channel
+// The shifted tile's A fragments are NOT loaded from memory (18 K chunks x hi / lo x 1 KB per wave, mostly zeros, at the 25-60
+// GB/s a CU pulls from L2: measured 6.8 us of a 22 us workgroup): a group's two left-over channels are 2 x 420 weights; they sit
+// in LDS as a zero-padded line per channel and hi / lo, [S18_WPRE zeros | 420 weights in slab order tap * 20 + channel | zeros],
+// and row (c, s), k group kg of chunk ch is the 8 halves at S18_WPRE + 32 ch + 8 kg - 20 s of line c.
+constexpr int S18_WPRE = 20 * (S18_SH - 1);                   // 140
+constexpr int S18_WL = S18_WPRE + 32 * S18_NKA + 8;           // 724 halves per line, rounded up so that a workgroup's eight lines are
+constexpr int S18_WLP = (S18_WL + 255) & ~255;                // a whole number of 256 x 16-byte pieces (768)
 
 template <int TT>
 __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __restrict__ x, const _Float16* __restrict__ wfrag,
@@ -902,15 +922,28 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
     constexpr int TIN = TT + KS - 1, GS = LY::slab(0, TT);
     static_assert(GS * 2 >= ((TT >= 128 ? TT - 8 : TT - 8) * P + 32 * S18_NKA) * 2, "slab tail");
     constexpr int CH = GB * CG, CH4 = CH / 4, RPP = 256 / CH4;
-    extern __shared__ __attribute__((aligned(16))) _Float16 slab[];   // [2 (hi, lo)][GB][GS]
+    extern __shared__ __attribute__((aligned(16))) _Float16 slab[];   // [2 (hi, lo)][GB][GS] | weight lines [GB][2 (channel)][2 (hi, lo)][S18_WLP]
     _Float16* s_hi = slab;
     _Float16* s_lo = slab + GB * GS;
+    _Float16* s_wl = slab + 2 * GB * GS;
 
     GC_BLOCK_INDEX(n_tt, n_gb)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = wave_id();
     const float* xb = x + (int64_t)b * T * C;
+    // the two groups' weight lines (contiguous in memory: g0, g0 + 1) as 16-byte pieces: requested first, written to LDS behind
+    // the slab rows' requests (loads return in order: a wait placed here would hold up everything behind it)
+    constexpr int NPL = GB * 4 * S18_WLP / 8, NLP = NPL / 256;
+    static_assert(NPL % 256 == 0, "weight lines");
+    f16x8 wline[NLP];
+    {
+        const f16x8* src = reinterpret_cast<const f16x8*>(wshift + (int64_t)g0 * (4 * S18_WLP));
+#pragma unroll
+        for (int j = 0; j < NLP; ++j) wline[j] = src[tid + 256 * j];
+        __builtin_amdgcn_sched_barrier(0);
+    }
     const int nrows = (int)(T - t0 < (int64_t)TT ? T - t0 : (int64_t)TT);
+    GC_STAMP(0);
 
     // ---- slab fill from the split-form input (as gconv_mfma_kernel<.., XSPLIT = true>) ----
     {
@@ -934,6 +967,10 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
             vh[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, voffs + u * RPP * C * 4, 0, 0);
             vl[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, voffs + 64 + u * RPP * C * 4, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NLP; ++j)
+            reinterpret_cast<f16x8*>(s_wl)[tid + 256 * j] = wline[j];
 #pragma unroll
         for (int u = 0; u < NPASS; ++u) {
             const int ti = r0 + u * RPP;
@@ -953,7 +990,9 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
         for (int i = tid; i < 2 * GB * tail2; i += 256)
             *reinterpret_cast<f16x2*>(slab + (i / tail2) * GS + TIN * P + 2 * (i % tail2)) = z2;
     }
+    GC_STAMP(1);
     __syncthreads();
+    GC_STAMP(2);
 
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int col = lane & 15, kg = lane >> 4;
@@ -966,14 +1005,19 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
     if (h < NRANGE) {
         const int cn = col & (NCOLV - 1);                          // (TT = 64: columns 8-15 repeat 0-7 and are dropped)
         const int base = h * 128 + S18_SH * cn;                    // first output step of this column
-        const f16x8* wf = reinterpret_cast<const f16x8*>(wshift) + (int64_t)g * (S18_NKA * 2 * 64) + lane;
         const _Float16* hs = s_hi + gl * GS + base * P + 8 * kg;   // 16-byte aligned: 8 rows = 320 bytes
         const _Float16* ls = s_lo + gl * GS + base * P + 8 * kg;
+        // this lane's A row = (channel 16 + (col & 1), shift col >> 1): 8 halves at S18_WPRE + 32 c + 8 kg - 20 shift of its line
+        typedef _Float16 f16x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+        const _Float16* wh_l = s_wl + ((gl * 2 + (col & 1)) * 2 + 0) * S18_WLP + S18_WPRE + 8 * kg - 20 * (col >> 1);
+        const _Float16* wl_l = wh_l + S18_WLP;
         const float b16 = bias[g * CG + 16], b17 = bias[g * CG + 17];
         f32x4 acc = {b16, b17, b16, b17}, ax1 = {0.f, 0.f, 0.f, 0.f}, ax2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < S18_NKA; ++c) {
-            const f16x8 ah = wf[(c * 2 + 0) * 64], al = wf[(c * 2 + 1) * 64];
+            const f16x4a8 a0 = *reinterpret_cast<const f16x4a8*>(wh_l + 32 * c), a1 = *reinterpret_cast<const f16x4a8*>(wh_l + 32 * c + 4);
+            const f16x4a8 l0 = *reinterpret_cast<const f16x4a8*>(wl_l + 32 * c), l1 = *reinterpret_cast<const f16x4a8*>(wl_l + 32 * c + 4);
+            const f16x8 ah = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, al = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
             const f16x8 bh = *reinterpret_cast<const f16x8*>(hs + 32 * c), bl = *reinterpret_cast<const f16x8*>(ls + 32 * c);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
             ax1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, ax1, 0, 0, 0);
@@ -1012,6 +1056,7 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
         }
     }
 
+    GC_STAMP(3);
     // ---- phase B: channels 0-15; wave h takes the blocks of its half of the tile, one after the other, WITHOUT barriers ----
     // A block's output halves overwrite the slab rows of its own 16 steps (dead once the block has its operands: the next block
     // reads from 16 rows further on).  The only rows two waves of a group contend for are the first 20 of the second half -- wave
@@ -1022,6 +1067,8 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
     constexpr int NB = TT / 16, NBH = NB / 2;
     static_assert(NB % 2 == 0 && NBH >= 2, "blocks per tile");
     {
+        // (requesting these 28 fragments earlier -- behind the slab rows, held in 112 registers across the fill and phase A --
+        //  measured SLOWER: 0.282 against 0.255 ms, profiles/r4_gconv_time_shift_and_xcd_order.txt)
         f16x8 wh[NK], wl[NK];
         const f16x8* wf = reinterpret_cast<const f16x8*>(wfrag) + (int64_t)(g * 2) * (NK * 2 * 64) + lane;
 #pragma unroll
@@ -1060,6 +1107,7 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
         }
         const _Float16* rh = s_hi + gl * GS + ch0;
         const _Float16* rl = s_lo + gl * GS + ch0;
+        GC_STAMP(4);
         auto block = [&](int tb, bool last, f16x4a8& oh, f16x4a8& ol) {
             f32x4 acc = bv, ax1 = {0.f, 0.f, 0.f, 0.f}, ax2 = {0.f, 0.f, 0.f, 0.f};
             const int nb = last ? boff : boff + 16 * P;
@@ -1132,6 +1180,7 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
         }
     }
     note_range(am, range_flag);
+    GC_STAMP(5);
 
     // ---- the tile leaves LDS along rows (as gconv_mfma_kernel's STAGED phase); channels 16, 17 come from the pad columns ----
     __syncthreads();
@@ -1145,6 +1194,7 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
         }
     }
     __syncthreads();
+    GC_STAMP(6);
     {
         constexpr int CW = GB * CG, PW = 2, NPC = CW / (2 * PW), WPG = CG / 2, NPR = 2 * NPC;
         constexpr int RP = 256 / NPR, NPO = (TT + RP - 1) / RP;
@@ -1175,28 +1225,27 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
             }
         }
     }
+    GC_STAMP(7);
 }
 
-// weights of the shifted tile: [g][K chunk][hi, lo][lane][8 halves]; row = lane & 15 = 2 s + c (shift s, channel 16 + c),
-// k = 32 chunk + 8 (lane >> 4) + i; k - 20 s = 20 tap + input channel
+// weight lines of the shifted tile: [g][channel 16 / 17][hi, lo][S18_WLP] halves = S18_WPRE zeros | the channel's 420 weights in
+// slab order (tap * 20 + input channel, pad channels 18, 19 zero) | zeros
 __global__ void pack_gconv_shift18_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int groups) {
-    const int64_t total = (int64_t)groups * S18_NKA * 64 * 8;
+    const int64_t total = (int64_t)groups * 2 * S18_WLP;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int i = (int)(idx & 7), l = (int)((idx >> 3) & 63);
-    const int c = (int)((idx >> 9) % S18_NKA), g = (int)((idx >> 9) / S18_NKA);
-    const int row = l & 15, sft = row >> 1, co = 16 + (row & 1);
-    const int k = 32 * c + 8 * (l >> 4) + i - 20 * sft;
+    const int i = (int)(idx % S18_WLP), c = (int)((idx / S18_WLP) & 1), g = (int)(idx / (2 * S18_WLP));
+    const int k = i - S18_WPRE;
     float v = 0.f;
     if (k >= 0 && k < KS * 20) {
         const int j = k / 20, cc = k - 20 * j;
-        if (cc < 18) v = src[((int64_t)(g * 18 + co) * 18 + cc) * KS + j];
+        if (cc < 18) v = src[((int64_t)(g * 18 + 16 + c) * 18 + cc) * KS + j];
     }
     _Float16 hi, lo;
     split_f16x3(v, hi, lo);
-    const int64_t base = ((((int64_t)g * S18_NKA + c) * 2) * 64 + l) * 8 + i;
-    dst[base] = hi;
-    dst[base + 64 * 8] = lo;
+    _Float16* line = dst + ((int64_t)(g * 2 + c) * 2) * S18_WLP + i;
+    line[0] = hi;
+    line[S18_WLP] = lo;
 }
 
 // reference Conv1d weight [C_out, C_in/G, 21] -> MFMA A fragments [g][mt][K chunk][hi, lo][lane][8 halves]:
@@ -1291,7 +1340,7 @@ static bool gconv_short_tiles(int64_t T_out, int tt_long, int group_blocks, int 
 bool gconv_f16x3_fits(int64_t T, int C) { return T * C * 4 + (int64_t)300 * C * 4 < ((int64_t)1 << 31); }
 
 // halves of the [g][mt][K chunk][hi, lo][lane][8] fragment table; the 18-channel stride-1 conv keeps a second table behind it:
-// the shifted tile of its two left-over channels (gconv18_shift_kernel)
+// the weight lines of its two left-over channels (gconv18_shift_kernel, pack_gconv_shift18_kernel)
 static size_t gconv_f16x3_main_halves(const GcPackDesc& d) { return (size_t)d.groups * d.mt_n * (d.nk[0] + d.nk[1]) * 2 * 64 * 8; }
 static bool gconv_has_shift18(const GcPackDesc& d) { return d.cig == 18 && d.cog == 18 && d.tapstep == 1 && d.nseg == 1 && d.pitch[0] == 20; }
 
@@ -1299,7 +1348,7 @@ size_t gconv_f16x3_weight_bytes(int C_in, int C_out, int groups, int stride) {
     if (groups <= 0 || C_in % groups || C_out % groups) return 0;
     GcPackDesc d;
     if (!gconv_mfma_desc(C_in / groups, C_out / groups, stride, groups, d)) return 0;
-    return gconv_f16x3_main_halves(d) * sizeof(_Float16) + (gconv_has_shift18(d) ? (size_t)groups * S18_NKA * 2 * 64 * 8 * sizeof(_Float16) : 0);
+    return gconv_f16x3_main_halves(d) * sizeof(_Float16) + (gconv_has_shift18(d) ? (size_t)groups * 4 * S18_WLP * sizeof(_Float16) : 0);
 }
 
 int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C_in, int C_out, int groups, int stride, hipStream_t s) {
@@ -1311,7 +1360,7 @@ int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C_in, int C_ou
     hipLaunchKernelGGL(pack_gconv_mfma_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w_ref, reinterpret_cast<_Float16*>(w_frag), d);
     TAL_CHECK_LAUNCH("tal_pack_gconv_f16x3_weight");
     if (gconv_has_shift18(d)) {
-        const int64_t ts = (int64_t)groups * S18_NKA * 64 * 8;
+        const int64_t ts = (int64_t)groups * 2 * S18_WLP;
         hipLaunchKernelGGL(pack_gconv_shift18_kernel, dim3((unsigned)cdiv(ts, 256)), dim3(256), 0, s, w_ref,
                            reinterpret_cast<_Float16*>(w_frag) + gconv_f16x3_main_halves(d), groups);
         TAL_CHECK_LAUNCH("tal_pack_gconv_f16x3_weight (shifted tile)");
@@ -1336,7 +1385,7 @@ int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias
         const _Float16* wshift = reinterpret_cast<const _Float16*>(w_frag) + gconv_f16x3_main_halves(d);
         const bool shortt = gconv_short_tiles(T, 256, groups / 2, B);
         using LY = GcLayout<18, 1>;
-        const size_t lds = (size_t)2 * 2 * LY::slab(0, shortt ? 64 : 256) * sizeof(_Float16);
+        const size_t lds = ((size_t)2 * 2 * LY::slab(0, shortt ? 64 : 256) + (size_t)2 * 4 * S18_WLP) * sizeof(_Float16);
         auto kern = shortt ? gconv18_shift_kernel<64> : gconv18_shift_kernel<256>;
         static const void* attr_done[2] = {};
         if (attr_done[shortt] != reinterpret_cast<const void*>(kern)) {
@@ -1399,6 +1448,12 @@ __global__ void pack_gconv_kernel(const float* __restrict__ src, float* __restri
 }
 
 }  // namespace tal
+
+#ifdef GC_TIMELINE
+extern "C" int tal_debug_gconv_timeline(void* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tal::g_gc_timeline), sizeof(tal::g_gc_timeline)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int tal_pack_gconv_weight(const float* w_ref, float* w_packed, int c_out, int c_in_per_group, int ksize,
                                      int groups, void* stream) {

@@ -115,6 +115,7 @@ enum Option {
     OPT_GCONV_SHORT_BELOW,        // grouped convs take 64-step tiles while the long tiles give a CU fewer workgroups than this (default 4)
     OPT_GCONV_NO_SHIFT18,         // 18-channel TDSBlock conv (split form in / out) on the two-M-tile kernel instead of the time-shift-packed one
     OPT_GCONV_GRID_XYZ,           // matrix-core grouped convs on the plain (time tile, group block, item) grid instead of the XCD-aware 1-D order
+    OPT_GEMM_W64_STAGGER,         // 256 x 160 dense launches: odd first-round workgroups start this many percent of a tile's duration late (default 0)
     OPT_COUNT
 };
 int opt(Option o);
@@ -173,6 +174,9 @@ struct GemmArgs {
     int f16x3, out_split;
     int res_split;     // mode 2: `res` is in the split form (hi / lo halves, fp32-row geometry); rebuilt as hi + lo * 2^-11
     int* range_flag;   // out_split: raised when an output value lies outside the fp16 range (may be NULL)
+    // gemm_w64_kernel: the odd workgroups among the first `stagger_blocks` (the launch's first round, one per CU) start
+    // `stagger_ticks` (100 MHz) late, so that half of the chip is in its K loop while the other half writes its tiles
+    int stagger_ticks, stagger_blocks;
 };
 // mode 0: acc+b | 1: relu(acc+b) | 2: res + alpha*(acc+b) | 3: alpha*(acc+b) | 4: row arg-max partials of acc+b
 int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s);

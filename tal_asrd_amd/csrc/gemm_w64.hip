@@ -61,6 +61,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w64_kernel(const GemmArgs g) {
     constexpr int NSUB = W_NSUB, BM = W_BM, BN = W_BN, PER_WAVE = W_PER_WAVE, A_T = W_AT, BUF_FLOATS = W_BUF_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[W_NBUF * W_BUF_FLOATS];      // 159,744 B: one workgroup per CU
 
+    if (g.stagger_ticks > 0 && blockIdx.x < (unsigned)g.stagger_blocks && (blockIdx.x & 1u)) {
+        // (every tile of a round runs the same K loop, so all 256 workgroups reach their epilogue -- a 42 MB write burst with the
+        //  matrix pipes idle -- together; a late start of every other first-round workgroup puts the two halves of the chip out
+        //  of phase for the whole launch: later workgroups start as CUs free up)
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)g.stagger_ticks) __builtin_amdgcn_s_sleep(64);
+    }
     // XCD-remapped tile index; SPLITK launches carry the whole-round tiles and, behind them, the K slices of the rest
     const bool is_slice = SPLITK && blockIdx.x >= (unsigned)g.tile_base;
     const unsigned sbid = blockIdx.x - (unsigned)g.tile_base;
@@ -253,7 +260,14 @@ static void launch_w64_mode(const GemmArgs& g, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL((gemm_w64_kernel<MODE, SPLITK, 0>), grid, dim3(256), 0, s, g);
 }
 
-void launch_gemm_w64(const GemmArgs& g, int mode, bool splitk, dim3 grid, hipStream_t s) {
+void launch_gemm_w64(const GemmArgs& g0, int mode, bool splitk, dim3 grid, hipStream_t s) {
+    GemmArgs g = g0;
+    const int pct = opt(OPT_GEMM_W64_STAGGER);
+    if (pct > 0 && grid.x >= 2u * (unsigned)device_cus()) {          // (at least two rounds: one round has nothing to be out of phase with)
+        const double tile_us = 1.39 * (g.K / 32) + 12.0;              // scripts/bench_gemm_f16x3_fit.py: K step + fixed cost per round
+        g.stagger_ticks = (int)(tile_us * pct);                       // us * pct / 100 * 100 ticks per us
+        g.stagger_blocks = device_cus();
+    }
     if (splitk) {
         switch (mode) {
             case 0: launch_w64_mode<0, true>(g, grid, s); break;

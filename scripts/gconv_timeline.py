@@ -8,8 +8,8 @@ import numpy as np, torch
 from tal_asrd_amd import ops, _native as N
 lib = N.lib()
 dev = torch.device("cuda:0")
-G, cg = 80, 18
-for B, T in ((1, 44983),):
+G = 80
+for B, T, cg in ((1, 179991, 10), (1, 89986, 14), (1, 44983, 18)):
     C = G * cg
     x = torch.randn(B, T, C, device=dev)
     w = torch.randn(C, cg, 21, device=dev) / (21 * cg) ** 0.5
@@ -24,12 +24,17 @@ for B, T in ((1, 44983),):
     t = buf.reshape(8, 4, 4096).astype(np.int64)
     t0 = t[0].min()
     d = (t - t0) * 0.01          # us (100 MHz counter)
-    print("B=%d T=%d: first 4096 workgroups; kernel start -> last stamp %.1f us" % (B, T, d.max()))
-    ph = ["fill (loads + ds_write + zeroing)", "barrier", "phase A (shifted tile)", "phase B weights", "phase B blocks", "barriers + held-back rows", "store phase"]
-    for h in (0, 1):
-        print("  waves with h = %d (group 0 and 1)" % h)
+    print("cg=%d B=%d T=%d: first 4096 workgroups; kernel start -> last stamp %.1f us" % (cg, B, T, d.max()))
+    if cg == 18:
+        ph = ["fill (loads + ds_write + zeroing)", "barrier", "phase A (shifted tile)", "phase B weights", "phase B blocks", "barriers + held-back rows", "store phase"]
+    else:          # gconv_mfma_kernel: no stamp 3 (2 -> 4 = weight / bias loads)
+        t[3] = t[2]
+        d[3] = d[2]
+        ph = ["fill (loads + ds_write + zeroing)", "barrier", "--", "weight / bias loads", "block loop", "barrier", "store phase"]
+    for h in ((0, 1) if cg == 18 else (0,)):
+        print("  waves with h = %d (group 0 and 1)" % h if cg == 18 else "  all waves")
         for i in range(7):
-            seg = (d[i + 1] - d[i])[h::2].reshape(-1)
+            seg = (d[i + 1] - d[i])[h::2].reshape(-1) if cg == 18 else (d[i + 1] - d[i]).reshape(-1)
             print("   %-36s mean %6.2f us   median %6.2f   p90 %6.2f" % (ph[i], seg.mean(), np.median(seg), np.percentile(seg, 90)))
     tot = d[7].max(axis=0) - d[0].min(axis=0)
     print("   workgroup lifetime                   mean %6.2f us   median %6.2f   p90 %6.2f;  starts spread over %.1f us" % (tot.mean(), np.median(tot), np.percentile(tot, 90), d[0].max()))

@@ -453,6 +453,19 @@ __device__ __forceinline__ f16x8 gconv_frag(const _Float16* p, const _Float16* p
     return *reinterpret_cast<const f16x8u*>(p);
 }
 
+// (ablation build -DGC_TIMELINE: lane 0 of every wave of the first 4096 workgroups stamps the 100 MHz wall clock at the phase
+//  boundaries; scripts/gconv_timeline.py reads them through tal_debug_gconv_timeline.  Not part of the product library.)
+#ifdef GC_TIMELINE
+__device__ unsigned long long g_gc_timeline[8 * 4 * 4096];
+#define GC_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                             \
+            g_gc_timeline[((i) * 4 + (threadIdx.x >> 6)) * 4096 + blockIdx.x] = wall_clock64();       \
+    } while (0)
+#else
+#define GC_STAMP(i)
+#endif
+
 // Which (batch item, time tile, group block) a workgroup takes.  n_tt > 0: a 1-D grid in the XCD-aware order -- group blocks
 // fastest, an XCD walks whole time tiles: a row of the activations is C * 4 bytes shared by all group blocks, and a workgroup's
 // 36-56 channels are 144-224 bytes that start and end inside 128-byte lines, so neighbouring group blocks READ and WRITE the same
@@ -507,6 +520,7 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
     const int w = wave_id();
     const float* xb = x + (int64_t)b * T_in * C_in;
     float* yb = y + (int64_t)b * T_out * C_out;
+    GC_STAMP(0);
 
     // ---- slab load: thread = (input row inside a pass, 16-byte column piece): 16-byte global loads (GB*CIG contiguous
     // floats per row), all passes in flight, split, 4-byte LDS stores ----
@@ -605,7 +619,9 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
                     *reinterpret_cast<f16x2*>(slab + (i / tail2) * GS + base + rows * pt + 2 * (i % tail2)) = z2;
         }
     }
+    GC_STAMP(1);
     __syncthreads();
+    GC_STAMP(2);
 
     // ---- units = (group, 16-channel M tile); a wave owns one unit (or a time slice of one) at a time ----
     constexpr int NU = GB * MT, NB = TT / 16;
@@ -632,6 +648,8 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
         for (int i = 0; i < 4; ++i)
             if (i < nvalid) bv[i] = bias[g * COG + ch0 + i];
         const int tbeg = part * NBW, tend = (part + 1) * NBW;
+        asm volatile("" :: "v"(wh[NKS - 1]), "v"(wl[NKS - 1]));
+        GC_STAMP(4);
         // fragment of K chunk c for output column (16 tb + col): segment base + (16 tb + col) * pitch + 8 kg + 32 ks
         // (LY::PERM: k group kg of the chunks below LY::NKP sits 64 (kg & 1) + 32 (kg >> 1) halves into its block of 128)
         constexpr int NKP = LY::NKP;
@@ -828,12 +846,14 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
         }
         if (SPLIT) note_range(am, range_flag);
     }
+    GC_STAMP(5);
     if constexpr (STAGED) {
         // ---- the tile leaves LDS as pieces of PW words (8 channels from a multiple of 8, or 4 from a multiple of 4 -- g0 * COG
         // is one -- so a piece never crosses a 32-channel block).  thread = (row inside a pass, piece): the lanes of a store
         // instruction walk along rows, a row's pieces sit in its 2-3 consecutive 128-byte lines (one row per lane, 64 lines per
         // instruction, made this phase 23-36 % of the kernel) ----
         __syncthreads();
+        GC_STAMP(6);
         constexpr int CW = GB * COG, PW = CW % 8 == 0 ? 4 : 2, NPC = CW / (2 * PW), WPG = COG / 2, NPR = 2 * NPC;
         constexpr int RP = 256 / NPR, NPO = (TT + RP - 1) / RP;
         typedef unsigned u32xp __attribute__((ext_vector_type(PW)));
@@ -866,6 +886,7 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
             }
         }
     }
+    GC_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -888,19 +909,6 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
 // An output's chain of MFMAs depends on its shift s = (t - tile start) % 8 only, and tile starts are multiples of 64: long
 // (256) and short (64) tiles give bit-identical results.  Channels 16, 17 differ from gconv_mfma_kernel's in the last bits
 // (other grouping of the products into K chunks), channels 0-15 are the same chains.
-// (ablation build -DGC_TIMELINE: lane 0 of every wave of the first 4096 workgroups stamps the 100 MHz wall clock at the phase
-//  boundaries; scripts/gconv_timeline.py reads them through tal_debug_gconv_timeline.  Not part of the product library.)
-#ifdef GC_TIMELINE
-__device__ unsigned long long g_gc_timeline[8 * 4 * 4096];
-#define GC_STAMP(i)                                                                                   \
-    do {                                                                                              \
-        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                             \
-            g_gc_timeline[((i) * 4 + (threadIdx.x >> 6)) * 4096 + blockIdx.x] = wall_clock64();       \
-    } while (0)
-#else
-#define GC_STAMP(i)
-#endif
-
 constexpr int S18_NKA = 18;      // K chunks of the shifted tile: (21 + 7) rows x 20 halves = 560 -> 576
 constexpr int S18_SH = 8;        // shifts per channel
 // The shifted tile's A fragments are NOT loaded from memory (18 K chunks x hi / lo x 1 KB per wave, mostly zeros, at the 25-60

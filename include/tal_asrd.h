@@ -381,7 +381,7 @@ size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H, int FF, i
 int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int64_t n_gen, int sync, void* stream);
 /* 1: the context's latest sync 2 / 3 step has delivered; 0: not after wait_ms milliseconds (0 = one look); < 0: error. */
 int tal_greedy_step_poll(const tal_greedy_ctx* c, int wait_ms);
-/* The same step for G sessions (1 <= G <= 8) in SHARED launches: one chain of 34 launches advances every session by one token
+/* The same step for G sessions (1 <= G <= 16) in SHARED launches: one chain of 34 launches advances every session by one token
  * (the decode loop of System.generate_unaligned is batch 1 -- .item() at tal/asr/system.py:331,411,417 --, so a corpus of
  * episodes is decoded as concurrent sessions; a chain of small dependent launches per session tops out at the device's four
  * hardware queues).  Each session keeps its own context (prefix, window K / V^T, workspace, tickets, pinned result buffer);

@@ -39,7 +39,7 @@ print("one at a time: %d episodes x %.0f s, %d decode steps, %.3f s = %.0f frame
       % (n_ep, seconds, steps, t_solo, n_ep * frames / t_solo, 1e3 * t_solo / steps), flush=True)
 modes = [(k, 1) for k in (1, 2, 4, 8, 16) if k <= n_ep]
 # sessions advanced in step through SHARED launches (tal_greedy_step_multi_fwd): (host threads, sessions per group)
-modes += [(t, gsz) for t, gsz in ((1, 8), (2, 4), (2, 8), (4, 2), (4, 4), (3, 8), (4, 8)) if gsz <= n_ep]
+modes += [(t, gsz) for t, gsz in ((1, 8), (2, 4), (4, 2), (1, 16), (2, 8), (4, 4), (2, 16)) if gsz <= n_ep]
 for k, gsz in modes:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     many = system.transcribe_unaligned_many(eps, streams=k, group=gsz)

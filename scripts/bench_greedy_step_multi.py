@@ -25,10 +25,10 @@ enc = asr.encode(torch.from_numpy(synth.synth_audio_batch(1, L, 7)).to(dev).half
 lib = N.lib()
 rng = np.random.default_rng(3)
 sessions = []
-for k in range(8):
+for k in range(16):
     toks = torch.from_numpy(rng.integers(3, 10000, size=U + 8).astype(np.int64)).to(dev)
     s = _GreedySession(asr, toks, 512)
-    sl = slice(30 * k, 30 * k + 357)
+    sl = slice(20 * k, 20 * k + 357)
     s.set_window({"encoder_out": enc["encoder_out"][:, sl].contiguous(), "encoder_padding_mask": enc["encoder_padding_mask"][:, sl].contiguous()})
     sessions.append(s)
 reps = 300
@@ -37,9 +37,9 @@ for s in sessions[:1]:
     t0 = time.perf_counter()
     for _ in range(reps): s.step(0, U)
     print("one session, own launches, prefix %d: %.3f ms per step" % (U, 1e3 * (time.perf_counter() - t0) / reps), flush=True)
-for G in (1, 2, 4, 8):
-    ctxs = (C.POINTER(N.GreedyCtx) * 8)(*[C.pointer(s.ctx) for s in sessions])
-    hs = (C.c_int64 * 8)(*([0] * 8)); ng = (C.c_int64 * 8)(*([U] * 8))
+for G in (1, 2, 4, 8, 12, 16):
+    ctxs = (C.POINTER(N.GreedyCtx) * 16)(*[C.pointer(s.ctx) for s in sessions])
+    hs = (C.c_int64 * 16)(*([0] * 16)); ng = (C.c_int64 * 16)(*([U] * 16))
     h = N.stream_handle()
     def step():
         N.check(lib.tal_greedy_step_multi_fwd(ctxs, hs, ng, G, h))
@@ -55,3 +55,31 @@ for G in (1, 2, 4, 8):
     t_call = (time.perf_counter() - t1) / 50
     torch.cuda.synchronize()
     print("%d sessions, shared launches: %.3f ms per merged step = %.3f ms per token; the C call alone (34 launches enqueued) %.3f ms" % (G, 1e3 * dt, 1e3 * dt / G, 1e3 * t_call), flush=True)
+
+# two half-groups on two streams, both steps enqueued by ONE host thread before either result is awaited
+s2 = torch.cuda.Stream()
+sessB = []
+with torch.cuda.stream(s2):
+    for k in range(8):
+        toks = torch.from_numpy(rng.integers(3, 10000, size=U + 8).astype(np.int64)).to(dev)
+        s = _GreedySession(asr, toks, 512)
+        sl = slice(30 * k, 30 * k + 357)
+        s.set_window({"encoder_out": enc["encoder_out"][:, sl].contiguous(), "encoder_padding_mask": enc["encoder_padding_mask"][:, sl].contiguous()})
+        sessB.append(s)
+    hB = N.stream_handle()
+torch.cuda.synchronize()
+for G in (2, 4, 8):
+    cA = (C.POINTER(N.GreedyCtx) * 8)(*[C.pointer(s.ctx) for s in sessions[:8]])
+    cB = (C.POINTER(N.GreedyCtx) * 8)(*[C.pointer(s.ctx) for s in sessB])
+    hs = (C.c_int64 * 8)(*([0] * 8)); ng = (C.c_int64 * 8)(*([U] * 8))
+    hA = sessions[0]._stream
+    def step2():
+        N.check(lib.tal_greedy_step_multi_fwd(cA, hs, ng, G, hA))
+        N.check(lib.tal_greedy_step_multi_fwd(cB, hs, ng, G, hB))
+        for s in sessions[:G] + sessB[:G]:
+            while not s.ready(50): pass
+    for _ in range(20): step2()
+    t0 = time.perf_counter()
+    for _ in range(reps): step2()
+    dt = (time.perf_counter() - t0) / reps
+    print("2 x %d sessions on two streams, one host thread: %.3f ms per pair of merged steps = %.3f ms per token" % (G, 1e3 * dt, 1e3 * dt / (2 * G)), flush=True)

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TAL_ASRD_LIB", os.path.join(_HERE, "libtal_asrd_hip.s
 TAL_MAX_STAGES = 4
 TAL_MAX_DEPTH = 8
 TAL_TDS_EXACT_F32 = 1
-TAL_GROUP_MAX = 8       # sessions per merged decode step (csrc/common.h)
+TAL_GROUP_MAX = 16      # sessions per merged decode step (csrc/common.h)
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 

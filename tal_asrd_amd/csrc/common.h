@@ -258,7 +258,7 @@ struct AttnArgs {
 };
 
 // several independent problems in one launch (the decode steps of several sessions): argument structs by value
-constexpr int TAL_GROUP_MAX = 8;
+constexpr int TAL_GROUP_MAX = 16;     // (16 argument sets of <= 152 bytes stay well inside the 4 KB kernel argument segment)
 template <typename T>
 struct ArgPack {
     T a[TAL_GROUP_MAX];

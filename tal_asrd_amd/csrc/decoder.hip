@@ -1459,6 +1459,26 @@ extern "C" int tal_unaligned_consume(tal_unaligned_state* st, int64_t token, con
     return flags;
 }
 
+// what the control flow asked for and the library can do itself: the window as a view of the episode-wide K | V table, the
+// rewritten prefix from the (pinned) host token stream.  Clears the flags it served.
+static int unaligned_serve(tal_unaligned_state* st, tal_greedy_ctx* c, int64_t dev_cap, void* stream) {
+    if ((st->flags & TAL_UNALIGNED_WINDOW_MOVED) && !(st->flags & TAL_UNALIGNED_DONE) && c->kv_all && st->chunk_start >= 0 &&
+        st->chunk_start + c->S <= c->enc_frames) {
+        const int rc = tal_greedy_set_window(c, st->chunk_start, stream);
+        if (rc) return rc;
+        st->flags &= ~TAL_UNALIGNED_WINDOW_MOVED;
+    }
+    if ((st->flags & TAL_UNALIGNED_PREFIX_REWRITTEN) && !(st->flags & (TAL_UNALIGNED_DONE | TAL_UNALIGNED_WINDOW_MOVED)) && st->gen_pinned &&
+        st->n <= dev_cap) {
+        if (hipMemcpyAsync(c->tokens, st->gen, (size_t)st->n * sizeof(int64_t), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+            set_error("tal_unaligned_group_run: prefix upload failed: %s", hipGetErrorString(hipGetLastError()));
+            return TAL_EHIP;
+        }
+        st->flags &= ~TAL_UNALIGNED_PREFIX_REWRITTEN;
+    }
+    return TAL_OK;
+}
+
 extern "C" int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greedy_ctx* const* ctxs, const int64_t* dev_cap, int G,
                                        int max_steps, void* stream) {
     TAL_CHECK_ARG(st && ctxs && dev_cap && G >= 1 && G <= TAL_GROUP_MAX && max_steps >= 1, "tal_unaligned_group_run: bad argument");
@@ -1467,21 +1487,9 @@ extern "C" int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greed
         bool go = true;
         for (int i = 0; i < G; ++i) {
             TAL_CHECK_ARG(st[i] && ctxs[i], "tal_unaligned_group_run: null session %d", i);
-            // what the control flow asked for and the library can do itself: the window as a view of the episode-wide K | V
-            // table, the rewritten prefix from the (pinned) host token stream
-            if ((st[i]->flags & TAL_UNALIGNED_WINDOW_MOVED) && !(st[i]->flags & TAL_UNALIGNED_DONE) && ctxs[i]->kv_all && st[i]->chunk_start >= 0 &&
-                st[i]->chunk_start + ctxs[i]->S <= ctxs[i]->enc_frames) {
-                const int rc = tal_greedy_set_window(ctxs[i], st[i]->chunk_start, stream);
+            {
+                const int rc = unaligned_serve(st[i], ctxs[i], dev_cap[i], stream);
                 if (rc) return rc;
-                st[i]->flags &= ~TAL_UNALIGNED_WINDOW_MOVED;
-            }
-            if ((st[i]->flags & TAL_UNALIGNED_PREFIX_REWRITTEN) && !(st[i]->flags & (TAL_UNALIGNED_DONE | TAL_UNALIGNED_WINDOW_MOVED)) && st[i]->gen_pinned &&
-                st[i]->n <= dev_cap[i]) {
-                if (hipMemcpyAsync(ctxs[i]->tokens, st[i]->gen, (size_t)st[i]->n * sizeof(int64_t), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
-                    set_error("tal_unaligned_group_run: prefix upload failed: %s", hipGetErrorString(hipGetLastError()));
-                    return TAL_EHIP;
-                }
-                st[i]->flags &= ~TAL_UNALIGNED_PREFIX_REWRITTEN;
             }
             if (st[i]->flags) { go = false; continue; }
             if (st[i]->n + 1 >= st[i]->gen_cap || st[i]->n_rec + 1 >= st[i]->rec_cap || st[i]->n + 1 > dev_cap[i]) {
@@ -1508,6 +1516,10 @@ extern "C" int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greed
             const float* ph = ctxs[i]->picked_host;
             rc = tal_unaligned_consume(st[i], (int64_t)__builtin_bit_cast(int32_t, ph[0]), ph + 1, ctxs[i]->S);
             if (rc < 0) return rc;
+            if (st[i]->flags) {
+                rc = unaligned_serve(st[i], ctxs[i], dev_cap[i], stream);
+                if (rc) return rc;
+            }
             flagged = flagged || st[i]->flags != 0;
         }
         if (flagged) return step + 1;

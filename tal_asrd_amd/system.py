@@ -291,6 +291,11 @@ class _UnalignedRun:
                 self.session_window = self.window
         st.flags &= N.UNALIGNED_DONE
 
+    def rebind_stream(self):
+        """The run continues on the CURRENT stream (it was started on another one and handed over with nothing in flight)."""
+        if self.session is not None:
+            self.session._stream = N.stream_handle()
+
     def can_merge(self):
         """May the next step run inside a merged launch (tal_greedy_group_ok)?  Never the first step (module API)."""
         return self.st.it > 0 and bool(self.session.lib.tal_greedy_group_ok(self.session._ctx_ref, self.st.history_start, self.st.n))
@@ -351,7 +356,7 @@ class System:
 
     # ------------------------------------------------------------------ several episodes in flight
     @torch.no_grad()
-    def transcribe_unaligned_many(self, episodes, streams=8, group=1, **kw):
+    def transcribe_unaligned_many(self, episodes, streams=8, group=1, stats=None, **kw):
         """`transcribe_unaligned` over a list of episodes with several decode sessions in flight -- the loop the reference runs
         this path in (tal/asr/system.py:625-742 per test item, one after the other).  Each session is the ordinary sliding-window
         decode with its own context (prefix buffer, workspace, window K / V^T, pinned result word); they share the weights.
@@ -362,13 +367,16 @@ class System:
         four kernels at a time (its four hardware queues): 3.0x one session at eight streams, a ceiling of 3.9x
         (scripts/ubench/launch_rate.hip, profiles/r3_ubench_launch_rate.txt).
 
-        group > 1: `streams` host threads, each advancing `group` (<= 8) sessions IN STEP through SHARED launches
+        group > 1: `streams` host threads, each advancing `group` (<= 16) sessions IN STEP through SHARED launches
         (tal_greedy_step_multi_fwd: one chain of 34 launches per generated token of every session of the group, each launch
         running the single-session kernel body per session).  A session whose next step does not take the merged kernels' forms
         (first step, prefix beyond 192 tokens, window of 64 frames or fewer) takes that step on launches of its own, in the same
         stream.  While one thread runs the host-side control flow on its group's results, the other threads' steps keep the GPU busy.
 
         An episode's waveform is uploaded on its session's stream (pinned host memory: the copy runs under the other sessions' compute).
+
+        stats (group > 1): a dict that receives counters of the group loop (calls of tal_unaligned_group_run, merged steps, steps
+        taken alone, flags that came back to Python) -- measurement only.
 
         episodes: list of (audio [1, L] float tensor -- host (pinned or not) or device --, audio_lens LongTensor [1]).
         Returns [(utterance dicts, generated, alignments)] in episode order, identical to the solo runs in either mode."""
@@ -411,56 +419,99 @@ class System:
         group = max(1, min(int(group), N.TAL_GROUP_MAX))
         lib = N.lib()
 
+        import queue
+        ready = queue.Queue(maxsize=max(2, group))          # episodes whose session is past its first step
+        n_workers = max(1, min(int(streams), (len(episodes) + group - 1) // group)) if group > 1 else 0
+
+        def producer():
+            """Everything an episode needs before it can join a group -- upload, encode, the episode-wide K | V table, the first
+            step through the module API, its session's buffers -- on a stream of its own, while the groups keep stepping."""
+            stream = torch.cuda.Stream(device=dev)
+            i = -1
+            try:
+                with torch.cuda.device(dev), torch.cuda.stream(stream):
+                    for i, (audio, lens) in enumerate(episodes):
+                        if errors:
+                            break
+                        x = audio.to(dev, non_blocking=True)
+                        prime = torch.full((1, 1), self.tokenizer.eos_token_id, dtype=torch.int64, device=dev)
+                        run = _UnalignedRun(self, x, prime, lens, 357, **kw)
+                        if not run.done:
+                            run.prepare()
+                            run.consume(*run.step_alone())
+                        stream.synchronize()               # (handed to another stream: nothing of the start-up may be in flight)
+                        ready.put((i, run))
+            except BaseException as e:      # noqa: B902 -- reported to the caller below
+                errors.append((i, e))
+            finally:
+                for _ in range(n_workers):
+                    ready.put(None)
+
         def group_worker():
             stream = torch.cuda.Stream(device=dev)
             slots = []                       # [episode index, _UnalignedRun]
-            G8 = N.TAL_GROUP_MAX
-            st_arr, ctx_arr, cap_arr = (C.POINTER(N.UnalignedState) * G8)(), (C.POINTER(N.GreedyCtx) * G8)(), (C.c_int64 * G8)()
-            i = -1
+            G16 = N.TAL_GROUP_MAX
+            st_arr, ctx_arr, cap_arr = (C.POINTER(N.UnalignedState) * G16)(), (C.POINTER(N.GreedyCtx) * G16)(), (C.c_int64 * G16)()
+            i, drained = -1, False
             with torch.cuda.device(dev), torch.cuda.stream(stream):
                 handle = N.stream_handle()
                 try:
                     while True:
-                        while len(slots) < group and not errors:          # refill the free slots
-                            with take:
-                                i = nxt[0]
-                                nxt[0] += 1
-                            if i >= len(episodes):
+                        while len(slots) < group and not drained and not errors:      # refill the free slots with episodes that are ready
+                            try:
+                                item = ready.get(block=not slots)                     # (wait only when there is nothing to step)
+                            except queue.Empty:
                                 break
-                            audio, lens = episodes[i]
-                            x = audio.to(dev, non_blocking=True)
-                            prime = torch.full((1, 1), self.tokenizer.eos_token_id, dtype=torch.int64, device=dev)
-                            slots.append([i, _UnalignedRun(self, x, prime, lens, 357, **kw)])
+                            if item is None:
+                                drained = True
+                                break
+                            i = item[0]
+                            item[1].rebind_stream()
+                            slots.append(list(item))
                         for sl in slots:
                             if sl[1].done:
                                 results[sl[0]] = self._episode_utterances(*sl[1].result())
                         slots = [sl for sl in slots if not sl[1].done]
-                        if not slots or errors:
+                        if errors or (not slots and drained):
                             break
+                        if not slots:
+                            continue
                         runs = [sl[1] for sl in slots]
                         merged, alone = [], []
                         for r in runs:
-                            if r.st.flags or r.st.it == 0 or r.session is None:
+                            if r.st.flags or r.session is None:
                                 r.prepare()               # (whatever the control flow asked for: window, prefix upload, room)
                             (merged if r.can_merge() else alone).append(r)
                         if len(merged) < 2:
                             alone, merged = alone + merged, []
-                        for r in alone:                   # first steps, and steps the merged launches do not take
+                        for r in alone:                   # steps the merged launches do not take
                             r.prepare()                   # (room for the appended token: nothing else checks it on this path)
                             r.consume(*r.step_alone())
                         if merged:
                             for k, r in enumerate(merged):
                                 st_arr[k], ctx_arr[k], cap_arr[k] = C.pointer(r.st), C.pointer(r.session.ctx), r.gen_dev.numel()
-                            rc = lib.tal_unaligned_group_run(st_arr, ctx_arr, cap_arr, len(merged), 4 if alone else 64, handle)
+                            # (a free slot: come back soon to look for a ready episode)
+                            limit = 4 if alone else (16 if len(slots) < group and not drained else 64)
+                            rc = lib.tal_unaligned_group_run(st_arr, ctx_arr, cap_arr, len(merged), limit, handle)
                             if rc < 0:
                                 N.check(rc, "tal_unaligned_group_run")
+                            if stats is not None:
+                                stats["calls"] = stats.get("calls", 0) + 1
+                                stats["steps"] = stats.get("steps", 0) + rc
+                                stats["sessions"] = stats.get("sessions", 0) + rc * len(merged)
+                                stats["alone_steps"] = stats.get("alone_steps", 0) + len(alone)
+                                for r in merged:
+                                    if r.st.flags:
+                                        stats["flag_%d" % r.st.flags] = stats.get("flag_%d" % r.st.flags, 0) + 1
                     stream.synchronize()
                 except BaseException as e:      # noqa: B902 -- reported to the caller below
                     errors.append((i, e))
+                finally:
+                    while not drained:          # (after an error: let the producer finish -- it may be blocked on a full queue)
+                        drained = ready.get() is None
 
         if group > 1:
-            n_threads = max(1, min(int(streams), (len(episodes) + group - 1) // group))
-            threads = [threading.Thread(target=group_worker, daemon=True) for _ in range(n_threads)]
+            threads = [threading.Thread(target=producer, daemon=True)] + [threading.Thread(target=group_worker, daemon=True) for _ in range(n_workers)]
         else:
             threads = [threading.Thread(target=worker, daemon=True) for _ in range(max(1, min(int(streams), len(episodes))))]
         for t in threads:

@@ -197,3 +197,21 @@ def test_merged_step_equals_solo_step_bit_for_bit(asr_weights):
             assert s.ready(20000)
             t2, r2 = s.result()
             assert t2 == tok and np.array_equal(r2, row) and int(s.gen_dev[U]) == appended
+
+
+def test_a_failing_episode_ends_the_whole_call(asr_weights):
+    """An episode whose start-up raises (a waveform too short for the encoder) ends transcribe_unaligned_many with an error that
+    names it -- in every mode, without leaving a thread waiting for the others."""
+    from tal_asrd_amd import ASRModel, synth
+    from tal_asrd_amd.system import System
+    from tal_asrd_amd.tokenizer import SynthTokenizer
+    dev = torch.device("cuda:0")
+    asr = _load(ASRModel("2x", num_speakers=6008, vocab_size=10000, use_speaker_head=True), asr_weights, dev)
+    system = System(asr, tokenizer=SynthTokenizer(10000))
+    good = [(torch.from_numpy(synth.synth_audio_batch(1, 40 * 16000, 77 + k)), torch.tensor([40 * 16000])) for k in range(3)]
+    bad = (torch.zeros(1, 3000), torch.tensor([3000]))
+    for streams, group in ((2, 1), (1, 4), (2, 2)):
+        with pytest.raises(RuntimeError, match="episode 2 failed"):
+            system.transcribe_unaligned_many(good[:2] + [bad] + good[2:], streams=streams, group=group)
+    out = system.transcribe_unaligned_many(good, streams=2, group=2)          # ... and the next call is unaffected
+    assert len(out) == 3 and all(o is not None for o in out)

@@ -1483,6 +1483,14 @@ extern "C" int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greed
                                        int max_steps, void* stream) {
     TAL_CHECK_ARG(st && ctxs && dev_cap && G >= 1 && G <= TAL_GROUP_MAX && max_steps >= 1, "tal_unaligned_group_run: bad argument");
     int64_t hs[TAL_GROUP_MAX], ng[TAL_GROUP_MAX];
+#ifdef TAL_GROUP_TIMING      // (ablation build: where a merged step's wall time goes, printed every 2000 steps)
+    static thread_local double t_launch = 0, t_poll = 0, t_consume = 0, t_pre = 0;
+    static thread_local long n_steps = 0, n_sess = 0;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+#define GT(var, expr) do { const double t0__ = now(); expr; var += now() - t0__; } while (0)
+#else
+#define GT(var, expr) do { expr; } while (0)
+#endif
     for (int step = 0; step < max_steps; ++step) {
         bool go = true;
         for (int i = 0; i < G; ++i) {
@@ -1503,21 +1511,29 @@ extern "C" int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greed
             ng[i] = st[i]->n;
         }
         if (!go) return step;
-        int rc = tal_greedy_step_multi_fwd(ctxs, hs, ng, G, stream);
+        int rc;
+        GT(t_launch, rc = tal_greedy_step_multi_fwd(ctxs, hs, ng, G, stream));
         if (rc) return rc;
+#ifdef TAL_GROUP_TIMING
+        n_steps += 1; n_sess += G;
+        if (n_steps % 2000 == 0)
+            fprintf(stderr, "[group timing] %ld steps, %.2f sessions per step: launch %.1f us, poll %.1f us, consume + serve %.1f us per step\n", n_steps,
+                    (double)n_sess / n_steps, t_launch / n_steps, t_poll / n_steps, t_consume / n_steps);
+#endif
         bool flagged = false;
         for (int i = 0; i < G; ++i) {
-            const int got = tal_greedy_step_poll(ctxs[i], 20000);
+            int got;
+            GT(t_poll, got = tal_greedy_step_poll(ctxs[i], 20000));
             if (got != 1) {
                 const hipError_t e = hipStreamSynchronize((hipStream_t)stream);      // nothing may stay in flight behind an error
                 set_error("tal_unaligned_group_run: session %d: no result after 20 s (stream after the wait: %s)", i, hipGetErrorString(e));
                 return TAL_EHIP;
             }
             const float* ph = ctxs[i]->picked_host;
-            rc = tal_unaligned_consume(st[i], (int64_t)__builtin_bit_cast(int32_t, ph[0]), ph + 1, ctxs[i]->S);
+            GT(t_consume, rc = tal_unaligned_consume(st[i], (int64_t)__builtin_bit_cast(int32_t, ph[0]), ph + 1, ctxs[i]->S));
             if (rc < 0) return rc;
             if (st[i]->flags) {
-                rc = unaligned_serve(st[i], ctxs[i], dev_cap[i], stream);
+                GT(t_consume, rc = unaligned_serve(st[i], ctxs[i], dev_cap[i], stream));
                 if (rc) return rc;
             }
             flagged = flagged || st[i]->flags != 0;

@@ -102,6 +102,26 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const LogmelPlan* __rest
             for (int par = 0; par < 2; ++par) {
                 const f64x2* fq = reinterpret_cast<const f64x2*>(plan->hbasis) + ((int64_t)(j * 2 + par) * NHALF + kq) * 16 + fi;
                 f64x4 r0 = zero, i0 = zero, r1 = zero, i1 = zero;
+                if constexpr (!TWO) {
+                    // short inputs (one 16-frame workgroup per CU at most: nothing else hides a round trip): the 26 basis pairs of
+                    // this (bin tile, parity) are requested up front -- 104 registers -- instead of two per loop iteration, each
+                    // behind the previous one's MFMAs (35 -> ~15 us on a 30-second clip)
+                    constexpr int NQ = NHALF / 4;
+                    f64x2 bq[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) bq[q] = fq[q * 64];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        if (par && q == NQ - 1) break;
+                        const int k = 4 * q;
+                        const int n = 2 * (k + kq) + par, m = NFFT - n;
+                        const int on = n + (n >= HOP ? 1 : 0);
+                        const int om = m + (m >= 2 * HOP ? 2 : 1);
+                        const double x0n = (double)s0[on], x0m = (double)s0[om];
+                        r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0n + x0m, bq[q].x, r0, 0, 0, 0);
+                        i0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0n - x0m, bq[q].y, i0, 0, 0, 0);
+                    }
+                } else
 #pragma unroll 2      // (3 needs more than the 168 registers that keep three workgroups on a CU)
                 for (int k = 0; k < (par ? NHALF - 4 : NHALF); k += 4) {
                     const int n = 2 * (k + kq) + par, m = NFFT - n;   // n <= 207, 193 <= m <= 400

@@ -1484,7 +1484,7 @@ extern "C" int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greed
     TAL_CHECK_ARG(st && ctxs && dev_cap && G >= 1 && G <= TAL_GROUP_MAX && max_steps >= 1, "tal_unaligned_group_run: bad argument");
     int64_t hs[TAL_GROUP_MAX], ng[TAL_GROUP_MAX];
 #ifdef TAL_GROUP_TIMING      // (ablation build: where a merged step's wall time goes, printed every 2000 steps)
-    static thread_local double t_launch = 0, t_poll = 0, t_consume = 0, t_pre = 0;
+    static thread_local double t_launch = 0, t_poll = 0, t_consume = 0, u_max_sum = 0, u_sum = 0;
     static thread_local long n_steps = 0, n_sess = 0;
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 #define GT(var, expr) do { const double t0__ = now(); expr; var += now() - t0__; } while (0)
@@ -1516,9 +1516,14 @@ extern "C" int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greed
         if (rc) return rc;
 #ifdef TAL_GROUP_TIMING
         n_steps += 1; n_sess += G;
+        {
+            int64_t um = 0;
+            for (int i = 0; i < G; ++i) { const int64_t u = ng[i] - hs[i]; um = u > um ? u : um; u_sum += (double)u; }
+            u_max_sum += (double)um;
+        }
         if (n_steps % 2000 == 0)
-            fprintf(stderr, "[group timing] %ld steps, %.2f sessions per step: launch %.1f us, poll %.1f us, consume + serve %.1f us per step\n", n_steps,
-                    (double)n_sess / n_steps, t_launch / n_steps, t_poll / n_steps, t_consume / n_steps);
+            fprintf(stderr, "[group timing] %ld steps, %.2f sessions per step, prefix mean %.1f / longest of a step %.1f tokens: launch %.1f us, poll %.1f us, consume + serve %.1f us per step\n",
+                    n_steps, (double)n_sess / n_steps, u_sum / n_sess, u_max_sum / n_steps, t_launch / n_steps, t_poll / n_steps, t_consume / n_steps);
 #endif
         bool flagged = false;
         for (int i = 0; i < G; ++i) {

@@ -157,12 +157,26 @@ def lib():
             fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        _lib = l
         # measurement scripts select kernels with TAL_OPTIONS="name=value,name,..." (a bare name means 1); the library
-        # itself never reads the environment -- a C caller uses tal_set_option
+        # itself never reads the environment -- a C caller uses tal_set_option.  The whole string is parsed and checked against
+        # the library's option list BEFORE anything is applied or the library is published: a malformed value raises here and the
+        # next lib() call raises again, instead of running on half of the switches.
+        pending = []
         for item in filter(None, (x.strip() for x in os.environ.get("TAL_OPTIONS", "").split(","))):
             name, _, val = item.partition("=")
-            set_option(name.strip(), int(val) if val.strip() else 1)
+            name = name.strip()
+            try:
+                value = int(val) if val.strip() else 1
+            except ValueError:
+                raise NativeError("TAL_OPTIONS: %r is not name=integer" % item) from None
+            probe = C.c_int()
+            if l.tal_get_option(name.encode(), C.byref(probe)) != 0:
+                raise NativeError("TAL_OPTIONS: unknown option %r" % name)
+            pending.append((name, value))
+        for name, value in pending:
+            if l.tal_set_option(name.encode(), value) != 0:
+                raise NativeError("TAL_OPTIONS: tal_set_option(%s, %d) failed: %s" % (name, value, l.tal_last_error().decode()))
+        _lib = l
     return _lib
 
 

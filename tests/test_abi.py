@@ -204,3 +204,24 @@ def test_tiled_entry_points_agree_with_the_python_plan():
         need = lib.tal_tds_tiled_workspace_bytes(C.byref(d), T, tile)
         assert need >= lib.tal_tds_workspace_bytes(C.byref(d), 1, longest) + 64
         assert lib.tal_tds_tiled_status_offset(C.byref(d), T, tile) == need - 64
+
+
+def test_malformed_tal_options_never_half_applies():
+    """TAL_OPTIONS is parsed and validated as a whole before the library is published: a bad entry raises on every lib() call
+    of that process and none of the good entries has been applied."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from tal_asrd_amd import _native as N\n"
+            "for _ in range(2):\n"
+            "    try:\n"
+            "        N.lib(); print('loaded')\n"
+            "    except N.NativeError as e:\n"
+            "        print('raised', e)\n"
+            "import ctypes as C\n"
+            "l = C.CDLL(N.LIB_PATH); v = C.c_int(); l.tal_get_option(b'gemm_no_w64', C.byref(v)); print('gemm_no_w64', v.value)\n" % ROOT)
+    for bad in ("gemm_no_w64=1,decode_small_rows=abc", "gemm_no_w64,no_such_switch=1"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TAL_OPTIONS=bad), capture_output=True, text=True, timeout=120).stdout
+        assert out.count("raised") == 2 and "loaded" not in out and "gemm_no_w64 0" in out, out
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TAL_OPTIONS="gemm_no_w64, decode_small_rows=128"), capture_output=True, text=True, timeout=120).stdout
+    assert out.count("loaded") == 2 and "gemm_no_w64 1" in out, out

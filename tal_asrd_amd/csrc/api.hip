@@ -187,7 +187,7 @@ static int64_t conv_out_len(int64_t t) { return t < 21 ? 0 : (t - 21) / 2 + 1; }
 
 using namespace tal;
 
-extern "C" int tal_version(void) { return 300; /* 0.3.0: tal_set_option; tal_attn_pool_fwd half_mode, tal_tds_desc flags (0.2) */ }
+extern "C" int tal_version(void) { return 400; /* 0.4.0: tal_greedy_ctx grew (k_pitch, episode-wide K | V table), merged decode steps, tal_unaligned_*, tal_logmel_f16_fwd; 0.3.0: tal_set_option */ }
 
 // Host-side helper of the decode loop (no device work): ngram_repeat_mask(row, n).sum() of tal/asr/util.py:5-17 -- the number
 // of positions covered by an n-gram that already occurred earlier in the row; like the reference, n-gram starts run to

@@ -528,13 +528,28 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
         const int r0 = tid / CH4, c4 = tid - r0 * CH4;
         const bool active = r0 < RPP;
         int so[2], sp[2];       // per channel pair: constant part of the LDS offset, row pitch
+        int npad[2];            // pad pairs behind this pair: the thread that stores a segment's LAST channel pair of a row also
+                                // zeroes the row's pad columns (finite bytes under zero weights) -- no separate pass over the slab
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int ch = c4 * 4 + 2 * q, gl = ch / CIG, ci = ch - gl * CIG;
             const int seg = (STRIDE == 1 && ci >= LY::nch(0)) ? 1 : 0;          // channel split (18 channels per group)
             so[q] = gl * GS + (seg ? SL0 + ci - LY::nch(0) : ci);
             sp[q] = seg ? P1 : P0;
+            const int cis = seg ? ci - LY::nch(0) : ci, nc = LY::nch(seg);
+            npad[q] = cis + 2 == nc ? (sp[q] - nc) / 2 : 0;
         }
+        constexpr int MAXPAD = (P0 - LY::nch(0)) / 2 > (LY::NSEG == 2 ? (P1 - LY::nch(1)) / 2 : 0) ? (P0 - LY::nch(0)) / 2
+                                                                                                 : (LY::NSEG == 2 ? (P1 - LY::nch(1)) / 2 : 0);
+        const unsigned zero_pair = 0u;
+        auto pad_row = [&](int q, int off) {          // off: LDS offset (halves) of the pair just stored
+#pragma unroll
+            for (int j = 0; j < MAXPAD; ++j)
+                if (j < npad[q]) {
+                    *reinterpret_cast<unsigned*>(s_hi + off + 2 + 2 * j) = zero_pair;
+                    *reinterpret_cast<unsigned*>(s_lo + off + 2 + 2 * j) = zero_pair;
+                }
+        };
         // Buffer loads over this batch item ([T_in, C_in] floats): a row before the first or past the last one is out of
         // the descriptor's range and reads as zeros -- the conv's zero padding without clamps or selects.  (The pass offset
         // has to travel in the lane offset: a scalar offset is not part of the range check.)
@@ -567,6 +582,7 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
                         for (int q = 0; q < 2; ++q) {
                             *reinterpret_cast<unsigned*>(s_hi + so[q] + tbase + row * sp[q]) = vh[u][q];
                             *reinterpret_cast<unsigned*>(s_lo + so[q] + tbase + row * sp[q]) = vl[u][q];
+                            if constexpr (MAXPAD > 0) pad_row(q, so[q] + tbase + row * sp[q]);
                         }
                     }
                 }
@@ -598,21 +614,17 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
                         const f16x2 ll = __builtin_convertvector((xc2 - hf) * 2048.f, f16x2);
                         *reinterpret_cast<f16x2*>(s_hi + so[q] + tbase + row * sp[q]) = hh;
                         *reinterpret_cast<f16x2*>(s_lo + so[q] + tbase + row * sp[q]) = ll;
+                        if constexpr (MAXPAD > 0) pad_row(q, so[q] + tbase + row * sp[q]);
                     }
                 }
             }
         }
         note_range(amax, range_flag);
-        // zeros in the pad channels of every row and behind the last row of each segment (finite bytes under zero weights)
+        // zeros behind the last row of each segment (the K round-up the last output steps read past their window)
         const f16x2 z2 = {(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
         for (int sg = 0; sg < LY::NSEG; ++sg) {
-            const int pt = sg ? P1 : P0, nc = LY::nch(sg), rows = LY::rows(sg, TT), sl = sg ? SL1 : SL0, base = sg ? SL0 : 0;
-            if (pt > nc)
-                for (int i = tid; i < 2 * GB * rows; i += 256) {
-                    _Float16* rp = slab + (i / rows) * GS + base + (i % rows) * pt;
-                    for (int c = nc; c < pt; c += 2) *reinterpret_cast<f16x2*>(rp + c) = z2;
-                }
+            const int pt = sg ? P1 : P0, rows = LY::rows(sg, TT), sl = sg ? SL1 : SL0, base = sg ? SL0 : 0;
             const int tail2 = (sl - rows * pt) / 2;
             if (tail2 > 0)
                 for (int i = tid; i < 2 * GB * tail2; i += 256)
@@ -959,10 +971,12 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
         const int r0 = tid / CH4, c4 = tid - r0 * CH4;
         const bool active = r0 < RPP;
         int so[2];
+        bool lastpair[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int ch = c4 * 4 + 2 * q, gl = ch / CG;
             so[q] = gl * GS + ch - gl * CG;
+            lastpair[q] = ch - gl * CG == CG - 2;
         }
         __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)(T * C * 4), 0x00020000);
         const int64_t row0 = t0 - PADT + r0;
@@ -987,13 +1001,15 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
                 for (int q = 0; q < 2; ++q) {
                     *reinterpret_cast<unsigned*>(s_hi + so[q] + ti * P) = vh[u][q];
                     *reinterpret_cast<unsigned*>(s_lo + so[q] + ti * P) = vl[u][q];
+                    if (lastpair[q]) {       // channels 16, 17 of a row: its pad columns 18, 19 too (finite bytes under zero weights)
+                        *reinterpret_cast<unsigned*>(s_hi + so[q] + ti * P + 2) = 0u;
+                        *reinterpret_cast<unsigned*>(s_lo + so[q] + ti * P + 2) = 0u;
+                    }
                 }
             }
         }
-        // zeros in the pad columns of every row and behind the last row (finite bytes under zero weights)
+        // zeros behind the last row (the K round-up the last columns read past their window)
         const f16x2 z2 = {(_Float16)0.f, (_Float16)0.f};
-        for (int i = tid; i < 2 * GB * TIN; i += 256)
-            *reinterpret_cast<f16x2*>(slab + (i / TIN) * GS + (i % TIN) * P + CG) = z2;
         constexpr int tail2 = (GS - TIN * P) / 2;
         for (int i = tid; i < 2 * GB * tail2; i += 256)
             *reinterpret_cast<f16x2*>(slab + (i / tail2) * GS + TIN * P + 2 * (i % tail2)) = z2;

@@ -371,6 +371,11 @@ static size_t tds_buf_floats(const tal_tds_desc* d, int B, int64_t T) {
 }
 
 // workspace = 4 rotating activation buffers | split-K scratch | 64-byte status block (word 0: fp16-range flag)
+// Clears the 64-byte status block of a call.  A kernel, not hipMemsetAsync: a memset node captured into a HIP graph replays
+// with a stale fill pattern on ROCm 7.2 (measured: the block came back holding two pointers, profiles/r4_short_clip_graph.txt),
+// which read as "out of fp16 range" on every replay of a captured SD call (tests/test_gpu_parity.py).
+__global__ void clear_status_kernel(int* __restrict__ status) { status[threadIdx.x] = 0; }
+
 extern "C" size_t tal_tds_status_offset(const tal_tds_desc* d, int B, int64_t T) {
     if (!d || B <= 0 || T <= 0) return 0;
     return 4 * tds_buf_floats(d, B, T) * sizeof(float) + gemm_splitk_ws_bytes();
@@ -399,7 +404,8 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
     const bool force_f32 = opt(OPT_TDS_EXACT_F32) != 0 || (d->flags & TAL_TDS_EXACT_F32) != 0;
     // status word: raised by any kernel that turns an fp32 value outside the finite fp16 range into hi / lo halves
     int* range_flag = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + tal_tds_status_offset(d, B, T));
-    if (hipMemsetAsync(range_flag, 0, 64, s) != hipSuccess) {
+    clear_status_kernel<<<1, 16, 0, s>>>(range_flag);
+    if (hipGetLastError() != hipSuccess) {
         set_error("tal_tds_fwd: cannot clear the status word");
         return TAL_EHIP;
     }
@@ -616,7 +622,8 @@ extern "C" int tal_tds_tiled_fwd(const tal_tds_desc* d, const float* x, int64_t 
     float* slice_out = reinterpret_cast<float*>(base);
     void* tds_ws = base + so;
     int* call_flag = reinterpret_cast<int*>(base + so + tb);
-    if (hipMemsetAsync(call_flag, 0, 64, s) != hipSuccess) {
+    clear_status_kernel<<<1, 16, 0, s>>>(call_flag);
+    if (hipGetLastError() != hipSuccess) {
         set_error("tal_tds_tiled_fwd: cannot clear the status word");
         return TAL_EHIP;
     }

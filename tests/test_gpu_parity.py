@@ -626,6 +626,34 @@ def test_speaker_ids_fused_path(sd_model):
     assert (ids.cpu().numpy() != g["ids"]).sum() == 0
 
 
+@pytest.mark.parametrize("seconds", [12, 300])
+def test_the_sd_path_can_be_captured_as_a_hip_graph(sd_model, seconds):
+    """The C-ABI calls of the SD path (log-mel, tal_tds_fwd, the head) issue nothing but kernel launches on the caller's stream,
+    so a caller may capture them into a HIP graph and replay it: same features and ids as the eager call for other clips of
+    the shape, and the fp16-range status block is cleared by every replay (it is cleared by a kernel: a captured
+    hipMemsetAsync node replayed with a stale fill pattern on ROCm 7.2 -- profiles/r4_short_clip_graph.txt)."""
+    from tal_asrd_amd import ops, synth
+    enc = sd_model.encoder
+    heads = (sd_model.spk_embed_proj.weight, sd_model.spk_embed_proj.bias, sd_model.spk_logit_proj.weight, sd_model.spk_logit_proj.bias)
+    clips = [torch.from_numpy(synth.synth_audio_batch(1, seconds * 16000, 900 + k)).to(dev()) for k in range(3)]
+    with torch.no_grad():
+        sd_model.speaker_ids(clips[0])                      # everything that is built once (plans, packs, kernel attributes)
+        torch.cuda.synchronize()
+        static_x = clips[0].clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            mel = sd_model.extract_features(static_x)
+            y, chk = ops.tds_forward(enc._descriptor(0, len(enc.sizes) - 1), mel, enc.sizes[-1], defer=True)
+            feat, _, ids = ops.sd_head(y, *heads, want_logits=False, want_ids=True)
+        for a in clips + clips[:1]:
+            for _ in range(20):
+                f0, i0 = sd_model.speaker_ids(a)            # eager traffic between replays (what exposed the stale memset node)
+            static_x.copy_(a)
+            graph.replay()
+            assert not chk.flagged()
+            assert torch.equal(i0, ids) and torch.equal(f0, feat)
+
+
 def test_speaker_ids_stream_over_clips_of_different_lengths(sd_model):
     """The episode-after-episode loop (tal/baseline/reconcile.py:96-102) over host clips that all differ in length (as real
     episodes do), one of them half precision: every result equals the one-clip call, in order, across two calls -- and the

@@ -116,6 +116,7 @@ enum Option {
     OPT_GCONV_NO_SHIFT18,         // 18-channel TDSBlock conv (split form in / out) on the two-M-tile kernel instead of the time-shift-packed one
     OPT_GCONV_GRID_XYZ,           // matrix-core grouped convs on the plain (time tile, group block, item) grid instead of the XCD-aware 1-D order
     OPT_GEMM_W64_STAGGER,         // 256 x 160 dense launches: odd first-round workgroups start this many percent of a tile's duration late (default 0)
+    OPT_GEMM_S64_ORDER,           // 64 x 80 dense launches: tile order 0 = by shape (n-major when M < N), 1 = m-major, 2 = n-major
     OPT_COUNT
 };
 int opt(Option o);
@@ -177,6 +178,11 @@ struct GemmArgs {
     // gemm_w64_kernel: the odd workgroups among the first `stagger_blocks` (the launch's first round, one per CU) start
     // `stagger_ticks` (100 MHz) late, so that half of the chip is in its K loop while the other half writes its tiles
     int stagger_ticks, stagger_blocks;
+    // gemm_s64_kernel: tile order.  n_major = 1 walks the M tiles of one N tile first (an XCD's contiguous range of tiles then
+    // shares a few W panels and reads all of X) -- for inputs with fewer rows than the layer has columns, where W is the
+    // larger operand; 0 walks the N tiles of one M tile first (X panel shared, every XCD reads all of W).
+    int n_major, tiles_m;
+    unsigned tiles_m_magic;
 };
 // mode 0: acc+b | 1: relu(acc+b) | 2: res + alpha*(acc+b) | 3: alpha*(acc+b) | 4: row arg-max partials of acc+b
 int launch_gemm(GemmArgs g, int mode, int nbatch, hipStream_t s);

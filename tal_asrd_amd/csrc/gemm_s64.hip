@@ -57,9 +57,16 @@ __global__ __launch_bounds__(256, 2) void gemm_s64_kernel(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[S_NBUF * S_BUF_FLOATS + 512];      // 75,776 B: two workgroups per CU
 
     const unsigned logical = logical_tile();
-    const unsigned tile_m = g.tiles_n == 1 ? logical : __umulhi(logical, g.tiles_n_magic);
+    unsigned tile_m, tile_n;
+    if (g.n_major) {
+        tile_n = g.tiles_m == 1 ? logical : __umulhi(logical, g.tiles_m_magic);
+        tile_m = logical - tile_n * (unsigned)g.tiles_m;
+    } else {
+        tile_m = g.tiles_n == 1 ? logical : __umulhi(logical, g.tiles_n_magic);
+        tile_n = logical - tile_m * (unsigned)g.tiles_n;
+    }
     const int64_t m0 = (int64_t)tile_m * BM;
-    const int n0 = (int)(logical - tile_m * (unsigned)g.tiles_n) * BN;
+    const int n0 = (int)tile_n * BN;
     const int64_t M = g.M;
     const int K = g.K;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -276,7 +283,15 @@ bool gemm_s64_ok(const GemmArgs& g, int mode) {
 void launch_gemm_s64(GemmArgs g, int mode, hipStream_t s) {
     g.tiles_n = g.N / S_BN;
     g.tiles_n_magic = g.tiles_n > 1 ? (unsigned)((1ull << 32) / (unsigned)g.tiles_n) + 1u : 0u;
-    const dim3 grid((unsigned)(cdiv(g.M, S_BM) * g.tiles_n));
+    g.tiles_m = (int)cdiv(g.M, S_BM);
+    g.tiles_m_magic = g.tiles_m > 1 ? (unsigned)((1ull << 32) / (unsigned)g.tiles_m) + 1u : 0u;
+    // An XCD (its own L2) takes a contiguous eighth of the tile order.  Fewer rows than columns: W (N x K) is the larger operand,
+    // so the order keeps an XCD on a few W panels; otherwise on a few X panels (measured, profiles/r4_gemm_s64_order_depth.txt:
+    // 30.5 -> 28.8 us per layer pair at 376 rows x 1440, 28.0 -> 26.6 at 751 x 1120; the other way round it loses as much).
+    // opt gemm_s64_order: 1 / 2 force m-major / n-major.
+    const int order = opt(OPT_GEMM_S64_ORDER);
+    g.n_major = order == 1 ? 0 : order == 2 ? 1 : (g.M < (int64_t)g.N ? 1 : 0);
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
     if (mode == 1) hipLaunchKernelGGL((gemm_s64_kernel<1>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_s64_kernel<2>), grid, dim3(256), 0, s, g);
 }

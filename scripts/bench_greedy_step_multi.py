@@ -37,7 +37,8 @@ for s in sessions[:1]:
     t0 = time.perf_counter()
     for _ in range(reps): s.step(0, U)
     print("one session, own launches, prefix %d: %.3f ms per step" % (U, 1e3 * (time.perf_counter() - t0) / reps), flush=True)
-for G in (1, 2, 4, 8, 12, 16):
+GS = [int(a) for a in os.environ["GS"].split(",")] if os.environ.get("GS") else [1, 2, 4, 8, 12, 16]
+for G in GS:
     ctxs = (C.POINTER(N.GreedyCtx) * 16)(*[C.pointer(s.ctx) for s in sessions])
     hs = (C.c_int64 * 16)(*([0] * 16)); ng = (C.c_int64 * 16)(*([U] * 16))
     h = N.stream_handle()
@@ -56,6 +57,8 @@ for G in (1, 2, 4, 8, 12, 16):
     torch.cuda.synchronize()
     print("%d sessions, shared launches: %.3f ms per merged step = %.3f ms per token; the C call alone (34 launches enqueued) %.3f ms" % (G, 1e3 * dt, 1e3 * dt / G, 1e3 * t_call), flush=True)
 
+if os.environ.get("GS"):
+    sys.exit(0)
 # two half-groups on two streams, both steps enqueued by ONE host thread before either result is awaited
 s2 = torch.cuda.Stream()
 sessB = []

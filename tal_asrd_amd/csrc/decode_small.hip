@@ -160,6 +160,121 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_multi_kernel(const ArgPac
     skinny_gemm_body<MODE, MT, NW>(g, Blk{blockIdx.x, blockIdx.y, blockIdx.z % KS, gridDim.x, gy});
 }
 
+// WIDE form of the multi launch, for merged steps with many row tiles (several sessions at long prefixes): one workgroup takes
+// NT neighbouring 16-column blocks of its 32 rows.  The rows' operand fragments -- a wave's whole K slice of 128, 64 registers --
+// are loaded ONCE and stay in registers while the W fragments of the NT blocks stream through (the next block's are in flight
+// while the current one is multiplied): the narrow form re-reads the 32 rows for every 16 columns, N / 16 times per layer, which
+// is two thirds of what a merged step of 8 sessions pulls from L2.  Per output the arithmetic is the narrow form's, instruction
+// for instruction (same chunks in the same order per wave, waves added in wave order, K slices in slice order through the same
+// partial buffers and tickets), so results are bit-identical to the narrow form and to a session's solo step.
+template <int MODE, int MT, int NW, int NT>
+__device__ __forceinline__ void skinny_gemm_wide_body(const SkinnyArgs& g, const Blk blk) {
+    __shared__ __attribute__((aligned(16))) float part[NW * MT * 256];   // [wave][m tile][row 16][col 16]
+    __shared__ unsigned ticket;
+    constexpr int UNR = 8;                          // Kw == 128: the wave's K slice is exactly one batch of 8 chunks
+    const int m0 = blk.y * 32;
+    const int lane = threadIdx.x & 63, w = wave_id();
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int KS = g.ksplit > 1 ? g.ksplit : 1;
+    const int Kw = g.K / (NW * KS);
+    const int kofs = ((int)blk.z * NW + w) * Kw;
+    f32x4 av[MT][UNR], bw[2][UNR];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = m0 + mt * 16 + r16;
+        const float* ap = g.A + (int64_t)(row < g.M ? row : g.M - 1) * g.lda + kofs + 4 * kq;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) av[mt][u] = *reinterpret_cast<const f32x4*>(ap + u * 16);
+    }
+    const int nb0 = blk.x * NT;                     // first 16-column block
+    auto load_w = [&](int nb, int buf) {
+        const float* wp = g.W + (int64_t)(nb * 16 + r16) * g.ldw + kofs + 4 * kq;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) bw[buf][u] = *reinterpret_cast<const f32x4*>(wp + u * 16);
+    };
+    load_w(nb0, 0);
+    const int t = threadIdx.x;
+    const int mt_t = t >> 6, r = (t & 63) >> 2, c4 = t & 3;
+    const int m = m0 + mt_t * 16 + r;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (nt + 1 < NT) load_w(nb0 + nt + 1, (nt + 1) & 1);
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u].x, bw[nt & 1][u].x, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u].y, bw[nt & 1][u].y, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u].z, bw[nt & 1][u].z, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u].w, bw[nt & 1][u].w, acc[mt], 0, 0, 0);
+            }
+        }
+        if (nt > 0) __syncthreads();                // the previous block's sums have been read out of `part`
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[((w * MT + mt) * 16 + 4 * kq + i) * 16 + r16] = acc[mt][i];
+        __syncthreads();
+        const int n0 = (nb0 + nt) * 16;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < MT * 64) {
+            v = *reinterpret_cast<const f32x4*>(&part[((0 * MT + mt_t) * 16 + r) * 16 + 4 * c4]);
+#pragma unroll
+            for (int q = 1; q < NW; ++q) v += *reinterpret_cast<const f32x4*>(&part[((q * MT + mt_t) * 16 + r) * 16 + 4 * c4]);   // wave order
+        }
+        bool finish = true;
+        if (KS > 1) {
+            const unsigned gx = blk.gx * NT;        // the narrow form's grid extent: same tile numbers, partial buffers and tickets
+            const unsigned tile = blk.y * gx + (unsigned)(nb0 + nt), ntile = gx * blk.gy;
+            float* mine = g.sk_part + ((size_t)blk.z * ntile + tile) * 512 + t * 4;
+            if (t < MT * 64) { st_agent(mine, v.x); st_agent(mine + 1, v.y); st_agent(mine + 2, v.z); st_agent(mine + 3, v.w); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) ticket = take_ticket(&g.sk_tickets[tile]);
+            __syncthreads();
+            finish = ticket == (unsigned)(KS - 1);
+            if (finish) {
+                if (t == 0) reset_ticket(&g.sk_tickets[tile]);
+                if (t < MT * 64) {
+                    const float* p0 = g.sk_part + (size_t)tile * 512 + t * 4;
+                    v = {0.f, 0.f, 0.f, 0.f};
+                    for (int q = 0; q < KS; ++q) {                 // split order
+                        const float* pq = p0 + (size_t)q * ntile * 512;
+                        v.x += ld_agent(pq); v.y += ld_agent(pq + 1); v.z += ld_agent(pq + 2); v.w += ld_agent(pq + 3);
+                    }
+                }
+            }
+        }
+        if (finish && t < MT * 64 && m < g.M) {
+            const int col = n0 + 4 * c4;
+            if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
+            if (MODE == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (MODE == 2) v = *reinterpret_cast<const f32x4*>(g.res + (int64_t)m * g.ldres + col) + g.alpha * v;
+            if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) v = g.alpha * v;
+            if (g.Yt && col >= g.vt_begin) {
+                const int b = m / g.U, u = m - b * g.U;
+                float* yt = g.Yt + (int64_t)b * g.vt_bs + (int64_t)(col - g.vt_begin) * g.ldt + u;
+                yt[0] = v.x;
+                yt[g.ldt] = v.y;
+                yt[2 * g.ldt] = v.z;
+                yt[3 * g.ldt] = v.w;
+            } else
+                *reinterpret_cast<f32x4*>(g.Y + (int64_t)m * g.ldy + col) = v;
+        }
+    }
+}
+
+template <int MODE, int MT, int NW, int NT>
+__global__ __launch_bounds__(64 * NW) void skinny_gemm_wide_multi_kernel(const ArgPack<SkinnyArgs> p, int KS) {
+    const SkinnyArgs& g = p.a[blockIdx.z / KS];
+    const unsigned gy = (unsigned)((g.M + 31) / 32);
+    if (blockIdx.y >= gy) return;
+    skinny_gemm_wide_body<MODE, MT, NW, NT>(g, Blk{blockIdx.x, blockIdx.y, blockIdx.z % KS, gridDim.x, gy});
+}
+
 bool skinny_gemm_applicable(const SkinnyArgs& g) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (g.ksplit > 1 && (!g.sk_part || !g.sk_tickets || g.K % (64 * g.ksplit) != 0)) return false;
@@ -196,6 +311,18 @@ static void launch_skinny_multi_mt(const ArgPack<SkinnyArgs>& p, int mmax, int K
 template <int MODE>
 static void launch_skinny_multi_nw(const ArgPack<SkinnyArgs>& p, int mmax, int KS, hipStream_t s) {
     const int k = p.a[0].K / KS;
+    // many row tiles (the narrow form's workgroups would queue up several deep on every CU): the wide form, 4 column blocks per
+    // workgroup with the rows' fragments resident (bit-identical results); needs a K slice of exactly 128 per wave
+    constexpr int NT = 4;
+    int row_tiles = 0;
+    for (int i = 0; i < p.n; ++i) row_tiles += (p.a[i].M + 31) / 32;
+    const int wide_opt = opt(OPT_DECODE_WIDE_GEMM);            // 0 = by size, 1 = never, 2 = always
+    if (k == 512 && p.a[0].N % (16 * NT) == 0 && mmax > 16 && wide_opt != 1 &&
+        (wide_opt == 2 || (int64_t)(p.a[0].N / 16) * row_tiles * KS >= 2 * (int64_t)device_cus())) {
+        const dim3 grid((unsigned)(p.a[0].N / (16 * NT)), (unsigned)((mmax + 31) / 32), (unsigned)(KS * p.n));
+        hipLaunchKernelGGL((skinny_gemm_wide_multi_kernel<MODE, 2, 4, NT>), grid, dim3(256), 0, s, p, KS);
+        return;
+    }
     if (k >= 2048 && k % 256 == 0) launch_skinny_multi_mt<MODE, 16>(p, mmax, KS, s);
     else if (k >= 1024 && k % 128 == 0) launch_skinny_multi_mt<MODE, 8>(p, mmax, KS, s);
     else launch_skinny_multi_mt<MODE, 4>(p, mmax, KS, s);

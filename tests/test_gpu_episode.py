@@ -189,14 +189,20 @@ def test_merged_step_equals_solo_step_bit_for_bit(asr_weights):
     hs = (C.c_int64 * 8)(0, 0, 0, 0)
     ng = (C.c_int64 * 8)(*[U for _, U in sessions])
     assert lib.tal_greedy_step_multi_fwd(ctxs, hs, ng, 4, N.stream_handle()) != 0 and b"step it alone" in lib.tal_last_error()
-    for rep in range(2):
-        for s, U in sessions[:3]:
-            s.gen_dev[U] = -1
-        N.check(lib.tal_greedy_step_multi_fwd(ctxs, hs, ng, 3, N.stream_handle()), "tal_greedy_step_multi_fwd")
-        for (s, U), (tok, row, appended) in zip(sessions[:3], solo):
-            assert s.ready(20000)
-            t2, r2 = s.result()
-            assert t2 == tok and np.array_equal(r2, row) and int(s.gen_dev[U]) == appended
+    # decode_wide_gemm: the merged dense layers on one 16-column block per workgroup (1), on four with the rows' fragments kept in
+    # registers (2: what merged steps of many long prefixes take), and chosen by launch size (0)
+    try:
+        for rep, wide in enumerate((0, 1, 2, 2)):
+            N.set_option("decode_wide_gemm", wide)
+            for s, U in sessions[:3]:
+                s.gen_dev[U] = -1
+            N.check(lib.tal_greedy_step_multi_fwd(ctxs, hs, ng, 3, N.stream_handle()), "tal_greedy_step_multi_fwd")
+            for (s, U), (tok, row, appended) in zip(sessions[:3], solo):
+                assert s.ready(20000)
+                t2, r2 = s.result()
+                assert t2 == tok and np.array_equal(r2, row) and int(s.gen_dev[U]) == appended, (wide, U)
+    finally:
+        N.set_option("decode_wide_gemm", 0)
 
 
 def test_a_failing_episode_ends_the_whole_call(asr_weights):

@@ -682,7 +682,9 @@ extern "C" size_t tal_sd_head_workspace_bytes(int64_t M, int S) {
     // (value, index) partials of the fused arg-max: one pair per row and per 32-column wave slice.  The small-M
     // kernel (32 x 128 tile, 4 waves side by side) writes 4 slots per 128-column tile, the last tile included
     // even when it is partly past S, hence the second term.
-    const size_t partials = sd_head_partials_bytes(M, S);
+    // ... and behind them (a multiple of 256 on) room for the speaker-logit weights as hi / lo fp16 halves (S x 128 x 4 bytes), which
+    // the A-stationary arg-max kernel multiplies in the fp16x3 form
+    const size_t partials = ((sd_head_partials_bytes(M, S) + 255) & ~(size_t)255) + (size_t)S * 128 * 4;
     // The same bytes serve first as K-slice scratch of the embedding layer (1440 -> 128: ONE column tile, so a clip of minutes is
     // a few dozen 128-row tiles for 256 CUs -- 120 us on 30 workgroups for a 5-minute clip; cut along K 8 ways it is ~30 us).
     // launch_gemm slices only launches below a quarter round (128 tiles).
@@ -719,7 +721,7 @@ extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_
     if (M == 0) return TAL_OK;
     if (b_logit && head_argmax_applicable(M, S, E)) {
         // long inputs: feature strip stationary in registers, running arg-max across N tiles (csrc/head.hip)
-        const int P = head_argmax_partials();
+        const int P = head_argmax_partials(M, S);
         float* pv = reinterpret_cast<float*>(workspace);
         int32_t* pi = reinterpret_cast<int32_t*>(pv + (size_t)M * P);
         // the speaker-logit weights as hi / lo fp16 split in the unused tail of the workspace (3 MB, one ~5 us pass per call):

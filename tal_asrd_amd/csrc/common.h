@@ -222,9 +222,9 @@ int launch_gconv_s2_f16x3(const float* x, const void* w_frag, const float* bias,
 int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias, float alpha, int B, int64_t T, int C, int groups,
                            float* y, void* y_split, hipStream_t s, int* range_flag = nullptr, bool x_split = false);
 int launch_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, hipStream_t s);
-// A-stationary speaker-logit arg-max (csrc/head.hip): partials [M, head_argmax_partials()] for argmax_partials_kernel
+// A-stationary speaker-logit arg-max (csrc/head.hip): partials [M, head_argmax_partials(M, S)] for argmax_partials_kernel
 bool head_argmax_applicable(int64_t M, int S, int E);
-int head_argmax_partials();
+int head_argmax_partials(int64_t M, int S);
 int launch_head_argmax(const float* feat, const float* w, const void* w_split, const float* b, int64_t M, int S, float* part_val,
                        int32_t* part_idx, hipStream_t s);
 

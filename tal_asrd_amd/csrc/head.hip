@@ -8,10 +8,11 @@
 // 16 MFMA-ready fragments, 64 VGPRs), only W streams through LDS (LDS-DMA, double-buffered 128 x 32 chunks,
 // one barrier per chunk), and the arg-max is a running (value, column) pair per accumulator element that
 // stays in registers across N tiles -- no cross-lane work and no memory traffic until a row block is done.
-// Work is cut into 2 x CUs equal runs of consecutive (row block, N tile) units, so a row block's 47 N tiles
-// are covered by at most 3 workgroups (N tile = 128 columns: 6008 = 46 x 128 + 120), each leaving one (value, column) partial per row; the existing
-// argmax_partials_kernel merges them in ascending column order (strict '>': lowest index wins ties, as
-// torch.argmax does).
+// Work is cut into equal runs of consecutive (row block, N tile) units -- 2 x CUs runs for long inputs, so a row block's 47 N
+// tiles (N tile = 128 columns: 6008 = 46 x 128 + 120) are covered by at most 3 workgroups; inputs of a few thousand rows get
+// shorter runs (down to 4 N tiles: up to 16 partial slots per row, head_argmax_plan) so that a clip of minutes still puts a
+// workgroup on every CU.  Each workgroup leaves one (value, column) partial per row; the existing
+// argmax_partials_kernel merges them in ascending column order (strict '>': lowest index wins ties, as torch.argmax does).
 #include "common.h"
 
 namespace tal {
@@ -20,7 +21,7 @@ namespace {
 
 constexpr int HK = 128;            // feature width (K)
 constexpr int HBM = 128, HBN = 128, HNSUB = 4;
-constexpr int HP = 3;              // partial slots per row
+constexpr int HP_MAX = 16;         // most partial slots per row: a run is at least NT / 15 N tiles (4 of 47) long
 
 __device__ __forceinline__ void* uniform_ptr(const void* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -36,7 +37,7 @@ template <bool F16X3>
 __global__ __launch_bounds__(256, 2) void head_argmax_kernel(const float* __restrict__ feat, const float* __restrict__ W,
                                                             const float* __restrict__ bias, int64_t M, int S, int NT,
                                                             int64_t U, float* __restrict__ part_val,
-                                                            int32_t* __restrict__ part_idx) {
+                                                            int32_t* __restrict__ part_idx, int HP) {
     __shared__ __attribute__((aligned(16))) float lds[2 * HBN * 32];   // 40,960 B
     const int64_t G = gridDim.x;
     const int64_t u0 = (int64_t)blockIdx.x * U / G, u1 = ((int64_t)blockIdx.x + 1) * U / G;
@@ -221,22 +222,40 @@ __global__ __launch_bounds__(256, 2) void head_argmax_kernel(const float* __rest
 
 }  // namespace
 
-// Workgroups of a launch: 2 per CU, fewer when that would make a run shorter than half a row block's N tiles (every row block
-// must be covered by <= HP workgroups): a batch of eight 5-minute segments (29,864 rows = 10,998 units) takes 458 instead of 512
-static int64_t head_argmax_grid(int64_t M, int S) {
-    const int64_t units = cdiv(M, HBM) * cdiv(S, HBN), by_runs = units / ((cdiv(S, HBN) + 1) / 2);
-    const int64_t full = 2 * (int64_t)device_cus();
-    return by_runs < full ? by_runs : full;
+// Workgroups of a launch and partial slots per row.  A row block's NT units may be covered by at most `hp` workgroups, i.e. a run
+// must be at least NT / (hp - 1) units long.  Long inputs: 2 workgroups per CU with hp = 3 (a batch of eight 5-minute segments,
+// 29,864 rows = 10,998 units, takes 458 runs instead of 512).  Fewer rows: the smallest hp of the ladder that still gives every
+// CU a workgroup (a 5-minute clip, 30 row blocks: hp = 12, 282 runs of 5 tiles).  Runs shorter than 4 tiles do not pay: below
+// ~2,700 rows the generic fused path is as fast or faster (measured on 30-second to 4-minute clips, profiles/r4_head_mid_sizes.txt).
+static void head_argmax_plan(int64_t M, int S, int64_t& grid, int& hp) {
+    const int64_t nt = cdiv(S, HBN), units = cdiv(M, HBM) * nt, full = 2 * (int64_t)device_cus(), want = device_cus();
+    static const int ladder[] = {3, 4, 6, 8, 12, HP_MAX};
+    grid = 0;
+    hp = 3;
+    for (int h : ladder) {
+        const int64_t lmin = cdiv(nt, (int64_t)(h - 1)), g = units / lmin < full ? units / lmin : full;
+        grid = g;
+        hp = h;
+        if (g >= want) break;
+    }
 }
 
 // true when the shape is one this kernel is meant for (the caller falls back to the generic fused path otherwise): at least
 // one workgroup per CU
 bool head_argmax_applicable(int64_t M, int S, int E) {
-    if (E != HK || S < HBN) return false;
-    return head_argmax_grid(M, S) >= device_cus() && !opt(OPT_HEAD_NO_ASTATIONARY);
+    if (E != HK || S < HBN || opt(OPT_HEAD_NO_ASTATIONARY)) return false;
+    int64_t grid;
+    int hp;
+    head_argmax_plan(M, S, grid, hp);
+    return grid >= device_cus();
 }
 
-int head_argmax_partials() { return HP; }
+int head_argmax_partials(int64_t M, int S) {
+    int64_t grid;
+    int hp;
+    head_argmax_plan(M, S, grid, hp);
+    return hp;
+}
 
 // w_split != nullptr: W as the hi / lo split of tal_split_f16x3_fwd -> the fp16x3 kernel; else w (fp32) -> the fp32 MFMA kernel
 int launch_head_argmax(const float* feat, const float* w, const void* w_split, const float* b, int64_t M, int S, float* part_val,
@@ -244,14 +263,17 @@ int launch_head_argmax(const float* feat, const float* w, const void* w_split, c
     TAL_CHECK_ARG(feat && (w || w_split) && b && part_val && part_idx, "head_argmax: null pointer");
     TAL_CHECK_ARG(((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(w_split)) & 15) == 0, "head_argmax: operands must be 16-byte aligned");
     const int NT = (int)cdiv(S, HBN);
-    const int64_t U = cdiv(M, HBM) * NT, grid = head_argmax_grid(M, S);
+    const int64_t U = cdiv(M, HBM) * NT;
+    int64_t grid;
+    int hp;
+    head_argmax_plan(M, S, grid, hp);
     TAL_CHECK_ARG(grid >= 1, "head_argmax: too few rows (M=%lld)", (long long)M);
     ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)S * HK, s);
     if (w_split)
         hipLaunchKernelGGL(head_argmax_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, feat, reinterpret_cast<const float*>(w_split), b, M,
-                           S, NT, U, part_val, part_idx);
+                           S, NT, U, part_val, part_idx, hp);
     else
-        hipLaunchKernelGGL(head_argmax_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, feat, w, b, M, S, NT, U, part_val, part_idx);
+        hipLaunchKernelGGL(head_argmax_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, feat, w, b, M, S, NT, U, part_val, part_idx, hp);
     TAL_CHECK_LAUNCH("head_argmax");
     return TAL_OK;
 }

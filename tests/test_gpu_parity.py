@@ -700,9 +700,11 @@ def test_speaker_ids_do_not_depend_on_dispatch_choices(sd_model, seconds):
     assert float((feat - feat2).abs().max()) < 2e-4 * max(1.0, float(feat.abs().max()))
 
 
-@pytest.mark.parametrize("M,S", [(33000, 6008), (32768 + 1, 6008), (70001, 1000), (29864, 6008), (16800, 6008), (17001, 6008)])
+@pytest.mark.parametrize("M,S", [(33000, 6008), (32768 + 1, 6008), (70001, 1000), (29864, 6008), (16800, 6008), (17001, 6008),
+                                 (9000, 6008), (3751, 6008), (751, 6008), (376, 6008), (300, 6008), (1100, 1000)])
 def test_long_input_argmax_head_matches_logits_argmax(M, S):
-    """The A-stationary arg-max kernel (long inputs, 128-d features): same ids as arg-max over materialised
+    """The A-stationary arg-max kernel (128-d features; 3 partial slots per row on long inputs, up to one per N tile on clips of
+    seconds to minutes): same ids as arg-max over materialised
     logits, ragged last row block and last column tile, and the LOWEST index on exact ties (two identical
     speaker rows made the winners of a band of rows), as torch.argmax does."""
     from tal_asrd_amd import ops

@@ -55,7 +55,7 @@ const char* tal_last_error(void);
  *   tds_fp32_activations  fp16x3 layers, but fp32 activations between the kernels of a stage
  *   gconv_fuse_split, gconv_c1_generic, head_no_astationary, gemm_global_loads, gemm_no_splitk4, gemm_no_glds,
  *   gemm_no_splitk_tail, gemm_no_w64, gemm_no_n96, gemm_no_row_split, logmel_no_fold, decode_no_small, gconv_no_shift18,
- *   gconv_grid_xyz, gemm_w64_stagger, gemm_s64_order, decode_wide_gemm
+ *   gconv_grid_xyz, gemm_w64_stagger, gemm_s64_order, decode_wide_gemm, gemm_s64_rows
  *                         kernel-selection switches of the ablation measurements
  *   decode_small_rows     largest prefix the latency-oriented decoder layer takes (default 256)
  *   gemm_s64_below        fp16x3 relu / residual layers run on 64 x 80 tiles without K slices while those tiles number

@@ -118,6 +118,7 @@ enum Option {
     OPT_GEMM_W64_STAGGER,         // 256 x 160 dense launches: odd first-round workgroups start this many percent of a tile's duration late (default 0)
     OPT_GEMM_S64_ORDER,           // 64 x 80 dense launches: tile order 0 = by shape (n-major when M < N), 1 = m-major, 2 = n-major
     OPT_DECODE_WIDE_GEMM,         // merged decode steps: 4 column blocks per workgroup in the skinny dense layers (0 = when the launch has >= 2 workgroups per CU, 1 = never, 2 = always)
+    OPT_GEMM_S64_ROWS,            // short-input dense launches: 0 = 32-row tiles (two waves) while they number at most one per CU, 1 = always 64 rows, 2 = always 32
     OPT_COUNT
 };
 int opt(Option o);

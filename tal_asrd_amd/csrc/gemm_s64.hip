@@ -36,12 +36,20 @@ namespace {
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
 
-constexpr int S_BM = 64, S_BN = 80, S_NJ = S_BN / 16, S_ROWS = S_BM + S_BN, S_NBUF = 4;
-constexpr int S_CHUNKS = S_ROWS / 8;            // 18 wave-loads of 1 KB (8 rows x 128 B) per K step
-constexpr int S_PER_WAVE = 5;                   // chunk i = w + 4 t; i >= 18 (t = 4 of waves 2, 3) lands in a dummy 2 KB behind the buffers
-                                                // (every wave issues the same number of loads: one vmcnt schedule for all)
-constexpr int S_AT = S_BM / 8 / 4;              // t < 2: X rows
-constexpr int S_BUF_FLOATS = S_ROWS * 32;
+// NWV waves per workgroup, 16 rows each: 4 (64 x 80 tiles) or 2 (32 x 80 tiles: launches with so few tiles that half of the CUs
+// would stay idle -- a CU streams its operands at ~36 B/clk whatever it computes, so more CUs with 112 instead of 144 operand rows
+// per K step each are faster, profiles/r4_gemm_s64_order_depth.txt)
+constexpr int S_BN = 80, S_NJ = S_BN / 16, S_NBUF = 4;
+template <int NWV>
+struct SGeo {
+    static constexpr int BM = 16 * NWV, ROWS = BM + S_BN;
+    static constexpr int CHUNKS = ROWS / 8;                        // 18 / 14 wave-loads of 1 KB (8 rows x 128 B) per K step
+    static constexpr int PER_WAVE = (CHUNKS + NWV - 1) / NWV;      // 5 / 7; chunk i = w + NWV t; i >= CHUNKS (4 waves: t = 4 of waves 2, 3) lands
+                                                                   // in a dummy 2 KB behind the buffers (every wave issues the same number
+                                                                   // of loads: one vmcnt schedule for all)
+    static constexpr int AT = BM / 8 / NWV;                        // t < 2: X rows
+    static constexpr int BUF_FLOATS = ROWS * 32;
+};
 
 struct SFrags {
     f16x8 xh, xl;                // 16 X rows of this wave
@@ -50,11 +58,12 @@ struct SFrags {
 
 }  // namespace
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_s64_kernel(const GemmArgs g) {
+template <int MODE, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void gemm_s64_kernel(const GemmArgs g) {
     static_assert(MODE == 1 || MODE == 2, "relu or residual layer");
-    constexpr int NJ = S_NJ, BM = S_BM, BN = S_BN, PER_WAVE = S_PER_WAVE, BUF = S_BUF_FLOATS;
-    __shared__ __attribute__((aligned(16))) float lds[S_NBUF * S_BUF_FLOATS + 512];      // 75,776 B: two workgroups per CU
+    using GEO = SGeo<NWV>;
+    constexpr int NJ = S_NJ, BM = GEO::BM, BN = S_BN, PER_WAVE = GEO::PER_WAVE, BUF = GEO::BUF_FLOATS, S_AT = GEO::AT, S_CHUNKS = GEO::CHUNKS;
+    __shared__ __attribute__((aligned(16))) float lds[S_NBUF * GEO::BUF_FLOATS + 512];      // 75,776 B (4 waves): two workgroups per CU
 
     const unsigned logical = logical_tile();
     unsigned tile_m, tile_n;
@@ -90,12 +99,13 @@ __global__ __launch_bounds__(256, 2) void gemm_s64_kernel(const GemmArgs g) {
     int voff[PER_WAVE];
 #pragma unroll
     for (int t = 0; t < PER_WAVE; ++t) {
-        const int row = 8 * (w + 4 * t) + sub;
+        const int row = 8 * (w + NWV * t) + sub;
         voff[t] = t < S_AT ? (int)((min(row, a_rows) * g.lda + srccol) * 4) : (int)((min(row - BM, BN - 1) * g.ldw + srccol) * 4);
     }
-    const bool last_chunk = w + 16 < S_CHUNKS;          // wave-uniform: chunk w + 16 exists
+    const bool last_chunk = w + NWV * (PER_WAVE - 1) < S_CHUNKS;          // wave-uniform: this wave's last chunk exists
     auto dma = [&](int t, unsigned nrec, int bufoff, int kofs) {
-        const unsigned dst = (t < 4 || last_chunk) ? lds_base + (unsigned)(bufoff * 4 + t * 4096) : lds_base + (unsigned)(S_NBUF * BUF * 4 - 2048);
+        const unsigned dst = (t < PER_WAVE - 1 || last_chunk) ? lds_base + (unsigned)(bufoff * 4 + t * (NWV * 1024))
+                                                              : lds_base + (unsigned)(S_NBUF * BUF * 4 - 2048);
         u32x4s rs = t < S_AT ? rs_a : rs_w;
         rs[2] = nrec;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff[t]), "s"(rs), "s"(kofs) : "memory");
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void gemm_s64_kernel(const GemmArgs g) {
         __builtin_amdgcn_s_barrier();
         // One wave per SIMD: whatever is issued in front of the MFMAs is matrix time lost.  The 12 fragment reads of tile kt + 1 and
         // the 5 LDS-DMA loads of tile kt + 4 are therefore issued BETWEEN the 15 MFMAs of tile kt, one behind each (an MFMA
-        // occupies the pipe for 16 cycles and the issue port for 4).
+        // occupies the pipe for 16 cycles and the issue port for 4; with two waves per workgroup a wave has 7 loads per step).
         const unsigned nrec = kt + 4 < nk ? NREC : 0u;
         const int kofs = (kt + 4) * (BK * 4);
         constexpr int nbuf = ((B + 1) % S_NBUF) * BUF;
@@ -201,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_s64_kernel(const GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             if (3 * j + 2 < 12) read_item(3 * j + 2);
             dma(j, nrec, B * BUF, kofs);
+            if (j + NJ < PER_WAVE) dma(j + NJ, nrec, B * BUF, kofs);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -283,7 +294,11 @@ bool gemm_s64_ok(const GemmArgs& g, int mode) {
 void launch_gemm_s64(GemmArgs g, int mode, hipStream_t s) {
     g.tiles_n = g.N / S_BN;
     g.tiles_n_magic = g.tiles_n > 1 ? (unsigned)((1ull << 32) / (unsigned)g.tiles_n) + 1u : 0u;
-    g.tiles_m = (int)cdiv(g.M, S_BM);
+    // 32-row tiles (two waves per workgroup) while even those leave CUs idle: stage 3 of a 30-second clip is 108 tiles of 64 rows
+    // on 256 CUs, 216 of 32.  opt gemm_s64_rows: 1 / 2 force 64 / 32 rows.
+    const int rows_opt = opt(OPT_GEMM_S64_ROWS);
+    const bool half = rows_opt == 2 || (rows_opt == 0 && cdiv(g.M, 32) * g.tiles_n <= (int64_t)device_cus());
+    g.tiles_m = (int)cdiv(g.M, half ? 32 : 64);
     g.tiles_m_magic = g.tiles_m > 1 ? (unsigned)((1ull << 32) / (unsigned)g.tiles_m) + 1u : 0u;
     // An XCD (its own L2) takes a contiguous eighth of the tile order.  Fewer rows than columns: W (N x K) is the larger operand,
     // so the order keeps an XCD on a few W panels; otherwise on a few X panels (measured, profiles/r4_gemm_s64_order_depth.txt:
@@ -292,8 +307,13 @@ void launch_gemm_s64(GemmArgs g, int mode, hipStream_t s) {
     const int order = opt(OPT_GEMM_S64_ORDER);
     g.n_major = order == 1 ? 0 : order == 2 ? 1 : (g.M < (int64_t)g.N ? 1 : 0);
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
-    if (mode == 1) hipLaunchKernelGGL((gemm_s64_kernel<1>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_s64_kernel<2>), grid, dim3(256), 0, s, g);
+    if (half) {
+        if (mode == 1) hipLaunchKernelGGL((gemm_s64_kernel<1, 2>), grid, dim3(128), 0, s, g);
+        else hipLaunchKernelGGL((gemm_s64_kernel<2, 2>), grid, dim3(128), 0, s, g);
+    } else {
+        if (mode == 1) hipLaunchKernelGGL((gemm_s64_kernel<1, 4>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_s64_kernel<2, 4>), grid, dim3(256), 0, s, g);
+    }
 }
 
 }  // namespace tal

@@ -685,7 +685,8 @@ def test_speaker_ids_do_not_depend_on_dispatch_choices(sd_model, seconds):
     round-3 choice switched off must give the SAME speaker ids and features equal to fp32 rounding."""
     from tal_asrd_amd import synth, _native as N_
     audio = torch.from_numpy(synth.synth_audio_batch(1, seconds * 16000, 4321 + seconds)).to(dev())
-    names = {"gemm_s64_below": (2, 0), "gconv_short_below": (4, 0), "gemm_no_n96": (0, 1), "gemm_no_row_split": (0, 1), "gemm_no_w64": (0, 1)}
+    names = {"gemm_s64_below": (2, 0), "gconv_short_below": (4, 0), "gemm_no_n96": (0, 1), "gemm_no_row_split": (0, 1), "gemm_no_w64": (0, 1),
+             "head_no_astationary": (0, 1)}
     feat, ids = sd_model.speaker_ids(audio)
     torch.cuda.synchronize()
     try:
@@ -698,6 +699,19 @@ def test_speaker_ids_do_not_depend_on_dispatch_choices(sd_model, seconds):
             N_.set_option(name, on)
     assert torch.equal(ids, ids2)
     assert float((feat - feat2).abs().max()) < 2e-4 * max(1.0, float(feat.abs().max()))
+    # round 4: tile order and 32-row tiles of the short-input dense layer change which workgroup computes a tile, not its arithmetic
+    try:
+        N_.set_option("gemm_s64_order", 1)
+        N_.set_option("gemm_s64_rows", 1)
+        feat3, ids3 = sd_model.speaker_ids(audio)
+        N_.set_option("gemm_s64_order", 2)
+        N_.set_option("gemm_s64_rows", 2)
+        feat4, ids4 = sd_model.speaker_ids(audio)
+        torch.cuda.synchronize()
+    finally:
+        N_.set_option("gemm_s64_order", 0)
+        N_.set_option("gemm_s64_rows", 0)
+    assert torch.equal(ids, ids3) and torch.equal(feat, feat3) and torch.equal(ids, ids4) and torch.equal(feat, feat4)
 
 
 @pytest.mark.parametrize("M,S", [(33000, 6008), (32768 + 1, 6008), (70001, 1000), (29864, 6008), (16800, 6008), (17001, 6008),

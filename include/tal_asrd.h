@@ -216,7 +216,10 @@ size_t tal_tds_workspace_bytes(const tal_tds_desc* d, int B, int64_t T);
  * kernel tracks max |x|; tal_tds_fwd clears a status word in its workspace at tal_tds_status_offset() bytes and the
  * kernels raise it (non-zero int32) when a value was out of range -- the output of that call is then NOT valid and the
  * caller re-runs it with desc->flags |= TAL_TDS_EXACT_F32 (fp32-input MFMA kernels, no range limit).  Values below
- * 2^-24 in magnitude lose their low half (absolute error <= 2^-35 per product, far below fp32 resolution of the sums). */
+ * 2^-24 in magnitude lose their low half (absolute error <= 2^-35 per product, far below fp32 resolution of the sums).
+ * Stream capture: tal_logmel_*_fwd, tal_tds_fwd and tal_sd_head_fwd enqueue kernel launches on `stream` and nothing else (the
+ * status word is cleared by a kernel, not a memset node), so a caller may capture them into a HIP graph once every one-off
+ * build (plans, weight packs) has run eagerly; the status word is read after each replay like after each call. */
 size_t tal_tds_status_offset(const tal_tds_desc* d, int B, int64_t T);
 /* x [B, T, channels[0]] -> y [B, T', channels[n_stages]] */
 int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t T, float* y,

@@ -311,14 +311,16 @@ static void launch_skinny_multi_mt(const ArgPack<SkinnyArgs>& p, int mmax, int K
 template <int MODE>
 static void launch_skinny_multi_nw(const ArgPack<SkinnyArgs>& p, int mmax, int KS, hipStream_t s) {
     const int k = p.a[0].K / KS;
-    // many row tiles (the narrow form's workgroups would queue up several deep on every CU): the wide form, 4 column blocks per
-    // workgroup with the rows' fragments resident (bit-identical results); needs a K slice of exactly 128 per wave
+    // many row tiles (the narrow form's workgroups would queue up two or more deep on every CU, and the wide form still puts one
+    // on three of four CUs): the wide form, 4 column blocks per workgroup with the rows' fragments resident (bit-identical
+    // results); needs a K slice of exactly 128 per wave
     constexpr int NT = 4;
     int row_tiles = 0;
     for (int i = 0; i < p.n; ++i) row_tiles += (p.a[i].M + 31) / 32;
     const int wide_opt = opt(OPT_DECODE_WIDE_GEMM);            // 0 = by size, 1 = never, 2 = always
     if (k == 512 && p.a[0].N % (16 * NT) == 0 && mmax > 16 && wide_opt != 1 &&
-        (wide_opt == 2 || (int64_t)(p.a[0].N / 16) * row_tiles * KS >= 2 * (int64_t)device_cus())) {
+        (wide_opt == 2 || ((int64_t)(p.a[0].N / 16) * row_tiles * KS >= 2 * (int64_t)device_cus() &&
+                           (int64_t)(p.a[0].N / (16 * NT)) * row_tiles * KS * 4 >= 3 * (int64_t)device_cus()))) {
         const dim3 grid((unsigned)(p.a[0].N / (16 * NT)), (unsigned)((mmax + 31) / 32), (unsigned)(KS * p.n));
         hipLaunchKernelGGL((skinny_gemm_wide_multi_kernel<MODE, 2, 4, NT>), grid, dim3(256), 0, s, p, KS);
         return;

@@ -40,12 +40,13 @@ print("one at a time: %d episodes x %.0f s, %d decode steps, %.3f s = %.0f frame
 modes = [(k, 1) for k in (1, 2, 4, 8, 16) if k <= n_ep]
 # sessions advanced in step through SHARED launches (tal_greedy_step_multi_fwd): (host threads, sessions per group)
 modes += [(t, gsz) for t, gsz in ((1, 8), (2, 4), (4, 2), (1, 16), (2, 8), (4, 4), (2, 16)) if gsz <= n_ep]
+modes.append((None, None))       # the default split of transcribe_unaligned_many
 for k, gsz in modes:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     many = system.transcribe_unaligned_many(eps, streams=k, group=gsz)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     same = all(torch.equal(a[1].cpu(), b[1].cpu()) and [int(c[0]) for c, _ in a[2]] == [int(c[0]) for c, _ in b[2]] and
                all(torch.equal(x[1], y[1]) for x, y in zip(a[2], b[2])) for a, b in zip(solo, many))
-    what = "%2d sessions in flight, own launches" % k if gsz == 1 else "%d thread(s) x groups of %d sessions, shared launches" % (k, gsz)
+    what = "default split (streams=None, group=None)" if k is None else "%2d sessions in flight, own launches" % k if gsz == 1 else "%d thread(s) x groups of %d sessions, shared launches" % (k, gsz)
     print("%s: %.3f s = %.0f frames/s (%.2fx one at a time), %.3f ms per step overall, trajectories identical: %s"
           % (what, dt, n_ep * frames / dt, t_solo / dt, 1e3 * dt / steps, same), flush=True)

@@ -356,7 +356,7 @@ class System:
 
     # ------------------------------------------------------------------ several episodes in flight
     @torch.no_grad()
-    def transcribe_unaligned_many(self, episodes, streams=8, group=1, stats=None, **kw):
+    def transcribe_unaligned_many(self, episodes, streams=None, group=None, stats=None, **kw):
         """`transcribe_unaligned` over a list of episodes with several decode sessions in flight -- the loop the reference runs
         this path in (tal/asr/system.py:625-742 per test item, one after the other).  Each session is the ordinary sliding-window
         decode with its own context (prefix buffer, workspace, window K / V^T, pinned result word); they share the weights.
@@ -378,10 +378,18 @@ class System:
         stats (group > 1): a dict that receives counters of the group loop (calls of tal_unaligned_group_run, merged steps, steps
         taken alone, flags that came back to Python) -- measurement only.
 
+        streams / group left at None: four host threads (the device runs four chains of launches side by side), each with a group
+        of ceil(episodes / 4) sessions, at most 4 -- the best or near-best measured split for 8 one-hour episodes (4 x 2: 3.9-4.3x
+        the one-at-a-time loop) and for 32 ten-minute ones (4 x 4: 5.4x; 2 x 16: 5.7x), profiles/r4_episode_streams*.txt.
+
         episodes: list of (audio [1, L] float tensor -- host (pinned or not) or device --, audio_lens LongTensor [1]).
         Returns [(utterance dicts, generated, alignments)] in episode order, identical to the solo runs in either mode."""
         if not episodes:
             return []
+        if group is None:
+            group = 1 if streams is not None else max(1, min(4, -(-len(episodes) // 4)))
+        if streams is None:
+            streams = 4 if group > 1 else min(8, len(episodes))
         dev = next(self.model.parameters()).device
         # everything the sessions share is built once, on the caller's stream, before any of them starts
         first_audio = episodes[0][0]

@@ -128,7 +128,8 @@ def test_sessions_in_flight_reproduce_their_solo_runs(asr_weights):
     solo = [system.transcribe_unaligned(a.to(dev), lens) for a, lens in eps]
     # (streams, group): one chain of launches per session on its own stream | sessions advanced in step through SHARED launches
     # (tal_greedy_step_multi_fwd): five in one group; groups of two and three on two threads, slots refilled as episodes end
-    for streams, group in ((2, 1), (5, 1), (1, 8), (2, 2), (2, 3)):
+    # (None, None): the default split -- four threads x groups of ceil(episodes / 4)
+    for streams, group in ((2, 1), (5, 1), (1, 8), (2, 2), (2, 3), (None, None)):
         many = system.transcribe_unaligned_many(eps, streams=streams, group=group)
         assert len(many) == len(solo)
         for (u1, g1, al1), (u2, g2, al2) in zip(solo, many):

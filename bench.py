@@ -853,7 +853,7 @@ def main():
                 base = cpu_baseline(sd, args.cpu_seconds, threads)
                 Ls = int(min(args.seconds, args.decode_episode_seconds) * 16000)
                 ep_s = synth.synth_audio_batch(1, Ls, 2469 + rank)
-                port = max((decode_episode_cpu(asr_sd, sd, ep_s, c)[0] for c in sorted({base["cores"], min(16, base["host_cpus"])})),
+                port = max((decode_episode_cpu(asr_sd, sd, ep_s, c)[0] for c in sorted({base["cores"], min(16, base["host_cpus"])}) for _ in range(2)),
                            key=lambda r: r["frames_per_s"])       # (the token loop's small GEMMs like fewer threads than the encoder)
                 line["cpu_baseline"] = {"value": port["frames_per_s"], "unit": "frames/s", "cores": port["threads"], "kind": "port",
                                         "host_cpus": base["host_cpus"], "tokens": port["tokens"], "decode_s": port["decode_s"], "sd_s": port["sd_s"],
@@ -864,9 +864,11 @@ def main():
                                                     full_seconds=None if (args.no_cpu_full_clip or args.workload != "clip") else args.seconds)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
             if decode_episode is not None and cpu_args is not None:
+                # best of two runs per thread count: the first one also warms the pool and the allocator
                 port, toks = max((decode_episode_cpu(cpu_args[0], sd, cpu_args[1], c)
-                                  for c in sorted({line["cpu_baseline"]["cores"], min(16, line["cpu_baseline"]["host_cpus"])})),
+                                  for c in sorted({line["cpu_baseline"]["cores"], min(16, line["cpu_baseline"]["host_cpus"])}) for _ in range(2)),
                                  key=lambda r: r[0]["frames_per_s"])
+                port["what"] = port["what"].replace("one run", "best of two runs")
                 same = len(toks) == len(cpu_args[2]) and bool((toks == cpu_args[2]).all())
                 decode_episode["cpu_port"] = port
                 decode_episode["gpu_over_cpu"] = decode_episode["frames_per_s"] / port["frames_per_s"]

@@ -1,11 +1,11 @@
 #!/bin/bash
 # One GPU job that regenerates the round's measurement artefacts (run through gpurun; copy the results from
-# gpurun_out/r4final/ into profiles/ with the r4_ prefix): bench lines of every workload, rocprofv3 kernel stats,
+# gpurun_out/r5final/ into profiles/ with the r5_ prefix): bench lines of every workload, rocprofv3 kernel stats,
 # FETCH / WRITE traffic passes, SQ counter passes, decode-step and short-clip traces.  PMC passes are separate runs with
 # --kernel-trace only, as the pool requires; every profiled program is `python3 <script>` directly after `--`.
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4final
+O=$R/gpurun_out/r5final
 mkdir -p $O
 cd $R
 python bench.py > $O/bench_1h.json 2> $O/bench_1h.err
@@ -21,7 +21,8 @@ python scripts/bench_short.py 10 30 60 120 300 600 > $O/short_clips_product.txt 
 python scripts/bench_greedy_step.py 1 16 32 64 128 256 > $O/decode_step.txt 2>&1
 python scripts/bench_episode_streams.py 3600 8 2>&1 | grep -v amdgpu.ids > $O/episode_streams.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode > $O/bench_1h_under_rocprof.log 2>&1
+# (only the 1-hour steps may be in the stats table: its averages are what roofline.avg_launch_ms is checked against)
+rocprofv3 --kernel-trace --stats -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency > $O/bench_1h_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $O/pmc_sq -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency --steps 2 --warmup 1 > $O/pmc_sq.log 2>&1
@@ -35,6 +36,11 @@ python scripts/pmc_sq_summary.py $Q > $O/pmc_sq_all_kernels.txt
 python scripts/pmc_generic.py $I tal > $O/pmc_inst_all_kernels.txt
 S=$(find $O/stats -name "*.db" | head -1); F=$(find $O/pmc_fetch -name "*.db" | head -1); W=$(find $O/pmc_write -name "*.db" | head -1)
 python scripts/rocpd_summary.py $S > $O/bench_1h_kernel_stats.txt
+if grep -q "gemm_s64_kernel" $O/bench_1h_kernel_stats.txt; then
+    echo "profile_round.sh: the 1-hour kernel stats contain short-input dense launches (gemm_s64_kernel): the stats pass ran more than the 1-hour steps" >&2
+    mv $O/bench_1h_kernel_stats.txt $O/bench_1h_kernel_stats.REJECTED.txt
+    FAILED=1
+fi
 python scripts/pmc_traffic_json.py $F $W > $O/pmc_traffic.json
 (python scripts/rocpd_pmc.py $F tal; python scripts/rocpd_pmc.py $W tal) > $O/pmc_traffic_all_kernels.txt
 python scripts/rocpd_summary.py $(find $O/dstats -name "*.db" | head -1) > $O/decode_5min_kernel_stats.txt
@@ -42,3 +48,4 @@ python scripts/rocpd_sequence.py $(find $O/gstep -name "*.db" | head -1) 37 > $O
 python scripts/rocpd_sequence.py $(find $O/short -name "*.db" | head -1) 52 > $O/clip_30s_kernel_sequence.txt
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_inst $O/dstats $O/gstep $O/short
 ls -la $O
+exit ${FAILED:-0}

@@ -1400,7 +1400,10 @@ extern "C" int tal_unaligned_consume(tal_unaligned_state* st, int64_t token, con
     st->rec_chunk_start[rec] = chunk_start;
     st->rec_len[rec] = S;
     float* row = st->rec_attn + rec * (int64_t)st->rec_stride;
-    // progress = sum_i attn[i] * (i / S): float32 products (system.py:405-408), summed in double and rounded once
+    // progress = sum_i attn[i] * (i / S): float32 products (system.py:405-408), summed in double and rounded ONCE to float32.  The
+    // reference leaves the order of its float32 sum to torch (a vectorised reduction on the CPU, a tree on CUDA: its own devices differ
+    // in the last place); the exactly-rounded sum is the one value every such order is within an ulp of, and the decisions below on
+    // rows a few ulps from the thresholds are pinned by tests/test_host_logic.py::test_unaligned_consume_progress_next_to_the_threshold
     double acc = 0.0;
     const float fS = (float)S;
     for (int i = 0; i < S; ++i) {

@@ -18,6 +18,7 @@
 // the power tile; the output is written once, coalesced, as [B, T, 80].
 #include <math.h>
 
+#include <cstddef>
 #include <vector>
 
 #include "common.h"
@@ -46,8 +47,9 @@ struct LogmelPlan {
     int folded;                            // 1 if the window is symmetric (w[n] == w[400-n], w[0] == 0): use fbasis
     int mel_lo[NMEL];
     int mel_cnt[NMEL];
-    float mel_w[NMEL * MAXW];
+    alignas(16) float mel_w[NMEL * MAXW];      // read as 16-byte vectors by the short-input kernel
 };
+static_assert(offsetof(LogmelPlan, mel_w) % 16 == 0, "LogmelPlan::mel_w must be 16-byte aligned");
 
 // AT: element type of the waveform -- float, or _Float16 for callers that hand over `.half()` audio as the reference's
 // GPU-era call sites do (tal/asr/system.py:92,285, tal/baseline/reconcile.py:78); the samples are widened while they are

@@ -41,13 +41,14 @@ def _layer_struct(layer):
 def layer_weights(layer):
     """Cached tal_decoder_layer_w for a ModRZTXDecoderLayer (rebuilt when a parameter changes)."""
     # (walking the module tree costs ~60 us per layer and call -- 8 % of an episode's decode at one call per layer and encoder
-    #  window; the cached list is rebuilt whenever any module registered a Parameter since, models._PARAM_EPOCH)
-    from .models import _PARAM_EPOCH
+    #  window; the cached list is rebuilt whenever a module of this layer registered a Parameter since, models.param_epoch)
+    from .models import param_epoch
+    epoch = param_epoch(layer)
     plist = layer.__dict__.get("_tal_plist")
     # (a conversion in torch's overwrite-parameters mode replaces the Parameter objects without registering them: the first one
     #  is compared by identity)
-    if plist is None or plist[0] != _PARAM_EPOCH[0] or plist[1][0] is not next(iter(layer.parameters()), None):
-        plist = (_PARAM_EPOCH[0], list(layer.parameters()))
+    if plist is None or plist[0] != epoch or plist[1][0] is not next(iter(layer.parameters()), None):
+        plist = (epoch, list(layer.parameters()))
         layer.__dict__["_tal_plist"] = plist
     key = tuple((p.data_ptr(), p._version) for p in plist[1])
     cached = getattr(layer, "_tal_w", None)

@@ -54,15 +54,40 @@ def _htk_filterbank(n_freqs, n_mels, sample_rate, f_min=0.0, f_max=None):
     return torch.clamp(torch.min(falling, rising), min=0.0)
 
 
-# bumped whenever any nn.Module registers a Parameter (cached parameter lists compare against it, TDS._param_key)
-_PARAM_EPOCH = [0]
+# Cached parameter lists (TDS._param_key, decoder.layer_weights) must notice a REPLACED Parameter object (`layer.weight =
+# nn.Parameter(...)`, load_state_dict(assign=True): both go through Module.register_parameter).  The counter that tells them is
+# per module TREE of this package: `_adopt(root)` puts one shared cell into the __dict__ of every module of the tree, and the
+# registration hook -- installed when the first tree is adopted, not at import -- bumps the cell of the module it is called for
+# and touches nothing else: modules of the host program (the reference's training code, Lightning) carry no cell.
+_EPOCH_ATTR = "_tal_param_epoch"
+_hook_installed = [False]
 
 
 def _note_parameter_registration(module, name, param):
-    _PARAM_EPOCH[0] += 1
+    cell = module.__dict__.get(_EPOCH_ATTR)
+    if cell is not None:
+        cell[0] += 1
 
 
-torch.nn.modules.module.register_module_parameter_registration_hook(_note_parameter_registration)
+def _adopt(root):
+    """Give every module of `root`'s tree the tree's parameter-registration counter; -> the counter cell."""
+    if not _hook_installed[0]:
+        torch.nn.modules.module.register_module_parameter_registration_hook(_note_parameter_registration)
+        _hook_installed[0] = True
+    cell = root.__dict__.get(_EPOCH_ATTR)
+    if cell is None:
+        cell = [0]
+    for m in root.modules():
+        m.__dict__[_EPOCH_ATTR] = cell
+    return cell
+
+
+def param_epoch(root):
+    """The tree's counter value (the tree is adopted on first use: modules built by other code, e.g. a deep copy, too)."""
+    cell = root.__dict__.get(_EPOCH_ATTR)
+    if cell is None:
+        cell = _adopt(root)
+    return cell[0]
 
 
 class _Spectrogram(nn.Module):
@@ -205,6 +230,7 @@ class TDS(nn.Module):
             for i in range(1, len(sizes))])
         self._plist = None
         self._plist_epoch = -1
+        _adopt(self)
         self._descs = {}        # (first, last) -> tal_tds_desc
         self._packs = {}        # stage -> packed / split weights (kept alive here)
         self._desc_key = None   # parameter versions the caches were built for
@@ -216,12 +242,13 @@ class TDS(nn.Module):
 
     def _param_key(self):
         # (walking the module tree costs ~200 us per call, the cached list ~15 us: it matters for 30-second clips)
-        # The list is rebuilt whenever ANY module registered a Parameter since it was taken (_PARAM_EPOCH: direct
+        # The list is rebuilt whenever a module of THIS tree registered a Parameter since it was taken (param_epoch: direct
         # `layer.weight = nn.Parameter(...)` assignments and load_state_dict(assign=True) go through register_parameter)
         # or this module was converted (_apply); in-place updates show in p._version, storage moves in data_ptr().
-        if self._plist is None or self._plist_epoch != _PARAM_EPOCH[0]:
+        epoch = param_epoch(self)
+        if self._plist is None or self._plist_epoch != epoch:
             self._plist = list(self.parameters())
-            self._plist_epoch = _PARAM_EPOCH[0]
+            self._plist_epoch = epoch
         return tuple((p.data_ptr(), p._version) for p in self._plist)
 
     def _stage_pack(self, s):
@@ -470,6 +497,7 @@ class ModRZTXDecoderLayer(nn.Module):
         self.resweight_src = nn.Parameter(torch.Tensor([0]))
         self.nhead = nhead
         self.src_attn_weights = None
+        _adopt(self)
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None):

@@ -189,6 +189,7 @@ class _UnalignedRun:
         prime = generated.detach().cpu().numpy().astype(np.int64)[0]
         self.st = st = N.UnalignedState()
         self._st_ref = C.byref(st)
+        self._retired = []
         self._gen_t = torch.empty(max(self.HOST_TOKENS0, 2 * prime.size), dtype=torch.int64).pin_memory()    # (pinned: the library uploads
         self.gen = self._gen_t.numpy()                                                                          #  a rewritten prefix itself)
         self.gen[:prime.size] = prime
@@ -210,7 +211,7 @@ class _UnalignedRun:
         # K | V of every encoder frame for every decoder layer, once per episode (windows become views: _GreedySession.set_episode)
         # -- whenever whole windows fit the episode; shorter episodes (python-slice windows that wrap) project window by window
         self.kv_all = self.kpm_all = None
-        if self.enc.shape[1] >= chunk_size and st.encoder_len >= chunk_size and self.EPISODE_TABLE:
+        if self.enc.shape[1] >= chunk_size and st.encoder_len >= chunk_size and self.EPISODE_TABLE and self._table_fits(model):
             E = self.enc.shape[2]
             self.kv_all = []
             for layer in model.decoder.layers:
@@ -225,6 +226,20 @@ class _UnalignedRun:
 
     HOST_TOKENS0, DEV_TOKENS0 = 4096, 1024      # initial capacities of the token stream (host / device); both grow by doubling
     EPISODE_TABLE = True                        # False: every window is projected on its own (tal_cross_kv_fwd), as in round 3
+    TABLE_MAX_FRACTION = 0.25                   # of the memory this process could still get: a table beyond it is not built
+
+    def table_bytes(self, model):
+        """Bytes of the episode-wide K | V table: decoder layers x encoder frames x 2E floats (737 MB per hour of audio for 4 x 512)."""
+        return len(model.decoder.layers) * self.enc.shape[1] * 2 * self.enc.shape[2] * 4
+
+    def _table_fits(self, model):
+        """The table is a speed-up (a window move becomes one launch), not a requirement: with many sessions resident
+        (transcribe_unaligned_many keeps streams x group + the queue depth + 1 runs alive) it is only built while it takes at most
+        TABLE_MAX_FRACTION of what the device can still give this process (free memory + torch's cached, unallocated blocks);
+        otherwise the run projects window by window (12 launches per window move instead of 1, same results)."""
+        free, _ = torch.cuda.mem_get_info(self.dev)
+        spare = free + torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev)
+        return self.table_bytes(model) <= self.TABLE_MAX_FRACTION * spare
 
     def _point_buffers(self):
         st = self.st
@@ -255,6 +270,9 @@ class _UnalignedRun:
             k = self.gen.size
             grown = torch.empty(2 * k, dtype=torch.int64).pin_memory()
             grown.numpy()[:k] = self.gen
+            # (the library may still have an upload of a rewritten prefix queued FROM the old buffer, tal_unaligned_group_run: it is
+            #  kept until the run ends instead of going back to torch's pinned-memory pool, where another thread could reuse it)
+            self._retired.append(self._gen_t)
             self._gen_t, self.gen = grown, grown.numpy()
             self.rec_cs = np.concatenate([self.rec_cs, np.empty(k, dtype=np.int64)])
             self.rec_attn = np.concatenate([self.rec_attn, np.empty((k, self.rec_attn.shape[1]), dtype=np.float32)])
@@ -382,6 +400,12 @@ class System:
         of ceil(episodes / 4) sessions, at most 4 -- the best or near-best measured split for 8 one-hour episodes (4 x 2: 3.9-4.3x
         the one-at-a-time loop) and for 32 ten-minute ones (4 x 4: 5.4x; 2 x 16: 5.7x), profiles/r4_episode_streams*.txt.
 
+        Device memory: every session in flight (streams x group, plus the producer's queue of max(2, group) + 1 prepared episodes in
+        group mode) holds its encoder output and -- while it fits -- an episode-wide K | V table of decoder layers x encoder frames x
+        2E floats (737 MB per hour of audio for the reference's 4 x 512 decoder: ~15 GB for 21 one-hour runs).  A run builds the table
+        only while it takes at most a quarter of the memory the process can still get (_UnalignedRun._table_fits) and projects window
+        by window otherwise: slower window moves, same results.
+
         episodes: list of (audio [1, L] float tensor -- host (pinned or not) or device --, audio_lens LongTensor [1]).
         Returns [(utterance dicts, generated, alignments)] in episode order, identical to the solo runs in either mode."""
         if not episodes:
@@ -461,6 +485,7 @@ class System:
             G16 = N.TAL_GROUP_MAX
             st_arr, ctx_arr, cap_arr = (C.POINTER(N.UnalignedState) * G16)(), (C.POINTER(N.GreedyCtx) * G16)(), (C.c_int64 * G16)()
             i, drained = -1, False
+            failing = [None]                 # episode index the failing call was made for (None: not attributable to one episode)
             with torch.cuda.device(dev), torch.cuda.stream(stream):
                 handle = N.stream_handle()
                 try:
@@ -486,15 +511,19 @@ class System:
                             continue
                         runs = [sl[1] for sl in slots]
                         merged, alone = [], []
-                        for r in runs:
+                        for sl in slots:
+                            r = sl[1]
+                            failing[0] = sl[0]
                             if r.st.flags or r.session is None:
                                 r.prepare()               # (whatever the control flow asked for: window, prefix upload, room)
                             (merged if r.can_merge() else alone).append(r)
                         if len(merged) < 2:
                             alone, merged = alone + merged, []
                         for r in alone:                   # steps the merged launches do not take
+                            failing[0] = next(sl[0] for sl in slots if sl[1] is r)
                             r.prepare()                   # (room for the appended token: nothing else checks it on this path)
                             r.consume(*r.step_alone())
+                        failing[0] = None
                         if merged:
                             for k, r in enumerate(merged):
                                 st_arr[k], ctx_arr[k], cap_arr[k] = C.pointer(r.st), C.pointer(r.session.ctx), r.gen_dev.numel()
@@ -502,6 +531,8 @@ class System:
                             limit = 4 if alone else (16 if len(slots) < group and not drained else 64)
                             rc = lib.tal_unaligned_group_run(st_arr, ctx_arr, cap_arr, len(merged), limit, handle)
                             if rc < 0:
+                                # (a merged call: the library's message names the session; the episodes of the group are reported)
+                                failing[0] = [sl[0] for sl in slots if sl[1] in merged]
                                 N.check(rc, "tal_unaligned_group_run")
                             if stats is not None:
                                 stats["calls"] = stats.get("calls", 0) + 1
@@ -513,7 +544,11 @@ class System:
                                         stats["flag_%d" % r.st.flags] = stats.get("flag_%d" % r.st.flags, 0) + 1
                     stream.synchronize()
                 except BaseException as e:      # noqa: B902 -- reported to the caller below
-                    errors.append((i, e))
+                    errors.append((failing[0] if failing[0] is not None else [sl[0] for sl in slots] or i, e))
+                    try:
+                        stream.synchronize()    # merged launches may still be in flight: the sessions' workspaces and pinned result
+                    except BaseException:       # noqa: B902 -- buffers are released when `slots` goes out of scope
+                        pass
                 finally:
                     while not drained:          # (after an error: let the producer finish -- it may be blocked on a full queue)
                         drained = ready.get() is None
@@ -528,7 +563,8 @@ class System:
             t.join()
         if errors:
             i, e = errors[0]
-            raise RuntimeError("transcribe_unaligned_many: episode %d failed: %r" % (i, e)) from e
+            which = "episode %d" % i if isinstance(i, int) else "one of the episodes %s (decoded in one group)" % (list(i),)
+            raise RuntimeError("transcribe_unaligned_many: %s failed: %r" % (which, e)) from e
         return results
 
     # ------------------------------------------------------------------ episode -> utterance dicts

@@ -102,3 +102,76 @@ def test_unaligned_consume_follows_the_pinned_control_flow():
         else:
             assert lens.tolist() == g["attn_len"].tolist()
             np.testing.assert_allclose(np.concatenate([bufs["attn"][i, :lens[i]] for i in range(st.n_rec)]), g["attn_flat"], atol=1e-5, rtol=0)
+
+
+def test_unaligned_consume_progress_next_to_the_threshold():
+    """The attention centre of mass (tal/asr/system.py:405-408) decides `progress > thresh_prct` (window shift) and
+    `progress > highest_progress` (stall counter).  The reference leaves the order of its float32 sum to torch (a vectorised
+    reduction on the CPU, a tree on CUDA: its own two devices differ in the last place); tal_unaligned_consume takes the float32
+    products, adds them in double and rounds ONCE to float32.  Pinned here on rows whose exact sum lies within a few ulps of the
+    threshold: the decision is the one exact arithmetic makes -- no row within an ulp flips by summation order."""
+    import ctypes as C
+    import numpy as np
+    from tal_asrd_amd import _native as N
+    lib = N.lib()
+    S, thresh = 357, 0.5
+    rng = np.random.RandomState(7)
+    ramp = (np.arange(S, dtype=np.float32) / np.float32(S)).astype(np.float32)
+    checked = {True: 0, False: 0}
+    for trial in range(200):
+        # two spikes either side of the window centre + a little mass everywhere; the weight of the upper spike is bisected until the
+        # exact centre of mass sits a few float32 steps from the threshold, on the side `want_above`
+        a, b = int(rng.randint(120, 170)), int(rng.randint(190, 240))
+        base = (rng.rand(S) * 1e-4).astype(np.float32)
+        want_above = bool(trial & 1)
+        lo, hi = 0.0, 1.0
+        for _ in range(int(rng.randint(19, 25))):          # stop a few float32 steps (6e-8 at 0.5) away, not on the threshold
+            w = 0.5 * (lo + hi)
+            row = base.copy()
+            row[a] += np.float32(1.0 - w)
+            row[b] += np.float32(w)
+            exact = float(np.sum((row * ramp).astype(np.float64)))        # the float32 products, summed exactly enough (53 bits)
+            if exact > thresh:
+                hi = w
+            else:
+                lo = w
+        w = hi if want_above else lo
+        row = base.copy()
+        row[a] += np.float32(1.0 - w)
+        row[b] += np.float32(w)
+        exact = float(np.sum((row * ramp).astype(np.float64)))
+        assert abs(exact - thresh) < 2e-6                              # a handful of float32 steps at 0.5
+        decision = float(np.float32(exact)) > thresh                    # rounded once
+        st, bufs = _unaligned_state([1, 5, 6], encoder_len=4000)
+        st.window_time, st.n_rec = 3, 2
+        row = np.ascontiguousarray(row, dtype=np.float32)
+        flags = lib.tal_unaligned_consume(C.byref(st), 7, row.ctypes.data, S)
+        assert flags >= 0, lib.tal_last_error()
+        moved = bool(flags & N.UNALIGNED_WINDOW_MOVED)
+        assert moved == decision, (trial, exact, moved)
+        assert (st.chunk_start == st.shift_frames) == decision
+        checked[decision] += 1
+    assert checked[True] > 20 and checked[False] > 20
+
+
+def test_parameter_registration_counter_is_scoped_to_this_packages_modules():
+    """A drop-in library must not watch the host program's modules: the counter that invalidates cached
+    parameter lists is per module tree of this package; a Parameter registered by any other module leaves it alone."""
+    import torch
+    from torch import nn
+    from tal_asrd_amd import models as M
+    tds = M.TDS(input_size=8, sizes=[8, 16], depths=[1])
+    layer = M.ModRZTXDecoderLayer(64, 4, 128)
+    e_tds, e_layer = M.param_epoch(tds), M.param_epoch(layer)
+    nn.Linear(4, 4)                                         # the host program builds a module
+    host = nn.Module()
+    host.w = nn.Parameter(torch.zeros(3))
+    assert (M.param_epoch(tds), M.param_epoch(layer)) == (e_tds, e_layer)
+    conv = tds.blocks[0][0]
+    conv.weight = nn.Parameter(conv.weight.detach().clone())                # replaced inside the tree: noticed by that tree only
+    assert M.param_epoch(tds) == e_tds + 1 and M.param_epoch(layer) == e_layer
+    layer.linear1.bias = nn.Parameter(layer.linear1.bias.detach().clone())
+    assert M.param_epoch(layer) == e_layer + 1 and M.param_epoch(tds) == e_tds + 1
+    k0 = tds._param_key()
+    conv.weight = nn.Parameter(conv.weight.detach().clone())
+    assert tds._param_key() != k0                           # the cached list was rebuilt (new storage)

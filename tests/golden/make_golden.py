@@ -372,15 +372,22 @@ def sec_uisrnn(ns):
 
 
 def sec_variants(ns):
-    """The other model variants of tal/asr/models.py:79-84,103: '1x' (d = 256, head dim 64) with the speaker head, and '2x'
-    with speaker ids as extra vocabulary tokens (use_speaker_head=False, V = 10000 + 6008): encoder projections, decode
+    """The other model variants of tal/asr/models.py:79-84,103: '1x' (d = 256, head dim 64) with the speaker head, '2x'
+    with speaker ids as extra vocabulary tokens (use_speaker_head=False, V = 10000 + 6008), '1x' without the factorised
+    embedding (embed_size=0): encoder projections, decode
     / decode_spk last rows, attention rows, and a short generate_unaligned trajectory each."""
     import types
     System = ns.system.System
     tok = types.SimpleNamespace(eos_token_id=1, bos_token_id=0, pad_token_id=2)
     keys = json.load(open(os.path.join(HERE, "state_dict_keys.json")))
+    only = os.environ.get("TAL_GOLDEN_VARIANTS")         # e.g. "1x_e0": record these variants only (the others' files stay as they are)
     for tag, kw in (("1x_spk", dict(model_type="1x", num_speakers=6008, vocab_size=10000, use_speaker_head=True)),
-                    ("2x_tok", dict(model_type="2x", num_speakers=6008, vocab_size=10000, use_speaker_head=False))):
+                    ("2x_tok", dict(model_type="2x", num_speakers=6008, vocab_size=10000, use_speaker_head=False)),
+                    # embed_size=0 (tal/asr/models.py:104-117,243-246): no factorised embedding -- nn.Embedding(V, d) feeds the decoder
+                    # directly and the tied LM head is h . embedding.weight^T without the projection
+                    ("1x_e0", dict(model_type="1x", num_speakers=6008, vocab_size=10000, use_speaker_head=True, embed_size=0))):
+        if only and tag not in only.split(","):
+            continue
         model = fill(ns.models.ASRModel(**kw))
         keys["ASRModel_" + tag] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
         V = model.embedding.weight.shape[0]

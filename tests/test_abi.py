@@ -97,6 +97,7 @@ def test_error_path_no_gpu_needed():
     ("SDModel", lambda m: m.SDModel()),
     ("ASRModel_2x_spk", lambda m: m.ASRModel("2x", num_speakers=6008, use_speaker_head=True)),
     ("ASRModel_1x_tok", lambda m: m.ASRModel("1x", num_speakers=40, use_speaker_head=False)),
+    ("ASRModel_1x_e0", lambda m: m.ASRModel("1x", num_speakers=6008, vocab_size=10000, use_speaker_head=True, embed_size=0)),
 ])
 def test_state_dict_keys_match_reference(name, ctor):
     from tal_asrd_amd import models

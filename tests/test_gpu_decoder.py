@@ -181,13 +181,16 @@ def test_core_rnn_golden():
 
 
 VARIANTS = {"1x_spk": dict(model_type="1x", num_speakers=6008, vocab_size=10000, use_speaker_head=True),
-            "2x_tok": dict(model_type="2x", num_speakers=6008, vocab_size=10000, use_speaker_head=False)}
+            "2x_tok": dict(model_type="2x", num_speakers=6008, vocab_size=10000, use_speaker_head=False),
+            # embed_size=0 (tal/asr/models.py:104-117,243-246): no factorised embedding -- the `proj_t == nullptr` arms of the LM head
+            # (tal_lm_head_fwd) and of the merged LM-head + pick kernel (lm_pick_body) run against the reference here
+            "1x_e0": dict(model_type="1x", num_speakers=6008, vocab_size=10000, use_speaker_head=True, embed_size=0)}
 
 
 @pytest.mark.parametrize("tag", sorted(VARIANTS))
 def test_model_variants_decode_and_greedy_flow(tag):
-    """The other model variants of tal/asr/models.py:79-84,103 -- '1x' (d = 256, head dim 64) with the speaker head and '2x'
-    with speaker ids as 6008 extra vocabulary tokens -- against fixtures recorded from the reference
+    """The other model variants of tal/asr/models.py:79-84,103 -- '1x' (d = 256, head dim 64) with the speaker head, '2x'
+    with speaker ids as 6008 extra vocabulary tokens, '1x' with embed_size=0 -- against fixtures recorded from the reference
     (tests/golden/make_golden.py, section `variants`): state_dict keys, encoder projection, decode / decode_spk last rows,
     attention rows, and a 150-step System.generate_unaligned trajectory (identical tokens and window starts)."""
     import json

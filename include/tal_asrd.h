@@ -44,7 +44,7 @@ extern "C" {
 #define TAL_MAX_STAGES 4
 #define TAL_MAX_DEPTH 8
 
-int tal_version(void);          /* 400 = 0.4.0 */
+int tal_version(void);          /* 410 = 0.4.1 */
 const char* tal_last_error(void);
 
 /* Process-wide behaviour switches.  The library never reads the environment: which kernels a caller gets depends on its
@@ -224,6 +224,16 @@ size_t tal_tds_status_offset(const tal_tds_desc* d, int B, int64_t T);
 /* x [B, T, channels[0]] -> y [B, T', channels[n_stages]] */
 int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t T, float* y,
                 void* workspace, size_t workspace_bytes, void* stream);
+/* The same call on a log-mel tensor BEFORE LogMelSpec's global-mean subtraction (tal/asr/models.py:52: `x -= x.mean()`;
+ * tal_logmel_fwd with subtract_mean = 0 leaves the scalar in *mean_out): x_mean is a DEVICE pointer to that scalar.  The first
+ * resize conv has no padding (models.py:363-364), so conv(x - m) = conv(x) - m * sum_k w[k]: the subtraction is applied as a
+ * correction of that conv's bias and the separate pass over the log-mel (two activation-sized transfers and a launch) is not run.
+ * Same workspace, status word and re-run rule as tal_tds_fwd.  Only for stacks whose first resize conv is the 1 -> 10 channels
+ * per group form (tal_tds_premean_ok() != 0: the reference's 80 -> 800 encoder, x 16-byte aligned); TAL_EINVAL otherwise.
+ * Results differ from tal_tds_fwd on the subtracted tensor by fp32 rounding of the first conv only. */
+int tal_tds_premean_ok(const tal_tds_desc* d, const float* x);
+int tal_tds_premean_fwd(const tal_tds_desc* d, const float* x, const float* x_mean, int B, int64_t T, float* y,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* Time-tiled form of the same call for ONE item (SURVEY.md section 8b `halo_mode`): the input is cut into tiles of
  * `out_tile` output frames; each tile runs as its own tal_tds_fwd over the slice of x that carries its receptive-field halo

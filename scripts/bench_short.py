@@ -27,8 +27,8 @@ for sec in [float(a) for a in sys.argv[1:]] or [30.0, 300.0]:
         heads = (m.spk_embed_proj.weight, m.spk_embed_proj.bias, m.spk_logit_proj.weight, m.spk_logit_proj.bias)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            mel = m.extract_features(static_x)
-            y, chk = ops.tds_forward(enc._descriptor(0, len(enc.sizes) - 1), mel, enc.sizes[-1], defer=True)
+            mel, mean = m.logmelspec.forward_unsubtracted(static_x)
+            y, chk = ops.tds_forward(enc._descriptor(0, len(enc.sizes) - 1), mel, enc.sizes[-1], defer=True, x_mean=mean)
             feat, _, ids = ops.sd_head(y, *heads, want_logits=False, want_ids=True)
         def replay():
             static_x.copy_(x); graph.replay()

@@ -96,6 +96,8 @@ SIGNATURES = {
     "tal_tds_workspace_bytes": (_sz, [C.POINTER(TdsDesc), _i, _i64]),
     "tal_tds_status_offset": (_sz, [C.POINTER(TdsDesc), _i, _i64]),
     "tal_tds_fwd": (_i, [C.POINTER(TdsDesc), _p, _i, _i64, _p, _p, _sz, _p]),
+    "tal_tds_premean_ok": (_i, [C.POINTER(TdsDesc), _p]),
+    "tal_tds_premean_fwd": (_i, [C.POINTER(TdsDesc), _p, _p, _i, _i64, _p, _p, _sz, _p]),
     "tal_tds_halo": (_i, [C.POINTER(TdsDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tal_tds_tiled_workspace_bytes": (_sz, [C.POINTER(TdsDesc), _i64, _i64]),
     "tal_tds_tiled_status_offset": (_sz, [C.POINTER(TdsDesc), _i64, _i64]),

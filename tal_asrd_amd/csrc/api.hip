@@ -187,7 +187,7 @@ static int64_t conv_out_len(int64_t t) { return t < 21 ? 0 : (t - 21) / 2 + 1; }
 
 using namespace tal;
 
-extern "C" int tal_version(void) { return 400; /* 0.4.0: tal_greedy_ctx grew (k_pitch, episode-wide K | V table), merged decode steps, tal_unaligned_*, tal_logmel_f16_fwd; 0.3.0: tal_set_option */ }
+extern "C" int tal_version(void) { return 410; /* 0.4.1: tal_tds_premean_fwd / tal_tds_premean_ok; 0.4.0: tal_greedy_ctx grew (k_pitch, episode-wide K | V table), merged decode steps, tal_unaligned_*, tal_logmel_f16_fwd; 0.3.0: tal_set_option */ }
 
 // Host-side helper of the decode loop (no device work): ngram_repeat_mask(row, n).sum() of tal/asr/util.py:5-17 -- the number
 // of positions covered by an n-gram that already occurred earlier in the row; like the reference, n-gram starts run to
@@ -386,8 +386,31 @@ extern "C" size_t tal_tds_workspace_bytes(const tal_tds_desc* d, int B, int64_t 
     return tal_tds_status_offset(d, B, T) + 64;
 }
 
+static int tds_fwd_impl(const tal_tds_desc* d, const float* x, const float* x_mean, int B, int64_t T, float* y, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t T, float* y, void* workspace,
                            size_t workspace_bytes, void* stream) {
+    return tds_fwd_impl(d, x, nullptr, B, T, y, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tal_tds_premean_ok(const tal_tds_desc* d, const float* x) {
+    if (check_desc(d) || d->n_stages < 1) return 0;
+    return gconv_s2_can_fold_mean(d->channels[0], d->channels[1], d->groups, x) ? 1 : 0;
+}
+
+extern "C" int tal_tds_premean_fwd(const tal_tds_desc* d, const float* x, const float* x_mean, int B, int64_t T, float* y, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    TAL_CHECK_ARG(x_mean, "tal_tds_premean_fwd: null mean pointer");
+    TAL_CHECK_ARG(tal_tds_premean_ok(d, x), "tal_tds_premean_fwd: the first resize conv of this stack (%d -> %d channels, %d groups) has no mean-folding "
+                  "kernel: subtract the mean (tal_subtract_scalar) and call tal_tds_fwd", d->channels[0], d->channels[1], d->groups);
+    return tds_fwd_impl(d, x, x_mean, B, T, y, workspace, workspace_bytes, stream);
+}
+
+static int tds_fwd_impl(const tal_tds_desc* d, const float* x, const float* x_mean, int B, int64_t T, float* y, void* workspace,
+                        size_t workspace_bytes, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     TAL_CHECK_ARG(x && y && workspace, "tal_tds_fwd: null pointer");
@@ -452,7 +475,7 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
             if (s2_mfma_ok(i, Tc))
                 rc = launch_gconv_s2_f16x3(cur, d->down_w_frag[i], d->down_b[i], B, Tc, cin, c, d->groups, nullptr, s, range_flag, cur_split, a);
             else
-                rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, nullptr, s, a, range_flag);
+                rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, nullptr, s, a, range_flag, i == 0 ? x_mean : nullptr);
         } else {
             TAL_CHECK_ARG(!cur_split, "tal_tds_fwd: internal: stage %d would read a split activation through an fp32 kernel", i);
             // stride-2 resize conv: on the matrix cores when the fragments are there (10 -> 14, 14 -> 18 per group); it pays from
@@ -460,7 +483,7 @@ extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t
             if (s2_mfma_ok(i, Tc))
                 rc = launch_gconv_s2_f16x3(cur, d->down_w_frag[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s, range_flag);
             else
-                rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s);
+                rc = launch_gconv_s2(cur, d->down_w[i], d->down_b[i], B, Tc, cin, c, d->groups, a, s, nullptr, nullptr, i == 0 ? x_mean : nullptr);
         }
         if (rc) return rc;
         ia = io;

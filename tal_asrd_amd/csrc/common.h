@@ -209,9 +209,11 @@ int launch_linear_f16x3(const void* xs, const void* wsplit, const float* b, cons
                         int N, int K, void* y, int out_split, float* ws, size_t ws_bytes, hipStream_t s, int* range_flag = nullptr,
                         int res_split = 0);
 // y_split != NULL: the output goes out in the hi / lo split form ONLY (first resize conv, 1 -> 10 channels per group)
+// in_mean != NULL: x is a log-mel before its mean subtraction; the scalar in_mean[0] is folded into the conv's bias (1 -> 10 only)
 int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, int64_t T_in, int C_in, int C_out,
-                    int groups, float* y, hipStream_t s, void* y_split = nullptr, int* range_flag = nullptr);
+                    int groups, float* y, hipStream_t s, void* y_split = nullptr, int* range_flag = nullptr, const float* in_mean = nullptr);
 bool gconv_s2_can_split(int C_in, int C_out, int groups, const float* x);
+bool gconv_s2_can_fold_mean(int C_in, int C_out, int groups, const float* x);
 int launch_gconv_res(const float* x, const float* wp, const float* bias, float alpha, int B, int64_t T, int C,
                      int groups, float* y, hipStream_t s);
 size_t gconv_f16x3_weight_bytes(int C_in, int C_out, int groups, int stride);

@@ -164,10 +164,14 @@ __global__ void gconv_generic_kernel(const float* __restrict__ x, const float* _
 // steps per iteration share their 27 input samples.  Same fmaf order as the generic kernel: bit-identical results.
 // YSPLIT: the output is written in the hi / lo split form of the fp16x3 dense layers only: lane pairs exchange halves so
 // that even lanes store two hi halves and odd lanes two lo halves (4-byte stores, 64 contiguous bytes per 32 channels).
+// in_mean != NULL: x is the log-mel BEFORE LogMelSpec's global-mean subtraction (tal/asr/models.py:52) and in_mean[0] the scalar:
+// the conv has no padding, so every output sees all 21 taps and conv(x - m) = conv(x) - m * sum_k w[k] exactly in real
+// arithmetic -- the subtraction becomes a correction of the channel's bias and the separate pass over the log-mel disappears.
 template <int COG, int NG, int TT, bool YSPLIT>
 __global__ __launch_bounds__(256) void gconv_s2_c1_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                          const float* __restrict__ bias, float* __restrict__ y, int64_t T_in,
-                                                         int64_t T_out, int C_in, int C_out, int* __restrict__ range_flag) {
+                                                         int64_t T_out, int C_in, int C_out, int* __restrict__ range_flag,
+                                                         const float* __restrict__ in_mean) {
     constexpr int NC = NG * COG;                       // output channels of this workgroup (<= 256)
     constexpr int TIN = (TT - 1) * 2 + KS;
     static_assert(NC <= 256 && NG % 4 == 0 && TT % 4 == 0, "shape");
@@ -188,7 +192,13 @@ __global__ __launch_bounds__(256) void gconv_s2_c1_kernel(const float* __restric
     float wk[KS];
 #pragma unroll
     for (int k = 0; k < KS; ++k) wk[k] = wp[((int64_t)(g0 + tid / COG) * KS + k) * COG + tid % COG];
-    const float bv = bias[ch];
+    float bv = bias[ch];
+    if (in_mean) {
+        float wsum = wk[0];
+#pragma unroll
+        for (int k = 1; k < KS; ++k) wsum += wk[k];
+        bv = fmaf(-in_mean[0], wsum, bv);
+    }
     const float* xc = xs + tid / COG;
     float* yc = y + (int64_t)b * T_out * C_out + ch;
     // split form: row = C_out * 4 bytes; channel ch -> 32-channel block ch / 32 (128 bytes), hi half at slot ch % 32, lo 64 bytes on.
@@ -262,9 +272,16 @@ bool gconv_s2_can_split(int C_in, int C_out, int groups, const float* x) {
            (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !c1_generic;
 }
 
+// the shapes whose first resize conv can take the mean of its input as a bias correction (gconv_s2_c1_kernel)
+bool gconv_s2_can_fold_mean(int C_in, int C_out, int groups, const float* x) {
+    return groups > 0 && C_in == groups && C_out == 10 * groups && groups % 20 == 0 && C_in % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !opt(OPT_GCONV_C1_GENERIC);
+}
+
 int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, int64_t T_in, int C_in, int C_out,
-                    int groups, float* y, hipStream_t s, void* y_split, int* range_flag) {
+                    int groups, float* y, hipStream_t s, void* y_split, int* range_flag, const float* in_mean) {
     TAL_CHECK_ARG(x && wp && bias && (y || y_split), "tal_gconv_s2_fwd: null pointer");
+    TAL_CHECK_ARG(!in_mean || gconv_s2_can_fold_mean(C_in, C_out, groups, x), "tal_gconv_s2_fwd: no mean-folding kernel for this shape");
     TAL_CHECK_ARG(!y_split || gconv_s2_can_split(C_in, C_out, groups, x), "tal_gconv_s2_fwd: no split-output kernel for this shape");
     TAL_CHECK_ARG(groups > 0 && C_in % groups == 0 && C_out % groups == 0, "tal_gconv_s2_fwd: channels %d->%d not divisible by groups %d", C_in, C_out, groups);
     TAL_CHECK_ARG(B > 0 && T_in >= KS, "tal_gconv_s2_fwd: T_in=%lld shorter than the kernel", (long long)T_in);
@@ -281,13 +298,13 @@ int launch_gconv_s2(const float* x, const float* wp, const float* bias, int B, i
         dim3 grid((unsigned)cdiv(T_out, small ? TTS : TT), (unsigned)(groups / NG), (unsigned)B);
         float* yo = y_split ? reinterpret_cast<float*>(y_split) : y;
         if (y_split && small)
-            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TTS, true>), grid, dim3(256), 0, s, x, wp, bias, yo, T_in, T_out, C_in, C_out, range_flag);
+            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TTS, true>), grid, dim3(256), 0, s, x, wp, bias, yo, T_in, T_out, C_in, C_out, range_flag, in_mean);
         else if (y_split)
-            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TT, true>), grid, dim3(256), 0, s, x, wp, bias, yo, T_in, T_out, C_in, C_out, range_flag);
+            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TT, true>), grid, dim3(256), 0, s, x, wp, bias, yo, T_in, T_out, C_in, C_out, range_flag, in_mean);
         else if (small)
-            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TTS, false>), grid, dim3(256), 0, s, x, wp, bias, yo, T_in, T_out, C_in, C_out, range_flag);
+            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TTS, false>), grid, dim3(256), 0, s, x, wp, bias, yo, T_in, T_out, C_in, C_out, range_flag, in_mean);
         else
-            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TT, false>), grid, dim3(256), 0, s, x, wp, bias, yo, T_in, T_out, C_in, C_out, range_flag);
+            hipLaunchKernelGGL((gconv_s2_c1_kernel<10, NG, TT, false>), grid, dim3(256), 0, s, x, wp, bias, yo, T_in, T_out, C_in, C_out, range_flag, in_mean);
         TAL_CHECK_LAUNCH("gconv (1 channel per group)");
         return TAL_OK;
     }

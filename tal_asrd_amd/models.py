@@ -140,6 +140,13 @@ class LogMelSpec(nn.Module):
         N.require_cuda(audio, "LogMelSpec.forward")
         return ops.logmel(self.plan(), audio, eps=self.eps, subtract_mean=True)
 
+    def forward_unsubtracted(self, audio: torch.Tensor):
+        """-> (log-mel [batch, frames, n_mels] BEFORE the mean subtraction, its global mean as a device tensor [1]): for callers that
+        hand both to TDS.forward_then(x_mean=...), where the subtraction becomes a bias correction of the first resize conv."""
+        N.require_cuda(audio, "LogMelSpec.forward_unsubtracted")
+        out, mean, _ = ops.logmel(self.plan(), audio, eps=self.eps, subtract_mean=False, return_stats=True)
+        return out, mean
+
 
 # ----------------------------------------------------------------------------
 # parameter containers whose direct call runs the HIP path
@@ -332,14 +339,19 @@ class TDS(nn.Module):
             return ops.tds_forward_tiled(self._descriptor(first, last), x, self.sizes[last], self.tile_frames)
         return ops.tds_forward(self._descriptor(first, last), x, self.sizes[last])
 
-    def forward_then(self, x, tail):
+    def forward_then(self, x, tail, x_mean=None):
         """tail(encoder output) with the fp16-range check of the encoder call read AFTER tail's kernels are enqueued (the
         read waits for the stream: done first, it would leave the GPU idle while the host launches the heads).  If the
-        check fires, the encoder is re-run on the exact fp32 kernels and tail is applied again."""
+        check fires, the encoder is re-run on the exact fp32 kernels and tail is applied again.
+        x_mean: x is LogMelSpec.forward_unsubtracted's tensor and x_mean its mean (folded into the first resize conv where the
+        kernels can -- ops.tds_premean_ok --, subtracted here otherwise)."""
         N.require_cuda(x, "TDS.forward")
+        desc = self._descriptor(0, len(self.sizes) - 1)
+        if x_mean is not None and (self._needs_tiles(x, 0, len(self.sizes) - 1) or not ops.tds_premean_ok(desc, x)):
+            x, x_mean = ops.subtract_scalar_(x, x_mean), None
         if self._needs_tiles(x, 0, len(self.sizes) - 1):
             return tail(self.forward_time_major(x))
-        y, chk = ops.tds_forward(self._descriptor(0, len(self.sizes) - 1), x, self.sizes[-1], defer=True)
+        y, chk = ops.tds_forward(desc, x, self.sizes[-1], defer=True, x_mean=x_mean)
         out = tail(y)
         if chk.flagged():
             out = tail(chk.rerun_exact())
@@ -418,7 +430,10 @@ class SDModel(nn.Module):
         def head(enc_out):
             return ops.sd_head(enc_out, self.spk_embed_proj.weight, self.spk_embed_proj.bias, self.spk_logit_proj.weight,
                                self.spk_logit_proj.bias, want_logits=want_logits, want_ids=True)
-        feat, logits, ids = self.encoder.forward_then(self.extract_features(x_wav), head)
+        # (eval: extract_features is the log-mel alone, models.py:430-438; its global-mean subtraction rides in the first resize conv's
+        #  bias instead of a pass of its own, TDS.forward_then)
+        mel, mean = self.logmelspec.forward_unsubtracted(x_wav)
+        feat, logits, ids = self.encoder.forward_then(mel, head, x_mean=mean)
         return (feat, ids, logits) if want_logits else (feat, ids)
 
     @torch.no_grad()

@@ -215,8 +215,8 @@ class RangeCheck:
     copy, i.e. a wait for the stream), `rerun_exact()` repeats the call on the exact fp32-input kernels into the same
     output tensor.  Deferring the read lets the caller enqueue the kernels that consume the encoder output first."""
 
-    def __init__(self, desc, x, y, ws, nws, off):
-        self.desc, self.x, self.y, self.ws, self.nws, self.off = desc, x, y, ws, nws, off
+    def __init__(self, desc, x, y, ws, nws, off, x_mean=None):
+        self.desc, self.x, self.y, self.ws, self.nws, self.off, self.x_mean = desc, x, y, ws, nws, off, x_mean
 
     def flagged(self):
         if self.desc.flags & N.TAL_TDS_EXACT_F32:
@@ -230,13 +230,27 @@ class RangeCheck:
         B, T, _ = self.x.shape
         exact = N.TdsDesc.from_buffer_copy(self.desc)       # (a copy: the cached descriptor may be in use by another thread's call)
         exact.flags |= N.TAL_TDS_EXACT_F32
-        N.check(lib.tal_tds_fwd(C.byref(exact), N.ptr(self.x), B, T, N.ptr(self.y), N.ptr(self.ws), self.nws,
-                                N.stream_handle()), "tal_tds_fwd (exact fp32 re-run)")
+        N.check(_tds_call(lib, exact, self.x, self.x_mean, B, T, self.y, self.ws, self.nws), "tal_tds_fwd (exact fp32 re-run)")
         return self.y
 
 
-def tds_forward(desc, x, c_out, check_range=True, defer=False):
+def _tds_call(lib, desc, x, x_mean, B, T, y, ws, nws):
+    if x_mean is None:
+        return lib.tal_tds_fwd(C.byref(desc), N.ptr(x), B, T, N.ptr(y), N.ptr(ws), nws, N.stream_handle())
+    return lib.tal_tds_premean_fwd(C.byref(desc), N.ptr(x), N.ptr(x_mean), B, T, N.ptr(y), N.ptr(ws), nws, N.stream_handle())
+
+
+def tds_premean_ok(desc, x):
+    """May `x` be handed to tds_forward as a log-mel BEFORE its mean subtraction (x_mean=...)?  (tal_tds_premean_ok)"""
+    return bool(N.lib().tal_tds_premean_ok(C.byref(desc), N.ptr(x)))
+
+
+def tds_forward(desc, x, c_out, check_range=True, defer=False, x_mean=None):
     """x [B, T, C0] -> [B, T', C_last] through tal_tds_fwd (whole encoder, one C call).
+
+    x_mean (device tensor [1]): x is the log-mel before LogMelSpec's global-mean subtraction and x_mean the scalar to subtract
+    (logmel(..., subtract_mean=False, return_stats=True)); the subtraction is folded into the first resize conv's bias
+    (tal_tds_premean_fwd).  Only where tds_premean_ok(desc, x).
 
     fp16-range guard: the long-input layers run in the fp16x3 form (fp32 values as two fp16 halves), which needs
     |activation| <= 65504.  The kernels raise a status word when a value was out of range; the call is then repeated
@@ -251,9 +265,8 @@ def tds_forward(desc, x, c_out, check_range=True, defer=False):
     y = torch.empty(B, t_out, c_out, dtype=torch.float32, device=x.device)
     nws = lib.tal_tds_workspace_bytes(C.byref(desc), B, T)
     ws = _ws(nws, x.device)
-    N.check(lib.tal_tds_fwd(C.byref(desc), N.ptr(x), B, T, N.ptr(y), N.ptr(ws), nws, N.stream_handle()),
-            "tal_tds_fwd")
-    chk = RangeCheck(desc, x, y, ws, nws, lib.tal_tds_status_offset(C.byref(desc), B, T))
+    N.check(_tds_call(lib, desc, x, x_mean, B, T, y, ws, nws), "tal_tds_fwd")
+    chk = RangeCheck(desc, x, y, ws, nws, lib.tal_tds_status_offset(C.byref(desc), B, T), x_mean)
     if defer:
         return y, chk
     if check_range and chk.flagged():

@@ -626,6 +626,52 @@ def test_speaker_ids_fused_path(sd_model):
     assert (ids.cpu().numpy() != g["ids"]).sum() == 0
 
 
+@pytest.mark.parametrize("name", ["sd_30s", "sd_5min", "sd_b2_ragged"])
+def test_mean_folded_into_the_first_resize_conv(sd_model, name):
+    """LogMelSpec subtracts the global mean of its call (tal/asr/models.py:52); SDModel.speaker_ids hands the UNSUBTRACTED log-mel
+    and the scalar to tal_tds_premean_fwd, where it becomes a bias correction of the first (padding-free) resize conv.  Against the
+    call sequence with the separate subtraction pass (extract_features -> tal_tds_fwd -> head): encoder output and features equal
+    to fp32 rounding of that one conv, speaker ids identical and equal to the reference's; extract_features itself is unchanged;
+    a stack whose first conv is not the 1 -> 10 form is refused by the C entry and served by the subtraction pass in Python."""
+    import ctypes as C
+    from tal_asrd_amd import synth, ops, _native as N
+    g = golden(name)
+    B, L = int(g["batch"]), int(g["audio_len"])
+    lens = g["audio_lens"].tolist() if "audio_lens" in g.files and name == "sd_b2_ragged" else None
+    audio = torch.from_numpy(synth.synth_audio_batch(B, L, int(g["audio_seed"]), lens=lens)).to(dev())
+    enc = sd_model.encoder
+    heads = (sd_model.spk_embed_proj.weight, sd_model.spk_embed_proj.bias, sd_model.spk_logit_proj.weight, sd_model.spk_logit_proj.bias)
+    with torch.no_grad():
+        mel = sd_model.extract_features(audio)
+        raw, mean = sd_model.logmelspec.forward_unsubtracted(audio)
+        np.testing.assert_array_equal((raw - mean).cpu().numpy(), mel.cpu().numpy())       # the same tensor, one subtraction apart
+        desc = enc._descriptor(0, len(enc.sizes) - 1)
+        assert ops.tds_premean_ok(desc, raw)
+        y_sub = ops.tds_forward(desc, mel, enc.sizes[-1])
+        y_fold = ops.tds_forward(desc, raw, enc.sizes[-1], x_mean=mean)
+        np.testing.assert_allclose(y_fold.cpu().numpy(), y_sub.cpu().numpy(), atol=2e-4, rtol=0)
+        f_sub, _, i_sub = ops.sd_head(y_sub, *heads, want_logits=False, want_ids=True)
+        feat, ids = sd_model.speaker_ids(audio)
+        np.testing.assert_allclose(feat.cpu().numpy(), f_sub.cpu().numpy(), atol=1e-4, rtol=0)
+        np.testing.assert_array_equal(ids.cpu().numpy(), i_sub.cpu().numpy())
+        np.testing.assert_array_equal(ids.cpu().numpy(), g["ids"])
+        # exact-fp32 descriptor: the same entry
+        exact = N.TdsDesc.from_buffer_copy(desc)
+        exact.flags |= N.TAL_TDS_EXACT_F32
+        y_ex = ops.tds_forward(exact, raw, enc.sizes[-1], x_mean=mean)
+        np.testing.assert_allclose(y_ex.cpu().numpy(), y_sub.cpu().numpy(), atol=2e-4, rtol=0)
+        # a stack that starts with the 10 -> 14 conv has no mean-folding kernel: refused with a message, nothing launched
+        sub = enc._descriptor(1, len(enc.sizes) - 1)
+        x1 = torch.zeros(1, 400, enc.sizes[1], device=dev())
+        assert not ops.tds_premean_ok(sub, x1)
+        lib = N.lib()
+        nws = lib.tal_tds_workspace_bytes(C.byref(sub), 1, 400)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev())
+        out = torch.empty(1, lib.tal_tds_out_len(C.byref(sub), 400), enc.sizes[-1], device=dev())
+        rc = lib.tal_tds_premean_fwd(C.byref(sub), N.ptr(x1), N.ptr(mean), 1, 400, N.ptr(out), N.ptr(ws), nws, N.stream_handle())
+        assert rc == -1 and b"mean-folding" in lib.tal_last_error()
+
+
 @pytest.mark.parametrize("seconds", [12, 300])
 def test_the_sd_path_can_be_captured_as_a_hip_graph(sd_model, seconds):
     """The C-ABI calls of the SD path (log-mel, tal_tds_fwd, the head) issue nothing but kernel launches on the caller's stream,
@@ -642,8 +688,8 @@ def test_the_sd_path_can_be_captured_as_a_hip_graph(sd_model, seconds):
         static_x = clips[0].clone()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            mel = sd_model.extract_features(static_x)
-            y, chk = ops.tds_forward(enc._descriptor(0, len(enc.sizes) - 1), mel, enc.sizes[-1], defer=True)
+            mel, mean = sd_model.logmelspec.forward_unsubtracted(static_x)       # (speaker_ids' own sequence: the mean rides in the first conv's bias)
+            y, chk = ops.tds_forward(enc._descriptor(0, len(enc.sizes) - 1), mel, enc.sizes[-1], defer=True, x_mean=mean)
             feat, _, ids = ops.sd_head(y, *heads, want_logits=False, want_ids=True)
         for a in clips + clips[:1]:
             for _ in range(20):

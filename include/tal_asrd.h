@@ -58,6 +58,10 @@ const char* tal_last_error(void);
  *   gconv_grid_xyz, gemm_w64_stagger, gemm_s64_order, decode_wide_gemm, gemm_s64_rows
  *                         kernel-selection switches of the ablation measurements
  *   decode_small_rows     largest prefix the latency-oriented decoder layer takes (default 256)
+ *   decode_persist        1: tal_greedy_step_fwd runs a step as ONE launch where its shapes allow (persistent workgroups walk the
+ *                         step's phases behind counter barriers and run the launch chain's own kernel bodies: bit-identical results;
+ *                         measured SLOWER than the chain, profiles/r5_decode_persistent_step.txt -- kept as a measurement switch)
+ *   decode_persist_wgs    workgroups per session of that launch (default 32)
  *   gemm_s64_below        fp16x3 relu / residual layers run on 64 x 80 tiles without K slices while those tiles number
  *                         at most this many per CU (default 2; 0: never)
  *   gconv_short_below     grouped convs use 64-step tiles while the long tiles would give a CU fewer workgroups than
@@ -372,7 +376,8 @@ typedef struct tal_greedy_ctx {
     float* picked_dev;       /* [1 + S] */
     float* picked_host;      /* pinned host [2 + S], or NULL when sync == 0 */
     uint32_t* tickets;       /* 256 words, ZERO before the first call (the kernels leave them zero): arrival tickets of the
-                              * kernels that merge partial results in-launch (key-split cross-attention, LM head + pick);
+                              * kernels that merge partial results in-launch (key-split cross-attention, LM head + pick; words
+                              * 252-254: phase counters and error word of the one-launch step, option decode_persist);
                               * NULL: the unmerged forms (more launches).  One context per stream. */
     float* picked_host_dev;  /* device alias of picked_host; NULL: resolved (hipHostGetDevicePointer) by the first sync 2 / 3 step */
     uint32_t seq;            /* library-owned: sequence value of the latest sync 2 / 3 step (start at 0) */

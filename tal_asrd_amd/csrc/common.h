@@ -119,6 +119,8 @@ enum Option {
     OPT_GEMM_S64_ORDER,           // 64 x 80 dense launches: tile order 0 = by shape (n-major when M < N), 1 = m-major, 2 = n-major
     OPT_DECODE_WIDE_GEMM,         // merged decode steps: 4 column blocks per workgroup in the skinny dense layers (0 = when the launch has >= 2 workgroups per CU, 1 = never, 2 = always)
     OPT_GEMM_S64_ROWS,            // short-input dense launches: 0 = 32-row tiles (two waves) while they number at most one per CU, 1 = always 64 rows, 2 = always 32
+    OPT_DECODE_PERSIST,           // decode steps as ONE launch (csrc/decode_persist.hip) where the step's shapes allow: 0 = launch chain, 1 = one launch
+    OPT_DECODE_PERSIST_WGS,       // workgroups per session of the one-launch step (default 32)
     OPT_COUNT
 };
 int opt(Option o);
@@ -274,6 +276,38 @@ struct ArgPack {
     T a[TAL_GROUP_MAX];
     int n;
 };
+
+// ---- the decode step as one launch (csrc/decode_persist.hip) ----
+constexpr int TAL_GREEDY_TICKETS = 256;      // words of a session's ticket block (tal_greedy_ctx.tickets); the last one belongs to the pick
+// words of the ticket block the one-launch step uses for itself (the FFN's split-K tickets start at 64: a step joins only while
+// they end below PS_BAR): arrival counter of the phase barriers, exit counter, error word (raised when a wait gives up)
+constexpr int PS_BAR = 252, PS_DONE = 253, PS_ERR = 254;
+constexpr int TAL_PS_MAX_SESS = 8, TAL_PS_MAX_LAYERS = 6;
+struct PsModel {
+    tal_decoder_layer_w layer[TAL_PS_MAX_LAYERS];
+    int n_layers, E, H, FF, V, K0;      // K0: embedding width (E0, or E without the factorised embedding)
+    float qscale;                       // head_dim^-0.5, computed once on the host (as the launch chain does)
+    const float *emb, *proj, *proj_t, *pe;
+};
+struct PsSession {
+    const int64_t* tokens;              // first token of the live prefix
+    int64_t* token_out;                 // where the picked token is appended
+    int U, S;
+    float *h0, *h1, *qkv, *vt, *ctx, *x1, *x2, *ff, *probs, *sk_part, *pick_part, *out;
+    unsigned* tickets;
+    const float* k_cache[TAL_PS_MAX_LAYERS];
+    const float* vt_cache[TAL_PS_MAX_LAYERS];
+    const uint8_t* kpm;
+    int64_t k_pitch;
+    unsigned host_seq;
+};
+struct PsArgs {
+    PsModel m;
+    PsSession s[TAL_PS_MAX_SESS];
+    int n, G;
+};
+static_assert(sizeof(PsArgs) <= 3800, "the one-launch step's arguments travel by value in the kernel argument segment");
+int launch_greedy_persist(const PsArgs& a, hipStream_t s);
 
 bool skinny_gemm_applicable(const SkinnyArgs& g);
 int launch_skinny_gemm(const SkinnyArgs& g, int mode, hipStream_t s);

@@ -13,138 +13,9 @@
 //       into LDS, the row softmax of torch (max, exp, sum, divide) in place, P.V from LDS against V^T -- one launch
 //       where the batched-GEMM form needs three.  Optionally writes the per-head probabilities of the rows
 //       >= prob_row0 (MultiheadAttention's returned weights are their head average, models.py:517-519).
-#include "common.h"
+#include "decode_bodies.h"
 
 namespace tal {
-
-// mode 0: acc+b | 1: relu(acc+b) | 2: res + alpha*(acc+b) | 3: alpha*(acc+b) on columns < scale_cols
-// One workgroup = 16 output columns x up to 32 rows (blockIdx.y picks the 32-row half).  NW waves split K; a wave's whole
-// K slice (<= 8 chunks of 16 k when K <= 128 NW) is requested before its first MFMA, so a launch costs ONE operand round
-// trip -- a CU pulls only ~25-60 GB/s, and the round trip, not the arithmetic, is what a launch this small pays for.
-// The kernels of this file exist in two launch forms that share one body each: the ordinary one (one problem per launch) and
-// the MULTI form, which runs the same body for up to TAL_GROUP_MAX independent problems -- the decode steps of several
-// sessions (System.transcribe_unaligned_many) -- in ONE launch: the argument structs travel by value in the kernel argument
-// segment, a grid dimension picks the problem, a block outside its problem's own grid returns.  A problem's outputs are the
-// same instructions on the same operands in both forms, i.e. bit-identical.  `Blk` carries the block coordinates (and the
-// grid extents the body derives indices from) of the problem's OWN grid.
-struct Blk {
-    unsigned x, y, z, gx, gy;
-};
-
-template <int MODE, int MT, int NW>
-__device__ __forceinline__ void skinny_gemm_body(const SkinnyArgs& g, const Blk blk) {
-    __shared__ __attribute__((aligned(16))) float part[NW * MT * 256];   // [wave][m tile][row 16][col 16]
-    const int n0 = blk.x * 16;
-    const int m0 = blk.y * 32;
-    const int lane = threadIdx.x & 63, w = wave_id();
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int KS = g.ksplit > 1 ? g.ksplit : 1;
-    const int Kw = g.K / (NW * KS);                // this wave's share of K
-    const int nchunk = Kw >> 4;                    // 16 k per chunk = 4 MFMAs
-    const int kofs = ((int)blk.z * NW + w) * Kw;
-    const float* wp = g.W + (int64_t)(n0 + r16) * g.ldw + kofs + 4 * kq;
-    const float* ap[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int row = m0 + mt * 16 + r16;
-        ap[mt] = g.A + (int64_t)(row < g.M ? row : g.M - 1) * g.lda + kofs + 4 * kq;
-    }
-    f32x4 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = {0.f, 0.f, 0.f, 0.f};
-    // A lane's 16-byte load holds k = 4 kq + {0..3} of a chunk; MFMA j of the chunk contracts the k set {j, 4+j, 8+j, 12+j}
-    // on both operands, so the chunk's four MFMAs cover its 16 k exactly once.
-    constexpr int UNR = 8;
-    constexpr int NBUF = NW >= 16 ? 1 : 2;        // 16 waves = 4 per SIMD = 128 registers each: one batch, no double buffer
-    f32x4 bw[NBUF][UNR], av[NBUF][MT][UNR];
-    auto load_batch = [&](int c0, int buf) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int c = c0 + u < nchunk ? c0 + u : nchunk - 1;     // (clamped: a tail batch re-reads the last chunk, unused)
-            bw[buf][u] = *reinterpret_cast<const f32x4*>(wp + c * 16);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[buf][mt][u] = *reinterpret_cast<const f32x4*>(ap[mt] + c * 16);
-        }
-    };
-    auto mfma_batch = [&](int c0, int buf) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u)
-            if (c0 + u < nchunk) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][mt][u].x, bw[buf][u].x, acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][mt][u].y, bw[buf][u].y, acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][mt][u].z, bw[buf][u].z, acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][mt][u].w, bw[buf][u].w, acc[mt], 0, 0, 0);
-                }
-            }
-    };
-    load_batch(0, 0);
-    if constexpr (NBUF == 1) {
-        for (int c0 = 0; c0 < nchunk; c0 += UNR) {
-            mfma_batch(c0, 0);
-            if (c0 + UNR < nchunk) load_batch(c0 + UNR, 0);
-        }
-    } else {
-        for (int c0 = 0; c0 < nchunk; c0 += 2 * UNR) {
-            if (c0 + UNR < nchunk) load_batch(c0 + UNR, NBUF - 1);
-            mfma_batch(c0, 0);
-            if (c0 + 2 * UNR < nchunk) load_batch(c0 + 2 * UNR, 0);
-            if (c0 + UNR < nchunk) mfma_batch(c0 + UNR, NBUF - 1);
-        }
-    }
-    // C layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) part[((w * MT + mt) * 16 + 4 * kq + i) * 16 + r16] = acc[mt][i];
-    __syncthreads();
-    const int t = threadIdx.x;
-    const int mt = t >> 6, r = (t & 63) >> 2, c4 = t & 3;
-    const int m = m0 + mt * 16 + r;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t < MT * 64) {
-        v = *reinterpret_cast<const f32x4*>(&part[((0 * MT + mt) * 16 + r) * 16 + 4 * c4]);
-#pragma unroll
-        for (int q = 1; q < NW; ++q) v += *reinterpret_cast<const f32x4*>(&part[((q * MT + mt) * 16 + r) * 16 + 4 * c4]);   // wave order
-    }
-    if (KS > 1) {
-        __shared__ unsigned ticket;
-        const unsigned tile = blk.y * blk.gx + blk.x, ntile = blk.gx * blk.gy;
-        float* mine = g.sk_part + ((size_t)blk.z * ntile + tile) * 512 + t * 4;
-        if (t < MT * 64) { st_agent(mine, v.x); st_agent(mine + 1, v.y); st_agent(mine + 2, v.z); st_agent(mine + 3, v.w); }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t == 0) ticket = take_ticket(&g.sk_tickets[tile]);
-        __syncthreads();
-        if (ticket != (unsigned)(KS - 1)) return;
-        if (t == 0) reset_ticket(&g.sk_tickets[tile]);
-        if (t < MT * 64) {
-            const float* p0 = g.sk_part + (size_t)tile * 512 + t * 4;
-            v = {0.f, 0.f, 0.f, 0.f};
-            for (int q = 0; q < KS; ++q) {                 // split order
-                const float* pq = p0 + (size_t)q * ntile * 512;
-                v.x += ld_agent(pq); v.y += ld_agent(pq + 1); v.z += ld_agent(pq + 2); v.w += ld_agent(pq + 3);
-            }
-        }
-    }
-    if (t >= MT * 64 || m >= g.M) return;
-    const int col = n0 + 4 * c4;
-    if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
-    if (MODE == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (MODE == 2) v = *reinterpret_cast<const f32x4*>(g.res + (int64_t)m * g.ldres + col) + g.alpha * v;
-    if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) v = g.alpha * v;
-    if (g.Yt && col >= g.vt_begin) {
-        const int b = m / g.U, u = m - b * g.U;
-        float* yt = g.Yt + (int64_t)b * g.vt_bs + (int64_t)(col - g.vt_begin) * g.ldt + u;
-        yt[0] = v.x;
-        yt[g.ldt] = v.y;
-        yt[2 * g.ldt] = v.z;
-        yt[3 * g.ldt] = v.w;
-        return;
-    }
-    *reinterpret_cast<f32x4*>(g.Y + (int64_t)m * g.ldy + col) = v;
-}
 
 template <int MODE, int MT, int NW>
 __global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(const SkinnyArgs g) {
@@ -372,152 +243,6 @@ int launch_skinny_gemm(const SkinnyArgs& g, int mode, hipStream_t s) {
     return TAL_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// 8 waves per workgroup.  Scores: wave w takes key blocks w, w + 8, ... three at a time (all 3 x HD/16 fragment loads in
-// flight before the first MFMA).  P.V: one 16-feature block per wave (HD = 128), the V^T fragments of the next 8 key
-// steps in flight while the current 8 are multiplied.
-constexpr int ATT_NW = 8;
-template <int HD>
-__device__ __forceinline__ void attn_small_body(const AttnArgs& g, const Blk blk) {
-    extern __shared__ __attribute__((aligned(16))) float sc[];   // [16][SP] scores -> probabilities
-    const int u0 = blk.x * 16, h = blk.y, b = blk.z;
-    const int lane = threadIdx.x & 63, w = wave_id();
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int U = g.U, S = g.S;
-    const int S16 = (S + 15) & ~15, SP = S16 + 4;
-    constexpr int NC = HD / 16;
-    // The P.V operand (V^T) does not depend on the scores: its first fragments are requested before anything else, so
-    // their round trip runs under the score / softmax phases.
-    constexpr int VU = 8;
-    const int nstep = S16 / 16;
-    const int S4 = (int)g.ldvt;
-    const int cb = w < NC ? w : NC - 1;
-    const float* vrow = g.vt + (int64_t)b * g.vt_bs + (int64_t)(h * HD + cb * 16 + r16) * g.ldvt + 4 * kq;
-    f32x4 vb[3][VU];
-    auto load_v = [&](int t0, int buf) {
-#pragma unroll
-        for (int t = 0; t < VU; ++t) {
-            const int s = (t0 + t) * 16 + 4 * kq;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t0 + t < nstep && s < S4) v = *reinterpret_cast<const f32x4*>(vrow + (t0 + t) * 16);   // ldvt % 4 == 0: all 16 bytes in the row
-            if (s + 0 >= S) v.x = 0.f;
-            if (s + 1 >= S) v.y = 0.f;
-            if (s + 2 >= S) v.z = 0.f;
-            if (s + 3 >= S) v.w = 0.f;
-            vb[buf][t] = v;
-        }
-    };
-    load_v(0, 0);
-    load_v(VU, 1);
-    load_v(2 * VU, 2);
-    // ---- scores
-    {
-        const int qr = u0 + r16 < U ? u0 + r16 : U - 1;
-        const float* qrow = g.q + (int64_t)b * g.q_bs + (int64_t)qr * g.ldq + h * HD + 4 * kq;
-        f32x4 qa[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) qa[c] = *reinterpret_cast<const f32x4*>(qrow + 16 * c);
-        constexpr int JU = HD <= 64 ? 4 : 3;
-        const int nblk = S16 / 16;
-        for (int jb0 = w; jb0 < nblk; jb0 += ATT_NW * JU) {
-            f32x4 kb[JU][NC];
-#pragma unroll
-            for (int ju = 0; ju < JU; ++ju) {
-                const int jb = jb0 + ju * ATT_NW;
-                int kr = jb * 16 + r16;
-                kr = kr < S ? kr : S - 1;
-                const float* krow = g.k + (int64_t)b * g.k_bs + (int64_t)kr * g.ldk + h * HD + 4 * kq;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) kb[ju][c] = *reinterpret_cast<const f32x4*>(krow + 16 * c);
-            }
-#pragma unroll
-            for (int ju = 0; ju < JU; ++ju) {
-                const int jb = jb0 + ju * ATT_NW;
-                if (jb >= nblk) break;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[c].x, kb[ju][c].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[c].y, kb[ju][c].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[c].z, kb[ju][c].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[c].w, kb[ju][c].w, acc, 0, 0, 0);
-                }
-                const int key = jb * 16 + r16;            // C: row = 4 kq + i (query), col = r16 (key)
-                const bool dead = key >= S || (g.kpm && g.kpm[(int64_t)b * S + key]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int u = u0 + 4 * kq + i;
-                    float v = acc[i];
-                    if (g.mask && u < U && key < S) v += g.mask[(int64_t)u * S + key];
-                    sc[(4 * kq + i) * SP + key] = dead ? -INFINITY : v;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- row softmax (max, exp, sum, divide, as torch): wave w owns rows 2 w and 2 w + 1, one per 32-lane half, so the two rows'
-    // cross-lane reductions (a shuffle is ~100 cycles of latency) run side by side
-    {
-        constexpr int LPR = 64 / (16 / ATT_NW);             // lanes per row
-        const int row = (16 / ATT_NW) * w + lane / LPR, ll = lane % LPR, u = u0 + row;
-        float* p = sc + row * SP;
-        if (u >= U) {
-            for (int s = ll; s < S16; s += LPR) p[s] = 0.f;
-        } else {
-            float m = -INFINITY;
-            for (int s = ll; s < S; s += LPR) m = fmaxf(m, p[s]);
-#pragma unroll
-            for (int off = LPR / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-            float sum = 0.f;
-            for (int s = ll; s < S; s += LPR) {
-                const float e = expf(p[s] - m);
-                p[s] = e;
-                sum += e;
-            }
-#pragma unroll
-            for (int off = LPR / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-            float* pr = (g.probs && u >= g.prob_row0)
-                            ? g.probs + (((int64_t)b * g.H + h) * (U - g.prob_row0) + (u - g.prob_row0)) * S : nullptr;
-            for (int s = ll; s < S16; s += LPR) {
-                const float v = s < S ? p[s] / sum : 0.f;
-                p[s] = v;
-                if (pr && s < S) pr[s] = v;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- ctx = P . V: feature block cb = w (waves >= HD / 16 are done); batches 0..2 are already in registers
-    if (w >= NC) return;
-    const float* prow = sc + r16 * SP + 4 * kq;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    auto mfma_v = [&](int t0, int buf) {
-#pragma unroll
-        for (int t = 0; t < VU; ++t)
-            if (t0 + t < nstep) {
-                const f32x4 pa = *reinterpret_cast<const f32x4*>(prow + (t0 + t) * 16);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.x, vb[buf][t].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.y, vb[buf][t].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.z, vb[buf][t].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.w, vb[buf][t].w, acc, 0, 0, 0);
-            }
-    };
-    for (int t0 = 0; t0 < nstep; t0 += 3 * VU) {
-        mfma_v(t0, 0);
-        if (t0 + 3 * VU < nstep) load_v(t0 + 3 * VU, 0);
-        if (t0 + VU < nstep) mfma_v(t0 + VU, 1);
-        if (t0 + 4 * VU < nstep) load_v(t0 + 4 * VU, 1);
-        if (t0 + 2 * VU < nstep) mfma_v(t0 + 2 * VU, 2);
-        if (t0 + 5 * VU < nstep) load_v(t0 + 5 * VU, 2);
-    }
-    const int col = h * HD + cb * 16 + r16;
-    const float bv = g.vbias ? g.vbias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int u = u0 + 4 * kq + i;
-        if (u < U) g.ctx[(int64_t)b * g.c_bs + (int64_t)u * g.ldc + col] = acc[i] + bv;
-    }
-}
-
 template <int HD>
 __global__ __launch_bounds__(64 * ATT_NW) void attn_small_kernel(const AttnArgs g) {
     attn_small_body<HD>(g, Blk{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y});
@@ -576,229 +301,6 @@ int launch_attn_small_multi(const AttnArgs* g, int G, int hd, hipStream_t s) {
     }
     TAL_CHECK_LAUNCH("attn_small (multi)");
     return TAL_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The same attention with the KEY axis cut over workgroups (cross-attention of a decode step: 357 keys x 512 features of
-// K and V^T are 1.4 MB, and the 8 workgroups of the kernel above each pull 367 KB through one CU at 25-60 GB/s).
-// Workgroup (row block, head, batch item x chunk) handles CB key blocks: scores, chunk-local max m_c, p = exp(s - m_c),
-// l_c = sum p, o_c = p . V_c, all written to a scratch record; the last workgroup to arrive at (row block, head, item)
-// -- ticket on a zero-initialised, self-resetting counter -- merges the chunks in chunk order,
-//     M = max m_c,  w_c = exp(m_c - M),  ctx = sum_c w_c o_c / sum_c w_c l_c (+ v bias),
-// and, for the rows >= prob_row0, the per-head probabilities p w_c / L.  Deterministic (fixed merge order).
-constexpr int SPLIT_MAX_CB = 8;      // key blocks per chunk (S <= 960 -> at most 8 chunks of 8 blocks)
-constexpr int SPLIT_NCH = 8;
-__host__ __device__ static inline int split_cb(int S) { const int nblk = (S + 15) / 16; return (nblk + SPLIT_NCH - 1) / SPLIT_NCH; }
-__host__ __device__ static inline size_t split_record_floats(int hd, int cb) { return (size_t)16 * hd + 32 + (size_t)16 * 16 * cb; }
-
-template <int HD>
-__device__ __forceinline__ void attn_split_body(const AttnArgs& g, int CB, int NCH, float* __restrict__ scratch,
-                                                unsigned* __restrict__ tickets, const Blk blk) {
-    extern __shared__ __attribute__((aligned(16))) float sc[];   // [16][SPc] chunk scores -> exp(s - m_c)
-    __shared__ float mrow[16], lrow[16], wsh[16 * SPLIT_NCH], Lsh[16];
-    __shared__ unsigned ticket;
-    const int u0 = blk.x * 16, h = blk.y;
-    const int b = blk.z / NCH, ch = blk.z % NCH;
-    const int lane = threadIdx.x & 63, w = wave_id();
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int U = g.U, S = g.S;
-    const int nblk = (S + 15) / 16;
-    const int jb0 = ch * CB;                         // first key block of this chunk
-    const int Sc = CB * 16, SPc = Sc + 4;
-    constexpr int NC = HD / 16;
-    const size_t rec_f = split_record_floats(HD, CB);
-    const size_t group = ((size_t)b * blk.gy + h) * blk.gx + blk.x;      // (item, head, row block)
-    float* rec = scratch + (group * NCH + ch) * rec_f;
-    // V^T fragments of this chunk for the wave's feature blocks (NC / 4 of them): requested first
-    constexpr int FB = (NC + 3) / 4;
-    const int S4 = (int)g.ldvt;
-    f32x4 vb[FB][SPLIT_MAX_CB];
-#pragma unroll
-    for (int f = 0; f < FB; ++f) {
-        const int cb = w * FB + f < NC ? w * FB + f : NC - 1;
-        const float* vrow = g.vt + (int64_t)b * g.vt_bs + (int64_t)(h * HD + cb * 16 + r16) * g.ldvt + 4 * kq;
-#pragma unroll
-        for (int t = 0; t < SPLIT_MAX_CB; ++t) {
-            const int s = (jb0 + t) * 16 + 4 * kq;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t < CB && s < S4) v = *reinterpret_cast<const f32x4*>(vrow + (jb0 + t) * 16);
-            if (s + 0 >= S) v.x = 0.f;
-            if (s + 1 >= S) v.y = 0.f;
-            if (s + 2 >= S) v.z = 0.f;
-            if (s + 3 >= S) v.w = 0.f;
-            vb[f][t] = v;
-        }
-    }
-    // ---- scores of the chunk: wave w takes key blocks w, w + 4
-    {
-        const int qr = u0 + r16 < U ? u0 + r16 : U - 1;
-        const float* qrow = g.q + (int64_t)b * g.q_bs + (int64_t)qr * g.ldq + h * HD + 4 * kq;
-        f32x4 qa[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) qa[c] = *reinterpret_cast<const f32x4*>(qrow + 16 * c);
-        f32x4 kb[2][NC];
-#pragma unroll
-        for (int ju = 0; ju < 2; ++ju) {
-            int kr = (jb0 + w + 4 * ju) * 16 + r16;
-            kr = kr < S ? kr : S - 1;
-            const float* krow = g.k + (int64_t)b * g.k_bs + (int64_t)kr * g.ldk + h * HD + 4 * kq;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) kb[ju][c] = *reinterpret_cast<const f32x4*>(krow + 16 * c);
-        }
-#pragma unroll
-        for (int ju = 0; ju < 2; ++ju) {
-            const int jl = w + 4 * ju;                 // key block inside the chunk
-            if (jl >= CB) break;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[c].x, kb[ju][c].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[c].y, kb[ju][c].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[c].z, kb[ju][c].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[c].w, kb[ju][c].w, acc, 0, 0, 0);
-            }
-            const int key = (jb0 + jl) * 16 + r16;
-            const bool dead = key >= S || (g.kpm && g.kpm[(int64_t)b * S + key]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int u = u0 + 4 * kq + i;
-                float v = acc[i];
-                if (g.mask && u < U && key < S) v += g.mask[(int64_t)u * S + key];
-                sc[(4 * kq + i) * SPc + jl * 16 + r16] = dead ? -INFINITY : v;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- chunk-local softmax statistics, wave w owns rows 4 w .. 4 w + 3: lane group (lane >> 4) takes one row, 16 lanes per
-    // row, so the four rows' reductions run side by side (a cross-lane shuffle is ~100 cycles of latency; one row at a
-    // time, 64 lanes wide, that is 48 dependent shuffles per wave)
-    {
-        const int row = 4 * w + (lane >> 4), l16 = lane & 15;
-        float* p = sc + row * SPc;
-        float m = -INFINITY;
-        for (int s = l16; s < Sc; s += 16) m = fmaxf(m, p[s]);
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-        float sum = 0.f;
-        for (int s = l16; s < Sc; s += 16) {
-            const float e = m == -INFINITY ? 0.f : expf(p[s] - m);     // a chunk whose keys are all masked contributes nothing
-            p[s] = e;
-            sum += e;
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-        if (l16 == 0) {
-            mrow[row] = m;
-            lrow[row] = sum;
-        }
-    }
-    __syncthreads();
-    // ---- o_c = p . V_c for the wave's feature blocks; record = [16][HD] o | [16] m | [16] l | [16][Sc] p
-#pragma unroll
-    for (int f = 0; f < FB; ++f) {
-        const int cb = w * FB + f;
-        if (cb >= NC) break;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < SPLIT_MAX_CB; ++t)
-            if (t < CB) {
-                const f32x4 pa = *reinterpret_cast<const f32x4*>(sc + r16 * SPc + t * 16 + 4 * kq);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.x, vb[f][t].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.y, vb[f][t].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.z, vb[f][t].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.w, vb[f][t].w, acc, 0, 0, 0);
-            }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) st_agent(&rec[(4 * kq + i) * HD + cb * 16 + r16], acc[i]);
-    }
-    if (threadIdx.x < 16) {
-        st_agent(&rec[16 * HD + threadIdx.x], mrow[threadIdx.x]);
-        st_agent(&rec[16 * HD + 16 + threadIdx.x], lrow[threadIdx.x]);
-    }
-    if (g.probs && u0 + 15 >= g.prob_row0)
-        for (int i = threadIdx.x; i < 16 * Sc; i += 256) st_agent(&rec[16 * HD + 32 + i], sc[(i / Sc) * SPc + i % Sc]);
-    // ---- published (write-through stores); take a ticket; the last arriver merges
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) ticket = take_ticket(&tickets[group]);
-    __syncthreads();
-    if (ticket != (unsigned)(NCH - 1)) return;
-    if (threadIdx.x == 0) reset_ticket(&tickets[group]);   // ready for the next launch (stream order)
-    const float* grp = scratch + group * NCH * rec_f;
-    // Merge.  Every thread reads the (m_c, l_c) of the rows it needs itself and its chunks' o values in the same batch of
-    // agent-scope loads: ONE round trip to memory, then arithmetic (fixed-trip loops: a run-time-bounded loop of memory
-    // loads is a serial chain of round trips).
-    if (threadIdx.x < 16) {
-        const int row = threadIdx.x;
-        float mc[SPLIT_NCH], lc[SPLIT_NCH];
-#pragma unroll
-        for (int c = 0; c < SPLIT_NCH; ++c) {
-            mc[c] = c < NCH ? ld_agent(grp + c * rec_f + 16 * HD + row) : -INFINITY;
-            lc[c] = c < NCH ? ld_agent(grp + c * rec_f + 16 * HD + 16 + row) : 0.f;
-        }
-        float M = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < SPLIT_NCH; ++c) M = fmaxf(M, mc[c]);
-        float L = 0.f;
-#pragma unroll
-        for (int c = 0; c < SPLIT_NCH; ++c) {
-            const float wc = mc[c] == -INFINITY ? 0.f : expf(mc[c] - M);
-            wsh[row * SPLIT_NCH + c] = wc;
-            L += wc * lc[c];
-        }
-        Lsh[row] = L;
-    }
-    {   // every chunk's o tile for this thread's groups of 4 outputs: 16-byte agent-scope loads, all chunks in flight at once,
-        // requested BEFORE the barrier that publishes the weights
-        constexpr int NI = (16 * HD + 1023) / 1024;
-        f32x4 oc[NI][SPLIT_NCH];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int i = (threadIdx.x + 256 * j) * 4;
-            if (i < 16 * HD) {
-                if (NCH == SPLIT_NCH) ld_agent_x4<SPLIT_NCH>(grp + i, rec_f, oc[j]);
-                else {
-#pragma unroll
-                    for (int c = 0; c < SPLIT_NCH; ++c) {
-                        const float* pc = grp + (c < NCH ? c : 0) * rec_f + i;      // (chunks past NCH: never used)
-                        oc[j][c] = {ld_agent(pc), ld_agent(pc + 1), ld_agent(pc + 2), ld_agent(pc + 3)};
-                    }
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int i = (threadIdx.x + 256 * j) * 4;
-            if (i >= 16 * HD) continue;
-            const int row = i / HD, col = i - row * HD;
-            const int u = u0 + row;
-            if (u >= U) continue;
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < SPLIT_NCH; ++c)
-                if (c < NCH) o += wsh[row * SPLIT_NCH + c] * oc[j][c];       // chunk order
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (g.vbias) bv = *reinterpret_cast<const f32x4*>(g.vbias + h * HD + col);
-            const float L = Lsh[row];
-            f32x4 r;
-            r.x = o.x / L + bv.x; r.y = o.y / L + bv.y; r.z = o.z / L + bv.z; r.w = o.w / L + bv.w;
-            *reinterpret_cast<f32x4*>(g.ctx + (int64_t)b * g.c_bs + (int64_t)u * g.ldc + h * HD + col) = r;
-        }
-    }
-    if (g.probs) {
-        const int row_lo = g.prob_row0 > u0 ? g.prob_row0 - u0 : 0;
-        const int row_hi = U - u0 < 16 ? U - u0 : 16;
-        const int nrow = row_hi - row_lo;
-        for (int i = threadIdx.x; i < nrow * NCH * Sc; i += 256) {
-            const int row = row_lo + i / (NCH * Sc), rem = i % (NCH * Sc);
-            const int c = rem / Sc, sl = rem - c * Sc;
-            const int u = u0 + row, key = c * Sc + sl;
-            if (key >= S) continue;
-            const float pc = ld_agent(grp + c * rec_f + 16 * HD + 32 + row * Sc + sl);
-            g.probs[(((int64_t)b * g.H + h) * (U - g.prob_row0) + (u - g.prob_row0)) * S + key] = pc * wsh[row * SPLIT_NCH + c] / Lsh[row];
-        }
-    }
 }
 
 template <int HD>

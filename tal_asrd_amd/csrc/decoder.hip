@@ -11,46 +11,11 @@
 #include <atomic>
 #include <chrono>
 
-#include "common.h"
+#include "decode_bodies.h"
 
 namespace tal {
 
 static inline int64_t pad4(int64_t n) { return (n + 3) & ~(int64_t)3; }
-
-// ---- token embedding: emb[tok] -> (proj) -> + pe[u] ---------------------------------------
-__device__ __forceinline__ void embed_body(const int64_t* __restrict__ tokens, const float* __restrict__ emb,
-                                           const float* __restrict__ proj, const float* __restrict__ pe,
-                                           float* __restrict__ out, int U, int V, int E0, int D, int row) {
-    extern __shared__ float e[];
-    const int u = row % U;
-    int64_t tok = tokens[row];
-    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);  // validated on the host side; never trusted for addressing
-    for (int k = threadIdx.x; k < E0; k += 256) e[k] = emb[tok * E0 + k];
-    __syncthreads();
-    for (int d = threadIdx.x; d < D; d += 256) {
-        float acc;
-        if (proj && E0 == 64 && (reinterpret_cast<uintptr_t>(proj) & 15) == 0) {
-            // all 16 loads of the projection row in flight at once (a run-time-bounded scalar loop is 64 serial round trips)
-            const float* pr = proj + (int64_t)d * 64;
-            f32x4 pv[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) pv[k] = *reinterpret_cast<const f32x4*>(pr + 4 * k);
-            acc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {                    // same fmaf chain order as the scalar loop
-                acc = fmaf(e[4 * k], pv[k].x, acc); acc = fmaf(e[4 * k + 1], pv[k].y, acc);
-                acc = fmaf(e[4 * k + 2], pv[k].z, acc); acc = fmaf(e[4 * k + 3], pv[k].w, acc);
-            }
-        } else if (proj) {
-            acc = 0.f;
-            const float* pr = proj + (int64_t)d * E0;
-            for (int k = 0; k < E0; ++k) acc = fmaf(e[k], pr[k], acc);
-        } else {
-            acc = e[d];
-        }
-        out[(int64_t)row * D + d] = acc + pe[(int64_t)u * D + d];
-    }
-}
 
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ emb,
                                                    const float* __restrict__ proj, const float* __restrict__ pe,
@@ -300,233 +265,6 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restric
     }
 }
 
-// Tied factorised LM head of the last position + the greedy pick in ONE launch (models.py:243-246, system.py:355-411):
-// every workgroup recomputes t = P^T h (E0 x E, 128 KB, L2-resident), takes 128 vocabulary rows (logit = emb[v] . t),
-// reduces them to its (max, first arg-max), and the last workgroup to arrive (ticket on a zeroed, self-resetting word)
-// merges the partials in workgroup order -- lowest index on ties, as torch.argmax -- and writes the token plus the
-// layer- / head-averaged attention row.  arg max of log_softmax(x) is taken as arg max of x (the same index unless two
-// logits lie within an ulp of each other).
-constexpr int LMP_ROWS = 128;
-struct LmPickArgs {
-    const float* h;          // last prefix row of the decoder output [E]
-    const float* attn;       // attention rows: attn[l * layer_stride + hh * head_stride + i]
-    int64_t layer_stride, head_stride;
-    int S;
-    float* partial;          // 2 floats per workgroup
-    unsigned* ticket_word;
-    float* out;              // {token, row [S] (, sequence word)}
-    int64_t* token_out;
-    unsigned host_seq;
-};
-__device__ __forceinline__ void lm_pick_body(const LmPickArgs& q, const float* __restrict__ proj_t, int E, int K0,
-                                             const float* __restrict__ emb, int V, int n_layers, int H, const unsigned bx, const unsigned gx) {
-    const float* __restrict__ h = q.h;
-    const float* __restrict__ attn = q.attn;
-    const int64_t layer_stride = q.layer_stride, head_stride = q.head_stride;
-    const int S = q.S;
-    float* __restrict__ partial = q.partial;
-    unsigned* __restrict__ ticket_word = q.ticket_word;
-    float* __restrict__ out = q.out;
-    int64_t* __restrict__ token_out = q.token_out;
-    const unsigned host_seq = q.host_seq;
-    extern __shared__ __attribute__((aligned(16))) float sm[];      // [E] h | [K0] t | [128] logits
-    float* hs = sm;
-    float* ts = sm + E;
-    float* lg = ts + K0;
-    __shared__ unsigned ticket;
-    const int tid = threadIdx.x, lane = tid & 63;
-    // Everything this workgroup reads from memory is requested up front (h, P^T, its 128 embedding rows): the dependent
-    // chain is one round trip, then arithmetic.  Sixteen lanes share a row, so one load instruction covers 4 rows x 256
-    // contiguous bytes (a lane-per-row mapping touches 64 cache lines per instruction and the line rate sets the time).
-    // Fast path: E = 512, K0 = 64 (the reference's '2x' model with the factorised embedding); otherwise plain loops.
-    const int l16 = tid & 15, grp = tid >> 4;
-    const bool fast = proj_t && E == 512 && K0 == 64;
-    f32x4 pv[4][8], ev[8];
-    if (fast) {
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps)
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                pv[ps][c] = *reinterpret_cast<const f32x4*>(proj_t + (int64_t)(grp + 16 * ps) * 512 + (l16 + 16 * c) * 4);
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            const int v = bx * LMP_ROWS + grp + 16 * ps;
-            ev[ps] = *reinterpret_cast<const f32x4*>(emb + (int64_t)(v < V ? v : V - 1) * 64 + l16 * 4);
-        }
-    }
-    for (int i = tid; i < E; i += 256) hs[i] = h[i];
-    __syncthreads();
-    if (fast) {
-        float a[4];
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            a[ps] = 0.f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const f32x4 hv = *reinterpret_cast<const f32x4*>(hs + (l16 + 16 * c) * 4);
-                a[ps] = fmaf(pv[ps][c].x, hv.x, a[ps]); a[ps] = fmaf(pv[ps][c].y, hv.y, a[ps]);
-                a[ps] = fmaf(pv[ps][c].z, hv.z, a[ps]); a[ps] = fmaf(pv[ps][c].w, hv.w, a[ps]);
-            }
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1)
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) a[ps] += __shfl_xor(a[ps], off, 64);
-        if (l16 == 0)
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) ts[grp + 16 * ps] = a[ps];
-    } else if (proj_t) {
-        // t[j] = sum_d h[d] proj_t[j][d]: four threads per j, a quarter of E each (E % 16 == 0)
-        const int q = tid & 3, Eq = E >> 2;
-        for (int j = tid >> 2; j < K0; j += 64) {
-            const float* pr = proj_t + (int64_t)j * E + q * Eq;
-            float a = 0.f;
-            for (int d = 0; d < Eq; d += 4) {
-                const f32x4 p4 = *reinterpret_cast<const f32x4*>(pr + d);
-                const f32x4 hv = *reinterpret_cast<const f32x4*>(hs + q * Eq + d);
-                a = fmaf(p4.x, hv.x, a); a = fmaf(p4.y, hv.y, a); a = fmaf(p4.z, hv.z, a); a = fmaf(p4.w, hv.w, a);
-            }
-            a += __shfl_xor(a, 1, 64);
-            a += __shfl_xor(a, 2, 64);
-            if (q == 0) ts[j] = a;
-        }
-    } else {
-        for (int i = tid; i < K0; i += 256) ts[i] = hs[i];
-    }
-    __syncthreads();
-    if (fast) {
-        const f32x4 tv = *reinterpret_cast<const f32x4*>(ts + l16 * 4);
-        float a[8];
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            a[ps] = ev[ps].x * tv.x;
-            a[ps] = fmaf(ev[ps].y, tv.y, a[ps]); a[ps] = fmaf(ev[ps].z, tv.z, a[ps]); a[ps] = fmaf(ev[ps].w, tv.w, a[ps]);
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1)
-#pragma unroll
-            for (int ps = 0; ps < 8; ++ps) a[ps] += __shfl_xor(a[ps], off, 64);
-        if (l16 == 0)
-#pragma unroll
-            for (int ps = 0; ps < 8; ++ps) {
-                const int v = bx * LMP_ROWS + grp + 16 * ps;
-                lg[grp + 16 * ps] = v < V ? a[ps] : -INFINITY;
-            }
-    } else {   // two threads per row, half of K0 each (K0 % 8 == 0)
-        const int r = tid >> 1, half = tid & 1, Kh = K0 >> 1;
-        const int v = bx * LMP_ROWS + r;
-        float a = 0.f;
-        if (v < V) {
-            const float* er = emb + (int64_t)v * K0 + half * Kh;
-            for (int d = 0; d < Kh; d += 4) {
-                const f32x4 e4 = *reinterpret_cast<const f32x4*>(er + d);
-                const f32x4 tv = *reinterpret_cast<const f32x4*>(ts + half * Kh + d);
-                a = fmaf(e4.x, tv.x, a); a = fmaf(e4.y, tv.y, a); a = fmaf(e4.z, tv.z, a); a = fmaf(e4.w, tv.w, a);
-            }
-        }
-        a += __shfl_xor(a, 1, 64);
-        if (half == 0) lg[r] = v < V ? a : -INFINITY;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        float best = lg[lane];
-        int bi = lane;
-        const float o = lg[lane + 64];
-        if (o > best) { best = o; bi = lane + 64; }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(best, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
-        if (lane == 0) {
-            st_agent(&partial[2 * bx], best);
-            st_agent(&partial[2 * bx + 1], __int_as_float(bx * LMP_ROWS + bi));
-        }
-    }
-    __syncthreads();
-    if (tid == 0) ticket = take_ticket(ticket_word);
-    __syncthreads();
-    if (ticket != gx - 1) return;
-    if (tid == 0) reset_ticket(ticket_word);
-    // attention row of the new token: mean over layers of (mean over heads), summed in layer / head order.
-    // (fixed-trip loops with every load issued first: a run-time-bounded loop of loads is a serial chain of round trips)
-    const float inv_h = 1.0f / (float)H;
-    constexpr int LM = 8, HM = 8;                         // layers x heads held in registers per position (no run-time
-    for (int i = tid; i < S; i += 256) {                  // division in the index arithmetic: 64 of them cost microseconds)
-        float a = 0.f;
-        if (n_layers <= LM && H <= HM) {
-            float rv[LM][HM];
-#pragma unroll
-            for (int l = 0; l < LM; ++l)
-#pragma unroll
-                for (int hh = 0; hh < HM; ++hh)
-                    rv[l][hh] = (l < n_layers && hh < H) ? attn[l * layer_stride + hh * head_stride + i] : 0.f;
-#pragma unroll
-            for (int l = 0; l < LM; ++l)
-                if (l < n_layers) {
-                    float al = rv[l][0];
-#pragma unroll
-                    for (int hh = 1; hh < HM; ++hh)
-                        if (hh < H) al += rv[l][hh];
-                    if (H > 1) al *= inv_h;
-                    a = l == 0 ? al : a + al;
-                }
-        } else {
-            for (int l = 0; l < n_layers; ++l) {
-                const float* r = attn + l * layer_stride + i;
-                float al = r[0];
-                if (H > 1) {
-                    for (int hh = 1; hh < H; ++hh) al += r[hh * head_stride];
-                    al *= inv_h;
-                }
-                a = l == 0 ? al : a + al;
-            }
-        }
-        out[1 + i] = a / (float)n_layers;
-    }
-    if (tid < 64) {
-        float best = -INFINITY;
-        int bi = 0x7fffffff;
-        constexpr int PJ = 4;                             // up to 256 workgroups' partials, all loads in flight
-        float pvv[PJ], pii[PJ];
-#pragma unroll
-        for (int k = 0; k < PJ; ++k) {
-            const int j = lane + 64 * k;
-            pvv[k] = j < (int)gx ? ld_agent(partial + 2 * j) : -INFINITY;
-            pii[k] = j < (int)gx ? ld_agent(partial + 2 * j + 1) : __int_as_float(0x7fffffff);
-        }
-#pragma unroll
-        for (int k = 0; k < PJ; ++k) {                    // ascending workgroup = ascending index: lowest index wins ties
-            const int idx = __float_as_int(pii[k]);
-            if (pvv[k] > best || (pvv[k] == best && idx < bi)) { best = pvv[k]; bi = idx; }
-        }
-        for (int j = lane + 64 * PJ; j < (int)gx; j += 64) {
-            const float v = ld_agent(partial + 2 * j);
-            const int idx = __float_as_int(ld_agent(partial + 2 * j + 1));
-            if (v > best || (v == best && idx < bi)) { best = v; bi = idx; }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(best, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
-        if (lane == 0) {
-            bi = bi == 0x7fffffff ? 0 : bi;
-            out[0] = __int_as_float(bi);
-            if (token_out) *token_out = bi;
-        }
-    }
-    if (host_seq) {
-        // `out` is pinned host memory mapped into the device's address space: the result lands there without a copy
-        // command, and the host, which polls the sequence word behind the row, sees it without a driver wake-up
-        __threadfence_system();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(out + 1 + S), host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 __global__ __launch_bounds__(256) void lm_pick_kernel(const LmPickArgs q, const float* __restrict__ proj_t, int E, int K0,
                                                      const float* __restrict__ emb, int V, int n_layers, int H) {
     lm_pick_body(q, proj_t, E, K0, emb, V, n_layers, H, blockIdx.x, gridDim.x);
@@ -712,7 +450,6 @@ struct DecodeScratch {
     float* part;         // attn_split_scratch_floats(...) floats
     unsigned* tickets;   // TAL_GREEDY_TICKETS words; the last one belongs to the pick
 };
-constexpr int TAL_GREEDY_TICKETS = 256;
 // floats of DecodeScratch::part for a prefix of U rows (batch 1): the key-split attention runs while its (row block, head)
 // groups fit 64 tickets, the FFN's split-K while its tiles fit the tickets 64 .. 254; the two uses never overlap in time
 static size_t decode_scratch_floats(int U, int S, int E, int H) {
@@ -874,6 +611,25 @@ static int decoder_layer_small_multi(const tal_decoder_layer_w* w, const Session
         g[i].sk_tickets = io[i].sk.tickets + 64;
     }
     return launch_skinny_gemm_multi(g, G, 2, s);
+}
+
+// may a step of (U, S) run as ONE launch (csrc/decode_persist.hip)?  The shapes the merged launches take (so that every phase is the
+// kernel form the launch chain uses for this step), dense layers no deeper than 512 per K slice (four waves per workgroup), and the
+// FFN's split-K tickets ending below the words the one-launch step keeps its counters in.
+static bool greedy_persist_ok(const tal_greedy_ctx* c, int U, int S) {
+    const int E = c->E, H = c->H, FF = c->FF, K0 = c->E0 > 0 ? c->E0 : c->E, hd = E / H;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return c->tickets && c->n_layers <= TAL_PS_MAX_LAYERS && (hd == 128 || hd == 64) && E <= 512 && FF / 4 <= 512 && E % 64 == 0 &&
+           small_layer_applicable(1, U, S, E, H, FF, true) && S > 64 && attn_split_tickets(1, U, H) <= 64 && FF >= 2048 && FF % 256 == 0 &&
+           64 + (E / 16) * ((U + 31) / 32) <= PS_BAR && E % 16 == 0 && K0 % 8 == 0 && al16(c->emb) && (!c->proj_t || al16(c->proj_t));
+}
+static void ps_fill_model(const tal_greedy_ctx* c, PsModel& m) {
+    m = PsModel{};
+    for (int l = 0; l < c->n_layers; ++l) m.layer[l] = c->layers[l];
+    m.n_layers = c->n_layers; m.E = c->E; m.H = c->H; m.FF = c->FF; m.V = c->V;
+    m.K0 = c->E0 > 0 ? c->E0 : c->E;
+    m.qscale = 1.0f / sqrtf((float)(c->E / c->H));
+    m.emb = c->emb; m.proj = c->E0 > 0 ? c->proj : nullptr; m.proj_t = c->E0 > 0 ? c->proj_t : nullptr; m.pe = c->pe;
 }
 
 // does a session's step take, in decoder_layer_small, exactly the kernel forms decoder_layer_small_multi launches?
@@ -1133,6 +889,54 @@ extern "C" int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int
     DecodeScratch sk = {p, c->tickets};
     p += up64(decode_scratch_floats(U, S, E, H));
     float* pick_part = p;
+    if (opt(OPT_DECODE_PERSIST) != 0 && greedy_persist_ok(c, U, S)) {
+        // ---- the whole step as ONE launch (csrc/decode_persist.hip): the same kernel bodies on the same arguments behind phase barriers
+        for (int l = 0; l < L; ++l) TAL_CHECK_ARG(c->k_cache[l] && c->vt_cache[l], "tal_greedy_step_fwd: layer %d has no cached K / V^T", l);
+        const bool host_direct = sync >= 2;
+        if (host_direct && !c->picked_host_dev) {
+            void* alias = nullptr;
+            if (hipHostGetDevicePointer(&alias, c->picked_host, 0) != hipSuccess || !alias) {
+                set_error("tal_greedy_step_fwd: picked_host is not mapped pinned host memory (%s)", hipGetErrorString(hipGetLastError()));
+                return TAL_EINVAL;
+            }
+            c->picked_host_dev = reinterpret_cast<float*>(alias);
+            reinterpret_cast<volatile unsigned*>(c->picked_host)[1 + S] = 0u;
+        }
+        if (host_direct && ++c->seq == 0) ++c->seq;
+        PsArgs a;
+        ps_fill_model(c, a.m);
+        a.n = 1;
+        a.G = opt(OPT_DECODE_PERSIST_WGS) > 0 ? opt(OPT_DECODE_PERSIST_WGS) : 32;
+        PsSession& q = a.s[0];
+        q = PsSession{};
+        q.tokens = c->tokens + history_start; q.token_out = c->tokens + n_gen;
+        q.U = U; q.S = S;
+        q.h0 = h0; q.h1 = h1; q.qkv = ws.mha.q; q.vt = ws.mha.vt; q.ctx = ws.mha.ctx; q.x1 = ws.x1; q.x2 = ws.x2; q.ff = ws.ff;
+        q.probs = probs; q.sk_part = sk.part; q.pick_part = pick_part;
+        q.out = host_direct ? c->picked_host_dev : c->picked_dev;
+        q.tickets = c->tickets;
+        for (int l = 0; l < L; ++l) { q.k_cache[l] = c->k_cache[l]; q.vt_cache[l] = c->vt_cache[l]; }
+        q.kpm = c->mem_kpm; q.k_pitch = c->k_pitch;
+        q.host_seq = host_direct ? c->seq : 0u;
+        int rc = launch_greedy_persist(a, s);
+        if (rc) return rc;
+        if (sync == 3 || sync == 0) return TAL_OK;
+        if (host_direct) {
+            const int got = tal_greedy_step_poll(c, 20000);
+            if (got == 1) return TAL_OK;
+            if (got == 0) {
+                const hipError_t e = hipStreamSynchronize(s);
+                set_error("tal_greedy_step_fwd: no result of the one-launch step after 20 s (stream after the wait: %s)", hipGetErrorString(e));
+            }
+            return TAL_EHIP;
+        }
+        if (hipMemcpyAsync(c->picked_host, c->picked_dev, (size_t)(1 + S) * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            set_error("tal_greedy_step_fwd: device-to-host copy failed: %s", hipGetErrorString(hipGetLastError()));
+            return TAL_EHIP;
+        }
+        return TAL_OK;
+    }
     int rc = tal_embed_tokens_fwd(c->tokens + history_start, 1, U, c->emb, V, E0 > 0 ? E0 : E, E0 > 0 ? c->proj : nullptr, E, c->pe,
                                   c->max_len, h0, stream);
     if (rc) return rc;

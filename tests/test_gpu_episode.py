@@ -206,6 +206,42 @@ def test_merged_step_equals_solo_step_bit_for_bit(asr_weights):
         N.set_option("decode_wide_gemm", 0)
 
 
+def test_one_launch_step_equals_the_launch_chain_bit_for_bit(asr_weights):
+    """The decode step as ONE launch (option decode_persist, csrc/decode_persist.hip: persistent workgroups walk the step's phases
+    behind counter barriers and run the launch chain's own kernel bodies) against tal_greedy_step_fwd's chain of 34 launches on
+    the same states: prefixes of 1, 17, 40 and 96 tokens on different windows, 16 / 32 / 64 workgroups per session, repeated
+    (the counters must come back to zero) -- token, attention row and the appended device token identical; the session's ticket
+    block is all zero afterwards; a prefix beyond the one-launch form's range (200 tokens) silently takes the chain."""
+    from tal_asrd_amd import ASRModel, synth, _native as N
+    from tal_asrd_amd.system import _GreedySession
+    dev = torch.device("cuda:0")
+    asr = _load(ASRModel("2x", num_speakers=6008, vocab_size=10000, use_speaker_head=True), asr_weights, dev)
+    L = 60 * 16000
+    audio = torch.from_numpy(synth.synth_audio_batch(1, L, 99)).to(dev)
+    enc = asr.encode(audio.half(), torch.tensor([L]))
+    rng = np.random.default_rng(5)
+    sessions, chain = [], []
+    for k, U in enumerate((1, 17, 40, 96, 200)):
+        toks = torch.from_numpy(rng.integers(3, 10000, size=U + 8).astype(np.int64)).to(dev)
+        s = _GreedySession(asr, toks, 512)
+        sl = slice(40 * k, 40 * k + 357)
+        s.set_window({"encoder_out": enc["encoder_out"][:, sl].contiguous(), "encoder_padding_mask": enc["encoder_padding_mask"][:, sl].contiguous()})
+        sessions.append((s, U))
+        chain.append(s.step(0, U) + (int(toks[U]),))
+    try:
+        N.set_option("decode_persist", 1)
+        for wgs in (32, 16, 64, 32):
+            N.set_option("decode_persist_wgs", wgs)
+            for (s, U), (tok, row, appended) in zip(sessions, chain):
+                s.gen_dev[U] = -1
+                t2, r2 = s.step(0, U)
+                assert t2 == tok and np.array_equal(r2, row) and int(s.gen_dev[U]) == appended, (wgs, U)
+                assert int(s._tickets.abs().sum()) == 0, (wgs, U)
+    finally:
+        N.set_option("decode_persist", 0)
+        N.set_option("decode_persist_wgs", 32)
+
+
 def test_a_failing_episode_ends_the_whole_call(asr_weights):
     """An episode whose start-up raises (a waveform too short for the encoder) ends transcribe_unaligned_many with an error that
     names it -- in every mode, without leaving a thread waiting for the others."""

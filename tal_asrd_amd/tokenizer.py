@@ -50,27 +50,11 @@ class Tokenizer:
 
     def decode_speakers(self, tokens, add_last=True):
         """:103-138.  Ids >= len(self) are speaker tokens, EOS closes an utterance, BOS is ignored.
-        -> ([(text, speaker | None), ...], [token index of every split])."""
-        utterances, buffer, split_indices = [], [], []
-        cur_speaker = None
-        i = -1
-        for i, x in enumerate(tokens):
-            x = int(x)
-            if x == self.bos_token_id:
-                continue
-            if x >= len(self):
-                cur_speaker = x - len(self)
-            elif x == self.eos_token_id:
-                if buffer:
-                    utterances.append((self.decode(buffer), cur_speaker))
-                    cur_speaker = None
-                    buffer = []
-                    split_indices.append(i)
-            else:
-                buffer.append(x)
-        if buffer and add_last:
-            utterances.append((self.decode(buffer), cur_speaker))
-            split_indices.append(i)
+        -> ([(text, speaker | None), ...], [token index of every split]).  The token-level loop is util.split_speaker_turns (one
+        implementation for the scorer and the tokenizer); each turn's tokens are then rendered by `decode`."""
+        from .util import split_speaker_turns
+        turns, split_indices = split_speaker_turns(tokens, len(self), self.bos_token_id, self.eos_token_id, add_last)
+        utterances = [(self.decode(buf), speaker) for buf, speaker in turns]
         assert len(utterances) == len(split_indices)
         return utterances, split_indices
 

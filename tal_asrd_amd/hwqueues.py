@@ -1,0 +1,81 @@
+"""HIP streams spread over the device's hardware queues.
+
+A HIP stream is served by one of a few hardware queues (four per process on this stack), and the runtime deals streams to queues in
+an order a caller cannot choose or ask for: of ten streams created one after the other on an MI355X, the 4th and 5th, the 3rd and
+6th, the 2nd and 7th ... share a queue (profiles/r5_stream_hardware_queues.txt).  Two chains of dependent launches on streams that
+share a queue run one after the other, not side by side -- System.transcribe_unaligned_many with four decode chains took 3.3 s or
+5.0 s for the same corpus depending on which streams its threads happened to get.
+
+`spread(device, k)` returns k streams on as many DIFFERENT hardware queues as there are, found by measurement, once per process and
+device: two short chains of spin kernels take the time of one when their streams sit on different queues and twice that when they
+share one.  Speed only: any set of streams is correct.
+"""
+import threading
+import time
+
+import torch
+
+_lock = threading.Lock()
+_classes = {}            # device index -> list of queue classes, each a list of torch.cuda.Stream
+POOL = 12                # streams probed per device
+_SPIN = 60000            # spin-kernel length (device clock ticks, ~30 us)
+_CHAIN = 10
+
+
+def _chain(stream):
+    with torch.cuda.stream(stream):
+        for _ in range(_CHAIN):
+            torch.cuda._sleep(_SPIN)
+
+
+def _timed(dev, streams):
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for s in streams:
+        _chain(s)
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0
+
+
+def classes(device):
+    """-> the device's probed streams grouped by hardware queue (a list of lists; one list when the probe cannot tell them apart)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _lock:
+        if idx in _classes:
+            return _classes[idx]
+        with torch.cuda.device(idx):
+            pool = [torch.cuda.Stream(device=dev) for _ in range(POOL)]
+            for s in pool[:2]:
+                _timed(dev, [s])                                  # (first launches: code upload, clocks)
+            one = min(_timed(dev, [pool[0]]) for _ in range(3))
+            out = []
+            for s in pool:
+                for c in out:
+                    # same queue: the two chains take ~2x one chain; different queues: ~1x (the midpoint decides; best of two)
+                    if min(_timed(dev, [c[0], s]) for _ in range(2)) > 1.5 * one:
+                        c.append(s)
+                        break
+                else:
+                    out.append([s])
+            if len(out) > 8:                                      # (implausible: timing noise) -- treat the pool as one class
+                out = [pool]
+        _classes[idx] = out
+        return out
+
+
+def spread(device, k):
+    """k streams, dealt round-robin over the hardware queues (the first min(k, queues) of them pairwise on different queues)."""
+    cl = classes(device)
+    order = []
+    depth = 0
+    while len(order) < k:
+        took = False
+        for c in cl:
+            if depth < len(c) and len(order) < k:
+                order.append(c[depth])
+                took = True
+        depth += 1
+        if not took:                                              # more streams asked for than probed: fresh ones
+            order.append(torch.cuda.Stream(device=torch.device(device)))
+    return order

@@ -429,9 +429,21 @@ class System:
         errors = []
         nxt = [0]
         take = threading.Lock()
+        # one stream per host thread, on DIFFERENT hardware queues as far as the device has them (two chains of launches on streams
+        # that share a queue run one after the other: 3.3 s or 5.0 s for the same corpus, by the luck of the draw, before hwqueues)
+        from . import hwqueues
+        group = max(1, min(int(group), N.TAL_GROUP_MAX))
+        n_workers = max(1, min(int(streams), (len(episodes) + group - 1) // group)) if group > 1 else 0
+        # (group mode: its worker threads + the producer; otherwise one thread per session in flight)
+        stream_pool = hwqueues.spread(dev, n_workers + 1 if group > 1 else max(1, min(int(streams), len(episodes))))
+        pool_lock = threading.Lock()
+
+        def own_stream():
+            with pool_lock:
+                return stream_pool.pop(0) if stream_pool else torch.cuda.Stream(device=dev)
 
         def worker():
-            stream = torch.cuda.Stream(device=dev)
+            stream = own_stream()
             with torch.cuda.device(dev), torch.cuda.stream(stream):
                 while True:
                     with take:
@@ -448,17 +460,15 @@ class System:
                         errors.append((i, e))
                         return
 
-        group = max(1, min(int(group), N.TAL_GROUP_MAX))
         lib = N.lib()
 
         import queue
         ready = queue.Queue(maxsize=max(2, group))          # episodes whose session is past its first step
-        n_workers = max(1, min(int(streams), (len(episodes) + group - 1) // group)) if group > 1 else 0
 
         def producer():
             """Everything an episode needs before it can join a group -- upload, encode, the episode-wide K | V table, the first
             step through the module API, its session's buffers -- on a stream of its own, while the groups keep stepping."""
-            stream = torch.cuda.Stream(device=dev)
+            stream = producer_stream
             i = -1
             try:
                 with torch.cuda.device(dev), torch.cuda.stream(stream):
@@ -480,7 +490,7 @@ class System:
                     ready.put(None)
 
         def group_worker():
-            stream = torch.cuda.Stream(device=dev)
+            stream = own_stream()
             slots = []                       # [episode index, _UnalignedRun]
             G16 = N.TAL_GROUP_MAX
             st_arr, ctx_arr, cap_arr = (C.POINTER(N.UnalignedState) * G16)(), (C.POINTER(N.GreedyCtx) * G16)(), (C.c_int64 * G16)()
@@ -554,6 +564,7 @@ class System:
                         drained = ready.get() is None
 
         if group > 1:
+            producer_stream = stream_pool.pop() if len(stream_pool) > n_workers else torch.cuda.Stream(device=dev)    # (the last one dealt: it shares a queue only when the workers already cover them all)
             threads = [threading.Thread(target=producer, daemon=True)] + [threading.Thread(target=group_worker, daemon=True) for _ in range(n_workers)]
         else:
             threads = [threading.Thread(target=worker, daemon=True) for _ in range(max(1, min(int(streams), len(episodes))))]

@@ -258,3 +258,27 @@ def test_a_failing_episode_ends_the_whole_call(asr_weights):
             system.transcribe_unaligned_many(good[:2] + [bad] + good[2:], streams=streams, group=group)
     out = system.transcribe_unaligned_many(good, streams=2, group=2)          # ... and the next call is unaffected
     assert len(out) == 3 and all(o is not None for o in out)
+
+
+def test_streams_are_spread_over_the_hardware_queues():
+    """tal_asrd_amd.hwqueues: the probed stream pool is partitioned into hardware-queue classes (every stream in exactly one), the
+    classes reproduce under a second look at the pairs (two chains on streams of one class take about twice one chain, of different
+    classes about once), and spread(k) deals k distinct streams with the first ones on pairwise different queues."""
+    from tal_asrd_amd import hwqueues
+    dev = torch.device("cuda:0")
+    cl = hwqueues.classes(dev)
+    flat = [s for c in cl for s in c]
+    assert len(flat) == hwqueues.POOL and len({s.stream_id for s in flat}) == hwqueues.POOL
+    assert 1 <= len(cl) <= 8
+    one = min(hwqueues._timed(dev, [flat[0]]) for _ in range(3))
+    if len(cl) > 1:
+        apart = min(hwqueues._timed(dev, [cl[0][0], cl[1][0]]) for _ in range(3))
+        assert apart < 1.5 * one, (one, apart)
+    if len(cl[0]) > 1:
+        together = min(hwqueues._timed(dev, [cl[0][0], cl[0][1]]) for _ in range(3))
+        assert together > 1.5 * one, (one, together)
+    for k in (1, 3, 5, 14):
+        got = hwqueues.spread(dev, k)
+        assert len(got) == k and len({id(s) for s in got}) == k
+        head = got[:min(k, len(cl))]
+        assert len({next(i for i, c in enumerate(cl) if s in c) for s in head}) == len(head)

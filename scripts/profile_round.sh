@@ -12,7 +12,7 @@ python bench.py > $O/bench_1h.json 2> $O/bench_1h.err
 TAL_OPTIONS=gemm_no_w64 python bench.py --no-cpu-baseline --no-exact-pass > $O/bench_1h_128row_tiles.json 2> /dev/null
 TAL_OPTIONS=tds_exact_f32 python bench.py --no-cpu-baseline > $O/bench_1h_fp32.json 2> $O/bench_1h_fp32.err
 TAL_OPTIONS=tds_fp32_activations python bench.py --no-cpu-baseline > $O/bench_1h_fp32_activations.json 2> /dev/null
-python bench.py --workload segments --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_segments_64x5min.json 2> /dev/null
+python bench.py --workload segments --no-cpu-baseline --steps 6 --warmup 2 > $O/bench_segments_64x5min.json 2> /dev/null
 python bench.py --workload segments --segments 8 --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_segments_8x5min.json 2> /dev/null
 python bench.py --workload decode --steps 2 --warmup 1 > $O/bench_decode_1h_episode.json 2> /dev/null
 python scripts/bench_gconv_grid.py > $O/gconv_grid.txt 2>&1

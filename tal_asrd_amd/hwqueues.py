@@ -46,6 +46,9 @@ def classes(device):
             return _classes[idx]
         with torch.cuda.device(idx):
             pool = [torch.cuda.Stream(device=dev) for _ in range(POOL)]
+            if not hasattr(torch.cuda, "_sleep"):                 # (no spin kernel to measure with: every stream in one class --
+                _classes[idx] = [pool]                            #  spread() then deals the pool in creation order, as before)
+                return _classes[idx]
             for s in pool[:2]:
                 _timed(dev, [s])                                  # (first launches: code upload, clocks)
             one = min(_timed(dev, [pool[0]]) for _ in range(3))

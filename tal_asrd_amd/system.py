@@ -15,8 +15,9 @@ Text-prefix recomputation is kept: the reference decodes with causal_mask=False
 (system.py:113,350), so every earlier position attends to later tokens and a self-attention
 KV cache would change results (hard parts).
 
-Not built (not on the acoustic hot path): LM fusion (`self.lm`, system.py:127-138 -- no
-language model ships with the reference), training / validation steps, data loaders.
+LM fusion (`self.lm`, system.py:127-138) takes any caller-side module called as lm(tokens, causal_mask=False): the
+reference's own `tal/lm` package does not exist; pinned with a stand-in LM on both sides (tests/golden/_lm_standin.py).
+Not built (not on the acoustic hot path): training / validation steps, data loaders.
 The half-precision casts of the waveform (`force_half`, system.py:91-92,285) are performed as written: the model
 takes the fp16 waveform, widens it exactly in the front-end and computes in fp32 from there (BASELINE.json: logits
 within 1e-3 of the fp32 CPU path run on the same -- fp16-rounded -- audio).
@@ -362,12 +363,14 @@ class System:
     """Holds the model and the decode-time arguments the reference reads from `self.args`
     (spk_weight, lm_weight) and `self.tokenizer` (eos_token_id)."""
 
-    def __init__(self, model, spk_weight=0.0, eos_token_id=1, bos_token_id=0, pad_token_id=2, tokenizer=None):
+    def __init__(self, model, spk_weight=0.0, eos_token_id=1, bos_token_id=0, pad_token_id=2, tokenizer=None, lm=None, lm_weight=0.0):
         self.model = model
-        self.args = SimpleNamespace(spk_weight=spk_weight, lm_weight=0.0)
+        self.args = SimpleNamespace(spk_weight=spk_weight, lm_weight=lm_weight)
         self.tokenizer = tokenizer if tokenizer is not None else SimpleNamespace(
             eos_token_id=eos_token_id, bos_token_id=bos_token_id, pad_token_id=pad_token_id)
-        self.lm = None
+        # shallow fusion in `generate` (system.py:127-138): any caller-side module called as lm(tokens [rows, U], causal_mask=False)
+        # -> logits [rows, U, vocab]; needs a tokenizer with __len__ (speaker tokens are clamped to len(tokenizer) - 1 for the LM)
+        self.lm = lm
         # the module API keeps per-call results on the modules themselves (layer.src_attn_weights, the cached window K / V^T):
         # sections that go through it are serialised; the per-token C call of a decode session needs no lock
         self._lock = threading.RLock()
@@ -637,6 +640,14 @@ class System:
             V = logits.size(-1)
             pred_speaker = asr_decode_spk(model, y, encoder_out, causal=False, last_only=True) if use_spk else None
             logprobs = log_softmax(logits)
+            if self.lm is not None and self.args.lm_weight > 0:
+                # system.py:127-138: the LM never sees speaker tokens; its last-position log-probabilities are added on the shared
+                # part of the two vocabularies (the LM is the caller's module; its log-softmax runs on the HIP row kernel)
+                lm_input = torch.clamp(y, max=len(self.tokenizer) - 1)
+                lm_logits = self.lm(lm_input, causal_mask=False)[:, -1, :]
+                lm_logprobs = log_softmax(lm_logits.float().contiguous())
+                nl = min(lm_logprobs.size(-1), logprobs.size(-1))
+                logprobs[:, :nl] += lm_logprobs[:, :nl] * self.args.lm_weight
             done_dev = torch.from_numpy(done.astype(np.uint8)).to(dev) if cur_beam == beam_size else None
             top_scores, indices = _beam_topk(logprobs, scores, done_dev, batch_size, cur_beam, beam_size)
             idx_h = indices.cpu().numpy()

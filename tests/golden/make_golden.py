@@ -256,6 +256,49 @@ def sec_flow(ns):
          attn=np.stack([a.numpy()[0] for _, a in align]).astype(np.float32))
 
 
+def sec_flow_lm(ns):
+    """The LM shallow-fusion branch of System.generate (tal/asr/system.py:127-138), recorded from the reference's own function with
+    a stand-in LM (tests/golden/_lm_standin.py: the reference's LM class does not exist): beam 1 with the speaker head and
+    force_output, beam 3 with a terminate token, lm_weight 0.5."""
+    import types
+    from tests.golden._lm_standin import StandInLM
+    System = ns.system.System
+    model = _asr_model(ns)
+    EOS, BOS = 1, 0
+
+    class Tok(types.SimpleNamespace):
+        def __len__(self):
+            return 10000
+    tok = Tok(eos_token_id=EOS, bos_token_id=BOS, pad_token_id=2)
+    lm = StandInLM().eval()
+    lens = [160000, 120000]
+    audio = synth.synth_audio_batch(2, 160000, 77, lens=lens)
+    term = None
+    plain = np.load(os.path.join(HERE, "flow_generate_beam1.npz"))
+    for beam, spkw in ((1, 1.0), (3, 0.0)):
+        me = types.SimpleNamespace(model=model, lm=lm, tokenizer=tok, args=types.SimpleNamespace(spk_weight=spkw, lm_weight=0.5))
+        margins = []
+        real = lm.forward
+
+        def spy(t, causal_mask=True):
+            return real(t, causal_mask=causal_mask)
+        seqs, spks = System.generate(me, torch.from_numpy(audio), torch.full((2, 1), BOS, dtype=torch.long), torch.tensor(lens),
+                                     length=24, beam_size=beam, terminate_token=EOS if beam == 1 else term, force_half=False,
+                                     force_output=(beam == 1))
+        out = {"audio_seed": 77, "audio_lens": np.asarray(lens), "length": 24, "beam": beam, "lm_weight": 0.5,
+               "terminate_token": EOS if beam == 1 else term}
+        for i, sq in enumerate(seqs):
+            out["seq_%d" % i] = sq.numpy() if sq is not None else np.zeros(0, dtype=np.int64)
+            if spks[i] is not None:
+                out["spk_argmax_%d" % i] = spks[i].argmax(-1).numpy()
+        if beam == 1:
+            term = int(seqs[0][9])
+            # the fusion must change the decode, or the fixture pins nothing
+            print("beam 1: tokens that differ from the run without the LM:", int((seqs[0].numpy() != plain["seq_0"]).sum()), "of", len(seqs[0]))
+            assert (seqs[0].numpy() != plain["seq_0"]).any()
+        save("flow_generate_lm_beam%d" % beam, **out)
+
+
 SPLICE_CASES = [
     (["the quick brown fox jumps over the lazy dog and runs", "over the lazy dog and runs away to the hills",
       "away to the hills where nobody ever goes"], 5),
@@ -493,7 +536,7 @@ def sec_half(ns):
     save("flow_generate_beam1_half", **out)
 
 
-SECTIONS = {"half": sec_half, "flow_short": sec_flow_short, "variants": sec_variants, "keys": sec_keys, "unit": sec_unit, "sd": sec_sd, "asr": sec_asr,
+SECTIONS = {"flow_lm": sec_flow_lm, "half": sec_half, "flow_short": sec_flow_short, "variants": sec_variants, "keys": sec_keys, "unit": sec_unit, "sd": sec_sd, "asr": sec_asr,
             "decode": sec_decode, "gru": sec_gru, "flow": sec_flow,
             "transcribe": sec_transcribe, "uisrnn": sec_uisrnn}
 

@@ -61,6 +61,36 @@ def test_generate_beam3_terminates(asr_model):
         assert spks[i] is None
 
 
+@pytest.mark.parametrize("beam", [1, 3])
+def test_generate_with_lm_shallow_fusion(asr_model, beam):
+    """The LM branch of System.generate (tal/asr/system.py:127-138: last-position LM log-probabilities, speaker tokens clamped away,
+    added with lm_weight on the shared vocabulary) against fixtures recorded from the reference's own function with a stand-in LM
+    (the reference ships no LM class): beam 1 with the speaker head and force_output, beam 3 with a terminate token."""
+    from tal_asrd_amd import synth
+    from tal_asrd_amd.system import System
+    from tal_asrd_amd.tokenizer import SynthTokenizer
+    from tests.golden._lm_standin import StandInLM
+    g = golden("flow_generate_lm_beam%d" % beam)
+    lens = g["audio_lens"].tolist()
+    audio = torch.from_numpy(synth.synth_audio_batch(2, max(lens), int(g["audio_seed"]), lens=lens)).to(dev())
+    lm = StandInLM().eval().to(dev())
+    sys_ = System(asr_model, spk_weight=1.0 if beam == 1 else 0.0, tokenizer=SynthTokenizer(10000), lm=lm, lm_weight=float(g["lm_weight"]))
+    seqs, spks = sys_.generate(audio, torch.zeros(2, 1, dtype=torch.long, device=dev()), torch.tensor(lens), length=int(g["length"]),
+                               beam_size=beam, terminate_token=int(g["terminate_token"]), force_half=False, force_output=(beam == 1))
+    for i in range(2):
+        want = g["seq_%d" % i]
+        if want.size == 0:
+            assert seqs[i] is None
+        else:
+            np.testing.assert_array_equal(seqs[i].numpy(), want)
+        if beam == 1:
+            np.testing.assert_array_equal(spks[i].argmax(-1).numpy(), g["spk_argmax_%d" % i])
+    # without the LM the decode is a different one (the fixture pins the fusion, not the plain path)
+    if beam == 1:
+        plain = golden("flow_generate_beam1")
+        assert (g["seq_0"] != plain["seq_0"]).any()
+
+
 def test_generate_unaligned_trajectory(asr_model):
     from tal_asrd_amd import synth
     from tal_asrd_amd.system import System

@@ -44,7 +44,7 @@ extern "C" {
 #define TAL_MAX_STAGES 4
 #define TAL_MAX_DEPTH 8
 
-int tal_version(void);          /* 410 = 0.4.1 */
+int tal_version(void);          /* 420 = 0.4.2 */
 const char* tal_last_error(void);
 
 /* Process-wide behaviour switches.  The library never reads the environment: which kernels a caller gets depends on its
@@ -211,6 +211,9 @@ typedef struct tal_tds_desc {
     int32_t _pad2;
 } tal_tds_desc;
 #define TAL_TDS_EXACT_F32 1
+#define TAL_TDS_OUT_SPLIT 2   /* leave y in the hi / lo split form where the last stage runs all-split (tal_tds_out_split() says whether
+                               * a call will): for tal_sd_head_split_fwd, whose embedding layer consumes that form -- the last dense layer
+                               * then never writes an fp32 copy of the encoder output */
 
 /* output length after all stride-2 stages: T' = f(f(f(T))), f(t) = (t-21)/2+1 */
 int64_t tal_tds_out_len(const tal_tds_desc* d, int64_t T);
@@ -225,6 +228,8 @@ size_t tal_tds_workspace_bytes(const tal_tds_desc* d, int B, int64_t T);
  * status word is cleared by a kernel, not a memset node), so a caller may capture them into a HIP graph once every one-off
  * build (plans, weight packs) has run eagerly; the status word is read after each replay like after each call. */
 size_t tal_tds_status_offset(const tal_tds_desc* d, int B, int64_t T);
+/* 1: tal_tds_fwd / tal_tds_premean_fwd with TAL_TDS_OUT_SPLIT in d->flags writes y in the split form for these shapes; 0: fp32 */
+int tal_tds_out_split(const tal_tds_desc* d, int B, int64_t T);
 /* x [B, T, channels[0]] -> y [B, T', channels[n_stages]] */
 int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t T, float* y,
                 void* workspace, size_t workspace_bytes, void* stream);
@@ -265,6 +270,13 @@ size_t tal_sd_head_workspace_bytes(int64_t M, int S);
 int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_embed, const float* b_embed, int E,
                     const float* w_logit, const float* b_logit, int S, float* feat, float* logits,
                     int32_t* ids, void* workspace, size_t workspace_bytes, void* stream);
+/* The same head on an encoder output still in the hi / lo split form (tal_tds_fwd with TAL_TDS_OUT_SPLIT where tal_tds_out_split()
+ * says so): x_split [M, C] split rows, w_embed_split = tal_split_f16x3_fwd of spk_embed_proj.weight [E, C]; the embedding layer
+ * runs in the fp16x3 form (fp32-equivalent: max error against float64 3e-6 on the 1-hour shape, the fp32 kernel's 9e-6), everything
+ * behind `feat` as above.  M > 128, C % 32 == 0. */
+int tal_sd_head_split_fwd(const void* x_split, int64_t M, int C, const void* w_embed_split, const float* b_embed, int E,
+                          const float* w_logit, const float* b_logit, int S, float* feat, float* logits,
+                          int32_t* ids, void* workspace, size_t workspace_bytes, void* stream);
 /* Row-wise argmax of a [M, N] fp32 matrix -> int32 ids (first maximum wins). */
 int tal_argmax_rows(const float* x, int64_t M, int N, int32_t* ids, void* stream);
 

@@ -28,8 +28,8 @@ for sec in [float(a) for a in sys.argv[1:]] or [30.0, 300.0]:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             mel, mean = m.logmelspec.forward_unsubtracted(static_x)
-            y, chk = ops.tds_forward(enc._descriptor(0, len(enc.sizes) - 1), mel, enc.sizes[-1], defer=True, x_mean=mean)
-            feat, _, ids = ops.sd_head(y, *heads, want_logits=False, want_ids=True)
+            y, chk = ops.tds_forward(enc._descriptor(0, len(enc.sizes) - 1), mel, enc.sizes[-1], defer=True, x_mean=mean, out_split=True)
+            feat, _, ids = ops.sd_head(y, *heads, want_logits=False, want_ids=True, x_split=chk.y_split, w_embed_split=m._embed_split())
         def replay():
             static_x.copy_(x); graph.replay()
             assert not chk.flagged()

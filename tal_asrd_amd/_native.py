@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("TAL_ASRD_LIB", os.path.join(_HERE, "libtal_asrd_hip.s
 TAL_MAX_STAGES = 4
 TAL_MAX_DEPTH = 8
 TAL_TDS_EXACT_F32 = 1
+TAL_TDS_OUT_SPLIT = 2
 TAL_GROUP_MAX = 16      # sessions per merged decode step (csrc/common.h)
 
 c_float_p = C.c_void_p  # device pointers travel as integers
@@ -96,6 +97,7 @@ SIGNATURES = {
     "tal_tds_workspace_bytes": (_sz, [C.POINTER(TdsDesc), _i, _i64]),
     "tal_tds_status_offset": (_sz, [C.POINTER(TdsDesc), _i, _i64]),
     "tal_tds_fwd": (_i, [C.POINTER(TdsDesc), _p, _i, _i64, _p, _p, _sz, _p]),
+    "tal_tds_out_split": (_i, [C.POINTER(TdsDesc), _i, _i64]),
     "tal_tds_premean_ok": (_i, [C.POINTER(TdsDesc), _p]),
     "tal_tds_premean_fwd": (_i, [C.POINTER(TdsDesc), _p, _p, _i, _i64, _p, _p, _sz, _p]),
     "tal_tds_halo": (_i, [C.POINTER(TdsDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -104,6 +106,7 @@ SIGNATURES = {
     "tal_tds_tiled_fwd": (_i, [C.POINTER(TdsDesc), _p, _i64, _p, _i64, _p, _sz, _p]),
     "tal_sd_head_workspace_bytes": (_sz, [_i64, _i]),
     "tal_sd_head_fwd": (_i, [_p, _i64, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _sz, _p]),
+    "tal_sd_head_split_fwd": (_i, [_p, _i64, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _sz, _p]),
     "tal_argmax_rows": (_i, [_p, _i64, _i, _p, _p]),
     "tal_embed_tokens_fwd": (_i, [_p, _i, _i, _p, _i, _i, _p, _i, _p, _i, _p, _p]),
     "tal_add_positional_fwd": (_i, [_p, _i, _i, _i, _p, _i, _p, _p]),

@@ -187,7 +187,7 @@ static int64_t conv_out_len(int64_t t) { return t < 21 ? 0 : (t - 21) / 2 + 1; }
 
 using namespace tal;
 
-extern "C" int tal_version(void) { return 410; /* 0.4.1: tal_tds_premean_fwd / tal_tds_premean_ok; 0.4.0: tal_greedy_ctx grew (k_pitch, episode-wide K | V table), merged decode steps, tal_unaligned_*, tal_logmel_f16_fwd; 0.3.0: tal_set_option */ }
+extern "C" int tal_version(void) { return 420; /* 0.4.2: TAL_TDS_OUT_SPLIT, tal_tds_out_split, tal_sd_head_split_fwd; 0.4.1: tal_tds_premean_fwd / tal_tds_premean_ok; 0.4.0: tal_greedy_ctx grew (k_pitch, episode-wide K | V table), merged decode steps, tal_unaligned_*, tal_logmel_f16_fwd; 0.3.0: tal_set_option */ }
 
 // Host-side helper of the decode loop (no device work): ngram_repeat_mask(row, n).sum() of tal/asr/util.py:5-17 -- the number
 // of positions covered by an n-gram that already occurred earlier in the row; like the reference, n-gram starts run to
@@ -388,6 +388,14 @@ extern "C" size_t tal_tds_workspace_bytes(const tal_tds_desc* d, int B, int64_t 
 
 static int tds_fwd_impl(const tal_tds_desc* d, const float* x, const float* x_mean, int B, int64_t T, float* y, void* workspace,
                         size_t workspace_bytes, void* stream);
+static bool tds_last_stage_allsplit(const tal_tds_desc* d, int B, int64_t T);
+
+// 1: a call with TAL_TDS_OUT_SPLIT in d->flags leaves y in the hi / lo split form (the last stage runs all-split: long inputs on
+// the fp16x3 kernels); 0: y is fp32 as always (short inputs, odd widths, the exact mode)
+extern "C" int tal_tds_out_split(const tal_tds_desc* d, int B, int64_t T) {
+    if (check_desc(d) || B <= 0 || tal_tds_out_len(d, T) <= 0 || !(d->flags & TAL_TDS_OUT_SPLIT)) return 0;
+    return tds_last_stage_allsplit(d, B, T) ? 1 : 0;
+}
 
 extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t T, float* y, void* workspace,
                            size_t workspace_bytes, void* stream) {
@@ -407,6 +415,45 @@ extern "C" int tal_tds_premean_fwd(const tal_tds_desc* d, const float* x, const 
     TAL_CHECK_ARG(tal_tds_premean_ok(d, x), "tal_tds_premean_fwd: the first resize conv of this stack (%d -> %d channels, %d groups) has no mean-folding "
                   "kernel: subtract the mean (tal_subtract_scalar) and call tal_tds_fwd", d->channels[0], d->channels[1], d->groups);
     return tds_fwd_impl(d, x, x_mean, B, T, y, workspace, workspace_bytes, stream);
+}
+
+// Which form a stage of the stack runs in is decided from the descriptor and the shapes alone (tal_tds_fwd and tal_tds_out_split share it).
+static bool tds_s2_mfma_ok(const tal_tds_desc* d, int B, int i, int64_t Tin, bool force_f32) {       // stride-2 resize conv of stage i on the matrix cores
+    return !force_f32 && d->down_w_frag[i] && (int64_t)B * conv_out_len(Tin) > 64 &&
+           gconv_f16x3_weight_bytes(d->channels[i], d->channels[i + 1], d->groups, 2) > 0 && gconv_f16x3_fits(Tin, d->channels[i]);
+}
+static bool tds_stage_allsplit(const tal_tds_desc* d, int B, int64_t T, int i, const float* xin, bool in_split, bool force_f32, bool no_allsplit) {
+    if (force_f32 || no_allsplit || i >= d->n_stages || d->depths[i] == 0) return false;
+    const int c = d->channels[i + 1], cin = d->channels[i];
+    int64_t Tin = T;
+    for (int q = 0; q < i; ++q) Tin = conv_out_len(Tin);
+    const int64_t To = conv_out_len(Tin), M = (int64_t)B * To;
+    if (M <= 128 || c % 160 != 0 || c % 32 != 0 || !gconv_f16x3_fits(To, c) || gconv_f16x3_weight_bytes(c, c, d->groups, 1) == 0) return false;
+    for (int j = 0; j < d->depths[i]; ++j)
+        if (!d->blocks[i][j].fc0_w_split || !d->blocks[i][j].fc3_w_split || !d->blocks[i][j].conv_w_frag) return false;
+    // the resize conv must be able to write the split form: the 1 -> 10 channel kernel or a matrix-core kernel
+    if (tds_s2_mfma_ok(d, B, i, Tin, force_f32)) return !in_split || cin % 32 == 0;
+    return !in_split && gconv_s2_can_split(cin, c, d->groups, xin);
+}
+// the last stage's form, with the input form it will see (the previous stage's output is split iff that stage and the matrix-core
+// resize conv between them allow it: the same chain of decisions tds_fwd_impl makes)
+static bool tds_last_stage_allsplit(const tal_tds_desc* d, int B, int64_t T) {
+    const bool force_f32 = opt(OPT_TDS_EXACT_F32) != 0 || (d->flags & TAL_TDS_EXACT_F32) != 0;
+    const bool no_allsplit = opt(OPT_TDS_FP32_ACTIVATIONS) != 0;
+    bool cur_split = false;
+    int64_t Tc = T;
+    bool allsplit = false;
+    for (int i = 0; i < d->n_stages; ++i) {
+        const int64_t To = conv_out_len(Tc);
+        // (stage 0 reads the caller's fp32 x; its alignment matters only to the 1 -> 10 kernel, which tal_tds_fwd checks again)
+        allsplit = tds_stage_allsplit(d, B, T, i, reinterpret_cast<const float*>(static_cast<uintptr_t>(16)), cur_split, force_f32, no_allsplit);
+        const bool last_stage = i == d->n_stages - 1;
+        const bool next_split = !last_stage && d->channels[i + 1] % 32 == 0 && tds_s2_mfma_ok(d, B, i + 1, To, force_f32) &&
+                                tds_stage_allsplit(d, B, T, i + 1, nullptr, true, force_f32, no_allsplit);
+        cur_split = d->depths[i] > 0 && allsplit && next_split;
+        Tc = To;
+    }
+    return allsplit && d->depths[d->n_stages - 1] > 0 && d->channels[d->n_stages] % 32 == 0;
 }
 
 static int tds_fwd_impl(const tal_tds_desc* d, const float* x, const float* x_mean, int B, int64_t T, float* y, void* workspace,
@@ -443,21 +490,8 @@ static int tds_fwd_impl(const tal_tds_desc* d, const float* x, const float* x_me
     // odd widths and the exact mode keep fp32 activations (the kernels below the `else`).
     const bool no_allsplit = opt(OPT_TDS_FP32_ACTIVATIONS) != 0;
     auto stage_len = [&](int i) { int64_t t = T; for (int q = 0; q <= i; ++q) t = conv_out_len(t); return t; };
-    auto s2_mfma_ok = [&](int i, int64_t Tin) {       // stride-2 resize conv of stage i on the matrix cores
-        return !force_f32 && d->down_w_frag[i] && (int64_t)B * conv_out_len(Tin) > 64 &&
-               gconv_f16x3_weight_bytes(d->channels[i], d->channels[i + 1], d->groups, 2) > 0 && gconv_f16x3_fits(Tin, d->channels[i]);
-    };
-    auto stage_allsplit = [&](int i, const float* xin, bool in_split) {
-        if (force_f32 || no_allsplit || i >= d->n_stages || d->depths[i] == 0) return false;
-        const int c = d->channels[i + 1], cin = d->channels[i];
-        const int64_t Tin = i == 0 ? T : stage_len(i - 1), To = conv_out_len(Tin), M = (int64_t)B * To;
-        if (M <= 128 || c % 160 != 0 || c % 32 != 0 || !gconv_f16x3_fits(To, c) || gconv_f16x3_weight_bytes(c, c, d->groups, 1) == 0) return false;
-        for (int j = 0; j < d->depths[i]; ++j)
-            if (!d->blocks[i][j].fc0_w_split || !d->blocks[i][j].fc3_w_split || !d->blocks[i][j].conv_w_frag) return false;
-        // the resize conv must be able to write the split form: the 1 -> 10 channel kernel or a matrix-core kernel
-        if (s2_mfma_ok(i, Tin)) return !in_split || cin % 32 == 0;
-        return !in_split && gconv_s2_can_split(cin, c, d->groups, xin);
-    };
+    auto s2_mfma_ok = [&](int i, int64_t Tin) { return tds_s2_mfma_ok(d, B, i, Tin, force_f32); };
+    auto stage_allsplit = [&](int i, const float* xin, bool in_split) { return tds_stage_allsplit(d, B, T, i, xin, in_split, force_f32, no_allsplit); };
     const float* cur = x;
     bool cur_split = false;
     int ia = -1;
@@ -504,7 +538,8 @@ static int tds_fwd_impl(const tal_tds_desc* d, const float* x, const float* x_me
                 if (rc) return rc;
                 rc = launch_linear_f16x3(x1, bw.fc0_w_split, bw.fc0_b, nullptr, 0.f, 1, M, c, c, h, 1, skws, gemm_splitk_ws_bytes(), s, range_flag);
                 if (rc) return rc;
-                const bool out_split = !last_block || next_split;
+                // (TAL_TDS_OUT_SPLIT: the caller's consumer -- the diarization head's embedding layer -- takes the split form itself)
+                const bool out_split = !last_block || next_split || (last_stage && (d->flags & TAL_TDS_OUT_SPLIT) != 0);
                 rc = launch_linear_f16x3(h, bw.fc3_w_split, bw.fc3_b, x1, bw.resweight, 2, M, c, c, outp, out_split ? 1 : 0, skws,
                                          gemm_splitk_ws_bytes(), s, range_flag, 1);
                 if (rc) return rc;
@@ -716,6 +751,9 @@ extern "C" size_t tal_sd_head_workspace_bytes(int64_t M, int S) {
     return partials > slices ? partials : slices;
 }
 
+static int sd_head_after_feat(int64_t M, int E, const float* w_logit, const float* b_logit, int S, float* feat, float* logits,
+                              int32_t* ids, void* workspace, size_t workspace_bytes, hipStream_t s);
+
 extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_embed, const float* b_embed, int E,
                                const float* w_logit, const float* b_logit, int S, float* feat, float* logits,
                                int32_t* ids, void* workspace, size_t workspace_bytes, void* stream) {
@@ -728,6 +766,29 @@ extern "C" int tal_sd_head_fwd(const float* x, int64_t M, int C, const float* w_
                  ? launch_linear_ws(x, w_embed, b_embed, nullptr, 0.f, 0, M, E, C, feat, reinterpret_cast<float*>(workspace), workspace_bytes, s)
                  : launch_linear(x, w_embed, b_embed, nullptr, 0.f, 0, M, E, C, feat, s);
     if (rc) return rc;
+    return sd_head_after_feat(M, E, w_logit, b_logit, S, feat, logits, ids, workspace, workspace_bytes, s);
+}
+
+// The same head on an encoder output that is still in the hi / lo split form (tal_tds_fwd with TAL_TDS_OUT_SPLIT): the 1440 -> 128
+// embedding layer runs in the fp16x3 form of the dense layers on the split rows and on pre-split weights (tal_split_f16x3_fwd of
+// spk_embed_proj.weight) -- 77 instead of 245 us per hour of audio, max error against float64 3e-6 instead of 9e-6 -- and the
+// last TDS layer never writes an fp32 copy.  Everything behind the features is tal_sd_head_fwd's.  M > 128, C % 32 == 0.
+extern "C" int tal_sd_head_split_fwd(const void* x_split, int64_t M, int C, const void* w_embed_split, const float* b_embed, int E,
+                                     const float* w_logit, const float* b_logit, int S, float* feat, float* logits,
+                                     int32_t* ids, void* workspace, size_t workspace_bytes, void* stream) {
+    TAL_CHECK_ARG(x_split && w_embed_split && w_logit && feat, "tal_sd_head_split_fwd: null pointer");
+    TAL_CHECK_ARG(M > 128 && C > 0 && C % 32 == 0 && E > 0 && S > 0, "tal_sd_head_split_fwd: needs M > 128 rows and C %% 32 == 0 (M=%lld, C=%d)", (long long)M, C);
+    hipStream_t s = (hipStream_t)stream;
+    const bool ws_ok = workspace && workspace_bytes >= tal_sd_head_workspace_bytes(M, S);
+    int rc = launch_linear_f16x3(x_split, w_embed_split, b_embed, nullptr, 0.f, 0, M, E, C, feat, 0, ws_ok ? reinterpret_cast<float*>(workspace) : nullptr,
+                                 ws_ok ? workspace_bytes : 0, s);
+    if (rc) return rc;
+    return sd_head_after_feat(M, E, w_logit, b_logit, S, feat, logits, ids, workspace, workspace_bytes, s);
+}
+
+static int sd_head_after_feat(int64_t M, int E, const float* w_logit, const float* b_logit, int S, float* feat, float* logits,
+                              int32_t* ids, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    int rc;
     if (!logits && !ids) return TAL_OK;
     if (logits) {
         rc = launch_linear(feat, w_logit, b_logit, nullptr, 0.f, 0, M, S, E, logits, s);

@@ -339,22 +339,26 @@ class TDS(nn.Module):
             return ops.tds_forward_tiled(self._descriptor(first, last), x, self.sizes[last], self.tile_frames)
         return ops.tds_forward(self._descriptor(first, last), x, self.sizes[last])
 
-    def forward_then(self, x, tail, x_mean=None):
+    def forward_then(self, x, tail, x_mean=None, split_ok=False):
         """tail(encoder output) with the fp16-range check of the encoder call read AFTER tail's kernels are enqueued (the
         read waits for the stream: done first, it would leave the GPU idle while the host launches the heads).  If the
         check fires, the encoder is re-run on the exact fp32 kernels and tail is applied again.
         x_mean: x is LogMelSpec.forward_unsubtracted's tensor and x_mean its mean (folded into the first resize conv where the
-        kernels can -- ops.tds_premean_ok --, subtracted here otherwise)."""
+        kernels can -- ops.tds_premean_ok --, subtracted here otherwise).
+        split_ok: `tail` is called as tail(y, y_split) and can take the encoder output in the hi / lo split form (y_split True:
+        long inputs, where the last stage runs all-split); after an exact re-run it is called with the fp32 output."""
         N.require_cuda(x, "TDS.forward")
         desc = self._descriptor(0, len(self.sizes) - 1)
         if x_mean is not None and (self._needs_tiles(x, 0, len(self.sizes) - 1) or not ops.tds_premean_ok(desc, x)):
             x, x_mean = ops.subtract_scalar_(x, x_mean), None
         if self._needs_tiles(x, 0, len(self.sizes) - 1):
-            return tail(self.forward_time_major(x))
-        y, chk = ops.tds_forward(desc, x, self.sizes[-1], defer=True, x_mean=x_mean)
-        out = tail(y)
+            y = self.forward_time_major(x)
+            return tail(y, False) if split_ok else tail(y)
+        y, chk = ops.tds_forward(desc, x, self.sizes[-1], defer=True, x_mean=x_mean, out_split=split_ok)
+        out = tail(y, chk.y_split) if split_ok else tail(y)
         if chk.flagged():
-            out = tail(chk.rerun_exact())
+            y = chk.rerun_exact()
+            out = tail(y, False) if split_ok else tail(y)
         return out
 
     def extract(self, x):
@@ -427,14 +431,29 @@ class SDModel(nn.Module):
         """The fused form of tal/baseline/reconcile.py:76-85 (get_speaker_ids): whole-episode
         waveform [1, L] -> (feat [T', 128], ids [T'] int32[, logits]) without materialising
         the [T', 6008] logits unless asked."""
-        def head(enc_out):
+        def head(enc_out, enc_split):
+            # (long inputs: the encoder output arrives in the hi / lo split form and the 1440 -> 128 embedding layer runs in the
+            #  fp16x3 form on it, tal_sd_head_split_fwd; its weight split is cached per parameter version)
             return ops.sd_head(enc_out, self.spk_embed_proj.weight, self.spk_embed_proj.bias, self.spk_logit_proj.weight,
-                               self.spk_logit_proj.bias, want_logits=want_logits, want_ids=True)
+                               self.spk_logit_proj.bias, want_logits=want_logits, want_ids=True, x_split=enc_split,
+                               w_embed_split=self._embed_split() if enc_split else None)
         # (eval: extract_features is the log-mel alone, models.py:430-438; its global-mean subtraction rides in the first resize conv's
         #  bias instead of a pass of its own, TDS.forward_then)
         mel, mean = self.logmelspec.forward_unsubtracted(x_wav)
-        feat, logits, ids = self.encoder.forward_then(mel, head, x_mean=mean)
+        feat, logits, ids = self.encoder.forward_then(mel, head, x_mean=mean, split_ok=self._embed_split() is not None)
         return (feat, ids, logits) if want_logits else (feat, ids)
+
+    def _embed_split(self):
+        """hi / lo fp16 split of spk_embed_proj.weight (None: a weight outside the fp16 range, or a width the fp16x3 layer does not
+        take -- the head then runs its fp32 embedding layer on the fp32 encoder output)."""
+        w = self.spk_embed_proj.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if getattr(self, "_embed_split_key", None) != key:
+            wd = w.detach()
+            ok = w.is_cuda and w.shape[1] % 32 == 0 and bool(torch.isfinite(wd).all()) and float(wd.abs().max()) <= 65504.0
+            self._embed_split_t = ops.split_f16x3(wd.contiguous()) if ok else None
+            self._embed_split_key = key
+        return self._embed_split_t
 
     @torch.no_grad()
     def speaker_ids_stream(self, host_clips):

@@ -215,8 +215,9 @@ class RangeCheck:
     copy, i.e. a wait for the stream), `rerun_exact()` repeats the call on the exact fp32-input kernels into the same
     output tensor.  Deferring the read lets the caller enqueue the kernels that consume the encoder output first."""
 
-    def __init__(self, desc, x, y, ws, nws, off, x_mean=None):
+    def __init__(self, desc, x, y, ws, nws, off, x_mean=None, y_split=False):
         self.desc, self.x, self.y, self.ws, self.nws, self.off, self.x_mean = desc, x, y, ws, nws, off, x_mean
+        self.y_split = y_split          # y holds the hi / lo split form (tds_forward(out_split=True)); an exact re-run writes fp32
 
     def flagged(self):
         if self.desc.flags & N.TAL_TDS_EXACT_F32:
@@ -231,6 +232,7 @@ class RangeCheck:
         exact = N.TdsDesc.from_buffer_copy(self.desc)       # (a copy: the cached descriptor may be in use by another thread's call)
         exact.flags |= N.TAL_TDS_EXACT_F32
         N.check(_tds_call(lib, exact, self.x, self.x_mean, B, T, self.y, self.ws, self.nws), "tal_tds_fwd (exact fp32 re-run)")
+        self.y_split = False
         return self.y
 
 
@@ -245,12 +247,16 @@ def tds_premean_ok(desc, x):
     return bool(N.lib().tal_tds_premean_ok(C.byref(desc), N.ptr(x)))
 
 
-def tds_forward(desc, x, c_out, check_range=True, defer=False, x_mean=None):
+def tds_forward(desc, x, c_out, check_range=True, defer=False, x_mean=None, out_split=False):
     """x [B, T, C0] -> [B, T', C_last] through tal_tds_fwd (whole encoder, one C call).
 
     x_mean (device tensor [1]): x is the log-mel before LogMelSpec's global-mean subtraction and x_mean the scalar to subtract
     (logmel(..., subtract_mean=False, return_stats=True)); the subtraction is folded into the first resize conv's bias
     (tal_tds_premean_fwd).  Only where tds_premean_ok(desc, x).
+
+    out_split=True (with defer=True): the caller's consumer takes the hi / lo split form (sd_head(x_split=True)); where the last
+    stage runs all-split the output tensor then holds that form -- same shape and bytes, NOT fp32 values -- and the returned
+    RangeCheck says so (`.y_split`).
 
     fp16-range guard: the long-input layers run in the fp16x3 form (fp32 values as two fp16 halves), which needs
     |activation| <= 65504.  The kernels raise a status word when a value was out of range; the call is then repeated
@@ -265,8 +271,16 @@ def tds_forward(desc, x, c_out, check_range=True, defer=False, x_mean=None):
     y = torch.empty(B, t_out, c_out, dtype=torch.float32, device=x.device)
     nws = lib.tal_tds_workspace_bytes(C.byref(desc), B, T)
     ws = _ws(nws, x.device)
+    y_split = False
+    if out_split:
+        if not defer:
+            raise N.NativeError("tds_forward: out_split needs defer=True (the caller must look at RangeCheck.y_split)")
+        asked = N.TdsDesc.from_buffer_copy(desc)
+        asked.flags |= N.TAL_TDS_OUT_SPLIT
+        if lib.tal_tds_out_split(C.byref(asked), B, T):
+            desc, y_split = asked, True
     N.check(_tds_call(lib, desc, x, x_mean, B, T, y, ws, nws), "tal_tds_fwd")
-    chk = RangeCheck(desc, x, y, ws, nws, lib.tal_tds_status_offset(C.byref(desc), B, T), x_mean)
+    chk = RangeCheck(desc, x, y, ws, nws, lib.tal_tds_status_offset(C.byref(desc), B, T), x_mean, y_split)
     if defer:
         return y, chk
     if check_range and chk.flagged():
@@ -305,8 +319,10 @@ def tds_forward_tiled(desc, x, c_out, out_tile, check_range=True):
 
 
 # ------------------------------------------------------------------ diarization head
-def sd_head(x, w_embed, b_embed, w_logit, b_logit, want_logits=True, want_ids=True):
-    """x [..., C] -> (feat [..., E], logits [..., S] | None, ids [...] int32 | None)."""
+def sd_head(x, w_embed, b_embed, w_logit, b_logit, want_logits=True, want_ids=True, x_split=False, w_embed_split=None):
+    """x [..., C] -> (feat [..., E], logits [..., S] | None, ids [...] int32 | None).
+    x_split=True: x holds the hi / lo split form (tds_forward(out_split=True) with RangeCheck.y_split) and w_embed_split the
+    split of w_embed (split_f16x3): the embedding layer runs in the fp16x3 form (tal_sd_head_split_fwd)."""
     lib = N.lib()
     x = _f32c(x, "sd_head")
     Cc = x.shape[-1]
@@ -318,6 +334,16 @@ def sd_head(x, w_embed, b_embed, w_logit, b_logit, want_logits=True, want_ids=Tr
     ids = torch.empty(x.shape[:-1], dtype=torch.int32, device=dev) if want_ids else None
     nws = lib.tal_sd_head_workspace_bytes(M, S) if (want_ids and not want_logits) else 0
     ws = _ws(nws, dev)
+    if x_split:
+        if w_embed_split is None:
+            raise N.NativeError("sd_head: x_split needs w_embed_split (ops.split_f16x3 of the embedding weight)")
+        if not nws:
+            nws = lib.tal_sd_head_workspace_bytes(M, S)
+            ws = _ws(nws, dev)
+        N.check(lib.tal_sd_head_split_fwd(N.ptr(x), M, Cc, N.ptr(w_embed_split), N.ptr(b_embed), E,
+                                          N.ptr(_f32c(w_logit, "w")), N.ptr(b_logit), S, N.ptr(feat), N.ptr(logits),
+                                          N.ptr(ids), N.ptr(ws), nws, N.stream_handle()), "tal_sd_head_split_fwd")
+        return feat, logits, ids
     N.check(lib.tal_sd_head_fwd(N.ptr(x), M, Cc, N.ptr(_f32c(w_embed, "w")), N.ptr(b_embed), E,
                                 N.ptr(_f32c(w_logit, "w")), N.ptr(b_logit), S, N.ptr(feat), N.ptr(logits),
                                 N.ptr(ids), N.ptr(ws), nws, N.stream_handle()), "tal_sd_head_fwd")

@@ -672,6 +672,48 @@ def test_mean_folded_into_the_first_resize_conv(sd_model, name):
         assert rc == -1 and b"mean-folding" in lib.tal_last_error()
 
 
+@pytest.mark.parametrize("name", ["sd_30s", "sd_5min", "sd_b2_ragged"])
+def test_head_on_the_split_encoder_output(sd_model, name):
+    """SDModel.speaker_ids leaves the encoder output of a long input in the hi / lo split form (TAL_TDS_OUT_SPLIT: the last dense
+    layer writes no fp32 copy) and runs the head's 1440 -> 128 embedding layer on it in the fp16x3 form (tal_sd_head_split_fwd).
+    Against the fp32 output + fp32 embedding layer: the split tensor decodes to the fp32 one within the form's 22 mantissa bits,
+    features within 1e-4, speaker ids identical and equal to the reference's; with logits requested the same; an exact-mode
+    descriptor never yields the split form."""
+    import ctypes as C
+    from tal_asrd_amd import synth, ops, _native as N
+    g = golden(name)
+    B, L = int(g["batch"]), int(g["audio_len"])
+    lens = g["audio_lens"].tolist() if name == "sd_b2_ragged" else None
+    audio = torch.from_numpy(synth.synth_audio_batch(B, L, int(g["audio_seed"]), lens=lens)).to(dev())
+    enc = sd_model.encoder
+    heads = (sd_model.spk_embed_proj.weight, sd_model.spk_embed_proj.bias, sd_model.spk_logit_proj.weight, sd_model.spk_logit_proj.bias)
+    with torch.no_grad():
+        mel = sd_model.extract_features(audio)
+        desc = enc._descriptor(0, len(enc.sizes) - 1)
+        y32 = ops.tds_forward(desc, mel, enc.sizes[-1])
+        ysp, chk = ops.tds_forward(desc, mel, enc.sizes[-1], defer=True, out_split=True)
+        assert chk.y_split and not chk.flagged()
+        Cc = enc.sizes[-1]
+        h = ysp.view(torch.float16).view(-1, Cc // 32, 2, 32).float()
+        dec = (h[:, :, 0] + h[:, :, 1] / 2048.0).reshape(y32.shape)
+        np.testing.assert_allclose(dec.cpu().numpy(), y32.cpu().numpy(), atol=2e-6 * float(y32.abs().max()) + 1e-7, rtol=0)
+        f32, l32, i32 = ops.sd_head(y32, *heads, want_logits=True, want_ids=True)
+        fsp, lsp, isp = ops.sd_head(ysp, *heads, want_logits=True, want_ids=True, x_split=True, w_embed_split=sd_model._embed_split())
+        np.testing.assert_allclose(fsp.cpu().numpy(), f32.cpu().numpy(), atol=1e-4, rtol=0)
+        np.testing.assert_allclose(lsp.cpu().numpy(), l32.cpu().numpy(), atol=LOGIT_TOL, rtol=0)
+        np.testing.assert_array_equal(isp.cpu().numpy(), i32.cpu().numpy())
+        _, _, ifast = ops.sd_head(ysp, *heads, want_logits=False, want_ids=True, x_split=True, w_embed_split=sd_model._embed_split())
+        np.testing.assert_array_equal(ifast.cpu().numpy(), g["ids"])
+        feat, ids, logits = sd_model.speaker_ids(audio, want_logits=True)
+        np.testing.assert_array_equal(ids.cpu().numpy(), g["ids"])
+        np.testing.assert_allclose(logits[:, g["logit_rows"]].cpu().numpy(), g["logit_sample"], atol=LOGIT_TOL, rtol=0)
+        exact = N.TdsDesc.from_buffer_copy(desc)
+        exact.flags |= N.TAL_TDS_EXACT_F32 | N.TAL_TDS_OUT_SPLIT
+        assert N.lib().tal_tds_out_split(C.byref(exact), B, mel.shape[1]) == 0
+        _, chk2 = ops.tds_forward(exact, mel, enc.sizes[-1], defer=True, out_split=True)
+        assert not chk2.y_split
+
+
 @pytest.mark.parametrize("seconds", [12, 300])
 def test_the_sd_path_can_be_captured_as_a_hip_graph(sd_model, seconds):
     """The C-ABI calls of the SD path (log-mel, tal_tds_fwd, the head) issue nothing but kernel launches on the caller's stream,
@@ -689,8 +731,8 @@ def test_the_sd_path_can_be_captured_as_a_hip_graph(sd_model, seconds):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             mel, mean = sd_model.logmelspec.forward_unsubtracted(static_x)       # (speaker_ids' own sequence: the mean rides in the first conv's bias)
-            y, chk = ops.tds_forward(enc._descriptor(0, len(enc.sizes) - 1), mel, enc.sizes[-1], defer=True, x_mean=mean)
-            feat, _, ids = ops.sd_head(y, *heads, want_logits=False, want_ids=True)
+            y, chk = ops.tds_forward(enc._descriptor(0, len(enc.sizes) - 1), mel, enc.sizes[-1], defer=True, x_mean=mean, out_split=True)
+            feat, _, ids = ops.sd_head(y, *heads, want_logits=False, want_ids=True, x_split=chk.y_split, w_embed_split=sd_model._embed_split())
         for a in clips + clips[:1]:
             for _ in range(20):
                 f0, i0 = sd_model.speaker_ids(a)            # eager traffic between replays (what exposed the stale memset node)

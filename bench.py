@@ -506,11 +506,9 @@ def main():
             mean = D.allreduce_logmel_stats(st) if reduce_mean else (st[0] / st[1]).to(torch.float32).reshape(1)
             out = {}
             if batch is not None:
-                ops.subtract_scalar_(mel, mean)
-                enc = model.encode_features(mel, None)
-                feat, _, ids = ops.sd_head(enc["encoder_out"], model.spk_embed_proj.weight, model.spk_embed_proj.bias,
-                                           model.spk_logit_proj.weight, model.spk_logit_proj.bias, want_logits=False,
-                                           want_ids=True)
+                # (the call's mean rides in the first resize conv's bias, the encoder output goes to the head in the split form:
+                #  SDModel.speaker_ids' own sequence, with the mean of the WHOLE call instead of this rank's share)
+                feat, ids = model.speaker_ids_from_logmel(mel, mean)
                 for k, i in enumerate(idx):
                     out[i] = D.pack_feat_ids(feat[k], ids[k])
             return out

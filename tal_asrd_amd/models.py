@@ -431,15 +431,21 @@ class SDModel(nn.Module):
         """The fused form of tal/baseline/reconcile.py:76-85 (get_speaker_ids): whole-episode
         waveform [1, L] -> (feat [T', 128], ids [T'] int32[, logits]) without materialising
         the [T', 6008] logits unless asked."""
+        mel, mean = self.logmelspec.forward_unsubtracted(x_wav)
+        return self.speaker_ids_from_logmel(mel, mean, want_logits=want_logits)
+
+    @torch.no_grad()
+    def speaker_ids_from_logmel(self, mel, mean, want_logits=False):
+        """The same from the log-mel BEFORE its mean subtraction and the scalar to subtract (a device tensor [1]): for callers
+        that own the mean -- a reference call whose batch is spread over several GPUs subtracts the mean of the WHOLE call
+        (tal/asr/models.py:52), i.e. an all-reduced (sum, count), distributed.allreduce_logmel_stats.  The subtraction rides in the
+        first resize conv's bias (eval: extract_features is the log-mel alone, models.py:430-438)."""
         def head(enc_out, enc_split):
             # (long inputs: the encoder output arrives in the hi / lo split form and the 1440 -> 128 embedding layer runs in the
             #  fp16x3 form on it, tal_sd_head_split_fwd; its weight split is cached per parameter version)
             return ops.sd_head(enc_out, self.spk_embed_proj.weight, self.spk_embed_proj.bias, self.spk_logit_proj.weight,
                                self.spk_logit_proj.bias, want_logits=want_logits, want_ids=True, x_split=enc_split,
                                w_embed_split=self._embed_split() if enc_split else None)
-        # (eval: extract_features is the log-mel alone, models.py:430-438; its global-mean subtraction rides in the first resize conv's
-        #  bias instead of a pass of its own, TDS.forward_then)
-        mel, mean = self.logmelspec.forward_unsubtracted(x_wav)
         feat, logits, ids = self.encoder.forward_then(mel, head, x_mean=mean, split_ok=self._embed_split() is not None)
         return (feat, ids, logits) if want_logits else (feat, ids)
 

@@ -41,10 +41,7 @@ def main():
         mel, _, st = ops.logmel(model.logmelspec.plan(), batch, eps=model.logmelspec.eps, subtract_mean=False, return_stats=True)
         st = st.cpu()
         mean = D.allreduce_logmel_stats(st).to(dev)
-        ops.subtract_scalar_(mel, mean)
-        enc = model.encode_features(mel, None)
-        feat, _, ids = ops.sd_head(enc["encoder_out"], model.spk_embed_proj.weight, model.spk_embed_proj.bias,
-                                   model.spk_logit_proj.weight, model.spk_logit_proj.bias, want_logits=False, want_ids=True)
+        feat, ids = model.speaker_ids_from_logmel(mel, mean)      # (bench.py --workload segments' own sequence)
         feat_l = {i: feat[k].cpu() for k, i in enumerate(mine)}
         ids_l = {i: ids[k].cpu() for k, i in enumerate(mine)}
         got_feat = D.gather_segments(feat_l, n_seg, dst=0)

@@ -440,7 +440,7 @@ class SDModel(nn.Module):
         that own the mean -- a reference call whose batch is spread over several GPUs subtracts the mean of the WHOLE call
         (tal/asr/models.py:52), i.e. an all-reduced (sum, count), distributed.allreduce_logmel_stats.  The subtraction rides in the
         first resize conv's bias (eval: extract_features is the log-mel alone, models.py:430-438)."""
-        def head(enc_out, enc_split):
+        def head(enc_out, enc_split=False):
             # (long inputs: the encoder output arrives in the hi / lo split form and the 1440 -> 128 embedding layer runs in the
             #  fp16x3 form on it, tal_sd_head_split_fwd; its weight split is cached per parameter version)
             return ops.sd_head(enc_out, self.spk_embed_proj.weight, self.spk_embed_proj.bias, self.spk_logit_proj.weight,

@@ -714,6 +714,34 @@ def test_head_on_the_split_encoder_output(sd_model, name):
         assert not chk2.y_split
 
 
+def test_an_embedding_weight_outside_the_fp16_range_keeps_the_fp32_head(sd_model):
+    """SDModel._embed_split() is None for an embedding weight the hi / lo split cannot carry (|w| > 65504): speaker_ids then
+    asks for the fp32 encoder output and runs the fp32 embedding layer -- same ids and features as ops.sd_head on the fp32 path;
+    the cached split follows the parameter's version (restoring the weight brings the split head back)."""
+    from tal_asrd_amd import synth, ops
+    audio = torch.from_numpy(synth.synth_audio_batch(1, 160000, 77)).to(dev())
+    w = sd_model.spk_embed_proj.weight
+    keep = w.detach().clone()
+    with torch.no_grad():
+        feat0, ids0 = sd_model.speaker_ids(audio)
+        assert sd_model._embed_split() is not None
+        try:
+            w[0, 0] = 1.0e5
+            assert sd_model._embed_split() is None
+            feat, ids = sd_model.speaker_ids(audio)
+            mel = sd_model.extract_features(audio)
+            enc = sd_model.encode_features(mel, None)["encoder_out"]
+            f32, _, i32 = ops.sd_head(enc, w, sd_model.spk_embed_proj.bias, sd_model.spk_logit_proj.weight,
+                                      sd_model.spk_logit_proj.bias, want_logits=False, want_ids=True)
+            np.testing.assert_array_equal(ids.cpu().numpy(), i32.cpu().numpy())
+            np.testing.assert_allclose(feat.cpu().numpy(), f32.cpu().numpy(), atol=1e-4 * float(f32.abs().max()), rtol=0)
+        finally:
+            w.copy_(keep)
+        assert sd_model._embed_split() is not None
+        feat1, ids1 = sd_model.speaker_ids(audio)
+        assert torch.equal(ids1, ids0) and torch.equal(feat1, feat0)
+
+
 @pytest.mark.parametrize("seconds", [12, 300])
 def test_the_sd_path_can_be_captured_as_a_hip_graph(sd_model, seconds):
     """The C-ABI calls of the SD path (log-mel, tal_tds_fwd, the head) issue nothing but kernel launches on the caller's stream,

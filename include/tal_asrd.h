@@ -44,7 +44,7 @@ extern "C" {
 #define TAL_MAX_STAGES 4
 #define TAL_MAX_DEPTH 8
 
-int tal_version(void);          /* 420 = 0.4.2 */
+int tal_version(void);          /* 430 = 0.4.3 */
 const char* tal_last_error(void);
 
 /* Process-wide behaviour switches.  The library never reads the environment: which kernels a caller gets depends on its
@@ -62,6 +62,7 @@ const char* tal_last_error(void);
  *                         step's phases behind counter barriers and run the launch chain's own kernel bodies: bit-identical results;
  *                         measured SLOWER than the chain, profiles/r5_decode_persistent_step.txt -- kept as a measurement switch)
  *   decode_persist_wgs    workgroups per session of that launch (default 32)
+ *   logmel_mfma           1: the log-mel front-end as the float64 matrix-core DFT instead of the fast transform (see tal_logmel_fwd)
  *   gemm_s64_below        fp16x3 relu / residual layers run on 64 x 80 tiles without K slices while those tiles number
  *                         at most this many per CU (default 2; 0: never)
  *   gconv_short_below     grouped convs use 64-step tiles while the long tiles would give a CU fewer workgroups than
@@ -78,13 +79,19 @@ const char* tal_option_name(int index);
  * ------------------------------------------------------------------ */
 /* frames for L samples: T = 1 + L / 160 (center=True STFT). */
 int64_t tal_logmel_num_frames(int64_t L);
-/* bytes of the device-resident plan (window-folded DFT basis + sparse mel filters). */
+/* bytes of the device-resident plan (window, twiddles of the 400 = 20 x 20 transform, sparse mel filters; the window-folded
+ * DFT basis of the matrix form). */
 size_t tal_logmel_plan_bytes(void);
 /* Build the plan from the module's buffers: window [400] (periodic Hann) and
  * fb [201, 80] (HTK triangles), the two torchaudio buffers reference
  * checkpoints carry. */
 int tal_logmel_plan_init(const float* window, const float* fb, void* plan, void* stream);
 size_t tal_logmel_workspace_bytes(int B, int64_t L);
+/* Two forms of the same arithmetic (window . frame, 400-point DFT, power: all float64; mel projection, log: float32):
+ *   default        a fast transform on the float64 vector ALU: two real frames per complex transform, 400 = 20 x 20 with a
+ *                  20-point prime-factor transform per lane (csrc/dft20.h); any window, applied in the time domain as given
+ *   logmel_mfma=1  the float64 matrix-core DFT of rounds 1-4 (a symmetric window folded and symmetrised to 4e-7; 2.4x slower)
+ * Also taken when the workspace is smaller than tal_logmel_workspace_bytes says (sized by an older header). */
 /* audio [B, L] -> out [B, T, 80].  If subtract_mean != 0 the global mean of the
  * whole [B,T,80] tensor (models.py:52) is subtracted in place.  The mean that
  * was (or would be) subtracted is written to *mean_out (device float, may be NULL).

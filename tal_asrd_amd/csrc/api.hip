@@ -20,8 +20,8 @@ void set_error(const char* fmt, ...) {
 // ---- behaviour switches (tal_set_option) ---------------------------------------------------
 static const char* const g_opt_names[OPT_COUNT] = {
     "tds_exact_f32", "tds_fp32_activations", "gconv_fuse_split", "gconv_c1_generic", "head_no_astationary", "gemm_global_loads",
-    "gemm_no_splitk4", "gemm_no_glds", "gemm_no_splitk_tail", "gemm_no_w64", "logmel_no_fold", "decode_no_small", "decode_small_rows", "gemm_no_row_split", "gemm_no_n96", "gemm_s64_below", "gconv_short_below", "gconv_no_shift18", "gconv_grid_xyz", "gemm_w64_stagger", "gemm_s64_order", "decode_wide_gemm", "gemm_s64_rows", "decode_persist", "decode_persist_wgs"};
-static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {256}, {0}, {0}, {2}, {4}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {32}};
+    "gemm_no_splitk4", "gemm_no_glds", "gemm_no_splitk_tail", "gemm_no_w64", "logmel_no_fold", "decode_no_small", "decode_small_rows", "gemm_no_row_split", "gemm_no_n96", "gemm_s64_below", "gconv_short_below", "gconv_no_shift18", "gconv_grid_xyz", "gemm_w64_stagger", "gemm_s64_order", "decode_wide_gemm", "gemm_s64_rows", "decode_persist", "decode_persist_wgs", "logmel_mfma"};
+static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {256}, {0}, {0}, {2}, {4}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {32}, {0}};
 int opt(Option o) { return g_opt[o].load(std::memory_order_relaxed); }
 
 int device_cus() {
@@ -187,7 +187,7 @@ static int64_t conv_out_len(int64_t t) { return t < 21 ? 0 : (t - 21) / 2 + 1; }
 
 using namespace tal;
 
-extern "C" int tal_version(void) { return 420; /* 0.4.2: TAL_TDS_OUT_SPLIT, tal_tds_out_split, tal_sd_head_split_fwd; 0.4.1: tal_tds_premean_fwd / tal_tds_premean_ok; 0.4.0: tal_greedy_ctx grew (k_pitch, episode-wide K | V table), merged decode steps, tal_unaligned_*, tal_logmel_f16_fwd; 0.3.0: tal_set_option */ }
+extern "C" int tal_version(void) { return 430; /* 0.4.3: log-mel as a fast transform (option logmel_mfma: the matrix form), the plan grew; 0.4.2: TAL_TDS_OUT_SPLIT, tal_tds_out_split, tal_sd_head_split_fwd; 0.4.1: tal_tds_premean_fwd / tal_tds_premean_ok; 0.4.0: tal_greedy_ctx grew (k_pitch, episode-wide K | V table), merged decode steps, tal_unaligned_*, tal_logmel_f16_fwd; 0.3.0: tal_set_option */ }
 
 // Host-side helper of the decode loop (no device work): ngram_repeat_mask(row, n).sum() of tal/asr/util.py:5-17 -- the number
 // of positions covered by an n-gram that already occurred earlier in the row; like the reference, n-gram starts run to

@@ -121,6 +121,7 @@ enum Option {
     OPT_GEMM_S64_ROWS,            // short-input dense launches: 0 = 32-row tiles (two waves) while they number at most one per CU, 1 = always 64 rows, 2 = always 32
     OPT_DECODE_PERSIST,           // decode steps as ONE launch (csrc/decode_persist.hip) where the step's shapes allow: 0 = launch chain, 1 = one launch
     OPT_DECODE_PERSIST_WGS,       // workgroups per session of the one-launch step (default 32)
+    OPT_LOGMEL_MFMA,              // log-mel as the float64 matrix-core DFT of rounds 1-4 instead of the fast transform on the vector ALU
     OPT_COUNT
 };
 int opt(Option o);

@@ -2,17 +2,19 @@
 // 0.4.0 MelSpectrogram semantics restated in SURVEY.md section 8c:
 //   reflect-pad 200 | frames of 400 @ hop 160 | periodic Hann | 400-point one-sided DFT |
 //   re^2+im^2 | 201x80 HTK mel filterbank | log(. + eps) | minus one global scalar mean.
+// Window product, DFT and power in float64 (near-silent frames have mel power within a few 1e-6 of eps, where an fp32 DFT is
+// off by up to 1e-3 in the log domain -- measured; the reference's own fp32 FFT is off by 2e-4 from the float64 truth).
 //
-// One workgroup = 32 consecutive frames of one batch item.  The 5360 samples the frames
+// Two forms (tal_logmel_fwd picks; include/tal_asrd.h):
+//   logmel_fft_kernel  (default, round 5) a fast transform on the float64 VECTOR ALU, further down: 0.33 ms per hour of audio
+//   logmel_kernel      (rounds 1-4, option logmel_mfma) the matrix-core form below: 0.81 ms per hour of audio
+//
+// The matrix form: one workgroup = 32 consecutive frames of one batch item.  The 5360 samples the frames
 // span are read once, coalesced, into LDS (reflect indexing resolved at load time; one pad
 // word per hop keeps the frame-strided MFMA operand reads conflict-free).  The windowed DFT
 // is a [32 x 400] . [400 x (re|im) x 208] contraction on the FP64 matrix cores
 // (v_mfma_f64_16x16x4_f64) against a Hann-folded float64 twiddle table that stays L2-resident
-// (1.3 MB): no per-sample window multiply, no bit-reversal traffic, and -- the reason for
-// fp64 -- no fp32 round-off in the 400-term sums.  Near-silent frames have mel power within
-// a few 1e-6 of eps, where an fp32 matrix-DFT is off by up to 1e-3 in the log domain (measured;
-// the reference's fp32 FFT is off by 2e-4 from the float64 truth, this kernel by ~1e-7).  The
-// front-end is ~2 % of the path's time, so fp64 costs nothing visible.  re/im of a bin land
+// (1.3 MB): no per-sample window multiply, no bit-reversal traffic.  re/im of a bin land
 // in the same lane of two accumulators, so the power spectrum is formed in registers.  The (sparse, triangular) mel
 // projection, the log and the partial sum for the global mean are done from an LDS copy of
 // the power tile; the output is written once, coalesced, as [B, T, 80].
@@ -22,6 +24,7 @@
 #include <vector>
 
 #include "common.h"
+#include "dft20.h"
 
 namespace tal {
 
@@ -48,8 +51,15 @@ struct LogmelPlan {
     int mel_lo[NMEL];
     int mel_cnt[NMEL];
     alignas(16) float mel_w[NMEL * MAXW];      // read as 16-byte vectors by the short-input kernel
+    // the 400 = 20 x 20 transform (logmel_fft_kernel): twiddles exp(-2 pi i n2 k1 / 400) as [n2][k1][re|im], and the window as given
+    alignas(16) double tw[20 * 20 * 2];
+    float win[NFFT];
+    alignas(16) float mel_wc[768];             // the filters' weights back to back, each filter zero-padded to a multiple of 4 (mel_off[m] ..); mel_compact = 0 when they do not fit
+    int mel_off[NMEL];
+    int mel_compact;
 };
 static_assert(offsetof(LogmelPlan, mel_w) % 16 == 0, "LogmelPlan::mel_w must be 16-byte aligned");
+static_assert(offsetof(LogmelPlan, tw) % 16 == 0 && offsetof(LogmelPlan, mel_wc) % 16 == 0, "LogmelPlan::tw / mel_wc must be 16-byte aligned");
 
 // AT: element type of the waveform -- float, or _Float16 for callers that hand over `.half()` audio as the reference's
 // GPU-era call sites do (tal/asr/system.py:92,285, tal/baseline/reconcile.py:78); the samples are widened while they are
@@ -246,6 +256,295 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const LogmelPlan* __rest
     if (tid == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same front-end as a FAST transform on the float64 vector ALU (round 5).  The matrix form above spends 46.6 k float64
+// multiply-adds per frame (728 MFMAs per 16 frames) and is bound by the fp64 matrix rate -- which on this chip is the fp64 VECTOR
+// rate (78.6 TFLOP/s both), so an O(N log N) transform on the vector ALU wins by its operation count alone: ~7 k operations per frame.
+//   * two real frames a, b ride one complex transform: z = w (a + i b), A[k] = (Z[k] + conj Z[400-k]) / 2, B[k] = (Z[k] - conj Z[400-k]) / 2i
+//   * 400 = 20 x 20 (n = 20 n1 + n2, k = k1 + 20 k2): a lane holds one 20-point transform in registers (dft20.h: prime-factor
+//     4 x 5, no inner twiddles); pass 1 = 20 lanes per frame pair (one per n2) transform over n1 and multiply by W400^(n2 k1),
+//     the [k1][n2] hand-over goes through LDS (pitch 21: the strided reads of pass 2 hit 16 different 16-byte bank groups),
+//     pass 2 = 20 lanes per pair (one per k1) transform over n2 and write Z[k1 + 20 k2] back over the same buffer
+//   * window applied in the time domain (any window: no symmetry needed), every product and sum in float64 as before
+//   * mel projection: a wave takes 64 / frames mel filters at a time, lane = (filter, frame), so the lanes of a filter run the same
+//     number of steps (lane = (frame, filter) made every wave wait for its widest filter: 48 steps for 5 on average); the filter
+//     weights come from a compact copy in LDS; results are staged in LDS and written out coalesced.
+// One workgroup = NP frame pairs on 128 threads (120 of them transforming); 53 KB of LDS: three workgroups per CU.
+constexpr int YP = 21;
+// (ablation build -DLM_TIMELINE: workgroup 100 stamps the 100 MHz wall clock after every stage of its first 8 blocks;
+//  scripts/r5_logmel_timeline.py reads them through tal_debug_logmel_timeline.  Not part of the product library.)
+#ifdef LM_TIMELINE
+__device__ unsigned long long g_lm_tl[8 * 8];
+#define LM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 100 && lm_it < 8) g_lm_tl[lm_it * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define LM_STAMP(i) do { } while (0)
+#endif
+constexpr int FFT_FB = 12;                        // frames per workgroup
+constexpr int MELC = 768;                         // capacity of the compact filter table (the filters' supports, each padded to a multiple of 4 with zeros; 402 + padding for the HTK bank)
+
+template <int NP, typename AT>
+__global__ __launch_bounds__(128, 2) void logmel_fft_kernel(const LogmelPlan* __restrict__ plan, const AT* __restrict__ audio, int64_t L,
+                                                         int64_t T, int64_t nblk, int64_t total, float eps, float* __restrict__ out,
+                                                         double* __restrict__ partial) {
+    constexpr int NTH = 128;
+    constexpr int FBK = 2 * NP, NS = (FBK - 1) * HOP + NFFT;
+    constexpr int SP = NS > FBK * PLD ? NS : FBK * PLD;
+    static_assert(NP * 20 <= NTH && FBK * NMEL * 4 <= NP * 20 * YP * 16, "lane roles / staging buffer");
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    __shared__ float sp[SP];                          // the samples, then (from the power stage on) the power tile
+    __shared__ f64x2 Yb[NP * 20 * YP];                // [pair][k1][n2] hand-over, then Z[pair][k], then the staged outputs
+    __shared__ __attribute__((aligned(16))) float melw[MELC];
+    __shared__ int mellc[NMEL];                       // lo | cnt << 8 | off << 16
+    __shared__ double red[NTH / 64];
+    float* samp = sp;
+    float* P = sp;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int pr = tid / 20, q = tid - pr * 20;       // frame pair; n2 in pass 1, k1 in pass 2
+    const bool act = pr < NP;
+    constexpr int NIT = (NS + NTH - 1) / NTH;
+    AT sv[NIT];
+    // the samples of block `blk` (flattened over the batch), reflect indexing resolved here
+    auto request = [&](int64_t blk) {
+        const int64_t b = blk / nblk;
+        const int64_t p0 = (blk - b * nblk) * FBK * HOP - NFFT / 2;
+        const AT* ab = audio + b * L;
+        if (p0 >= 0 && p0 + NIT * NTH <= L) {        // interior block (all but the first and the last few of an item): no index arithmetic
+            const AT* src = ab + p0 + tid;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) sv[it] = src[it * NTH];
+            return;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int64_t p = p0 + tid + it * NTH;
+            if (p < 0) p = -p;                       // reflect (no edge repeat), as torch.stft pad_mode='reflect'
+            if (p >= L) p = 2 * (L - 1) - p;
+            p = p < 0 ? 0 : (p >= L ? L - 1 : p);    // frames past T (tail block) only
+            sv[it] = ab[p];
+        }
+    };
+    int64_t blk = blockIdx.x;
+    request(blk);
+    // loop-invariant operands: the lane's twiddles and window taps (registers), the filter table (LDS)
+    // (the 19 twiddles W400^(q k1) of a lane are rebuilt per block from W^q and W^4q -- four chains of at most four products --
+    //  instead of living in 76 registers across the loop: one wave more per SIMD)
+    f64x2 tw1, tw4;
+    const float* wp = plan->win + (act ? q : 0);      // the lane's 20 window taps are re-read per block (cache-resident; 20 registers less across the loop)
+    {
+        const f64x2* twp = reinterpret_cast<const f64x2*>(plan->tw) + (act ? q : 0) * 20;
+        tw1 = twp[1];
+        tw4 = twp[4];
+    }
+    const bool compact = plan->mel_compact != 0;
+    {
+        for (int i = tid; i < MELC / 4; i += NTH) reinterpret_cast<f32x4*>(melw)[i] = reinterpret_cast<const f32x4*>(plan->mel_wc)[i];
+        if (tid < NMEL) mellc[tid] = plan->mel_lo[tid] | (plan->mel_cnt[tid] << 8) | (plan->mel_off[tid] << 16);
+    }
+    // mel stage roles: a wave takes MPW filters at a time, lane = (filter, frame); the lane's NPASS filters never change
+    constexpr int MPW = 64 / FBK, NPASS = (NMEL + (NTH / 64) * MPW - 1) / ((NTH / 64) * MPW);
+    const int mf = lane / FBK, fr = lane - mf * FBK;
+    __syncthreads();                                  // (the filter table is in LDS)
+    double local = 0.0;
+    int lm_it = 0;
+    while (blk < total) {
+        const int64_t b = blk / nblk;
+        const int64_t f0 = (blk - b * nblk) * FBK;
+        LM_STAMP(0);
+        float wn[20];
+#pragma unroll
+        for (int i = 0; i < 20; ++i) wn[i] = wp[20 * i];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * NTH;
+            if (i < NS) samp[i] = (float)sv[it];
+        }
+        __syncthreads();
+        LM_STAMP(1);
+        const int64_t nxt = blk + gridDim.x;
+
+        double xr[20], xi[20], yr[20], yi[20];
+        if (act) {
+            const float* sa = samp + (2 * pr) * HOP + q;
+            const float* sb = sa + HOP;
+#pragma unroll
+            for (int n1 = 0; n1 < 20; ++n1) {
+                const double wv = (double)wn[n1];
+                xr[n1] = wv * (double)sa[20 * n1];
+                xi[n1] = wv * (double)sb[20 * n1];
+            }
+            dft20(xr, xi, yr, yi);
+            f64x2* yo = Yb + pr * 20 * YP + q;
+            f64x2 t[4];                                   // W^(q (4 a + c)), c = 0..3, advanced over a by W^4q
+            // (opaque to the optimiser: the products are loop-invariant, and hoisted out of the block loop they are 76 live registers)
+            asm volatile("" : "+v"(tw1.x), "+v"(tw1.y), "+v"(tw4.x), "+v"(tw4.y));
+            t[0] = f64x2{1.0, 0.0};
+            t[1] = tw1;
+            t[2] = f64x2{tw1.x * tw1.x - tw1.y * tw1.y, 2.0 * tw1.x * tw1.y};
+            t[3] = f64x2{t[2].x * tw1.x - t[2].y * tw1.y, t[2].x * tw1.y + t[2].y * tw1.x};
+#pragma unroll
+            for (int a = 0; a < 5; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k1 = 4 * a + c;
+                    yo[k1 * YP] = f64x2{yr[k1] * t[c].x - yi[k1] * t[c].y, yr[k1] * t[c].y + yi[k1] * t[c].x};
+                    if (a < 4) t[c] = f64x2{t[c].x * tw4.x - t[c].y * tw4.y, t[c].x * tw4.y + t[c].y * tw4.x};
+                }
+        }
+        __syncthreads();
+        LM_STAMP(2);
+        if (nxt < total) request(nxt);               // the next block's samples: in flight under the rest of this block (not before pass 1: its registers)
+        if (act) {
+            const f64x2* yin = Yb + (pr * 20 + q) * YP;
+#pragma unroll
+            for (int n2 = 0; n2 < 20; ++n2) {
+                const f64x2 v = yin[n2];
+                xr[n2] = v.x;
+                xi[n2] = v.y;
+            }
+            dft20(xr, xi, yr, yi);
+        }
+        __syncthreads();                                  // every row is in registers: the buffer becomes Z[k], natural order
+        if (act) {
+            f64x2* zo = Yb + pr * 20 * YP + q;
+#pragma unroll
+            for (int k2 = 0; k2 < 20; ++k2) zo[20 * k2] = f64x2{yr[k2], yi[k2]};
+        }
+        __syncthreads();                                  // (the samples are dead since pass 1: their buffer takes the power tile)
+        LM_STAMP(3);
+        if (tid < FBK * 8) P[(tid >> 3) * PLD + NBIN + (tid & 7)] = 0.f;       // (columns 201..208: read, times a zero weight, by the 4-wide mel steps)
+        {
+            // bins tid and tid + 128 of every pair: all the reads of a lane are requested before its first product
+            const int ka = tid, kb = tid + NTH;
+            const bool hasb = kb < NBIN;
+#pragma unroll
+            for (int h = 0; h < NP; h += NP / 2) {
+                f64x2 za[NP / 2], zam[NP / 2], zb[NP / 2], zbm[NP / 2];
+#pragma unroll
+                for (int p = 0; p < NP / 2; ++p) {
+                    const f64x2* Z = Yb + (h + p) * 20 * YP;
+                    za[p] = Z[ka];
+                    zam[p] = Z[ka ? NFFT - ka : 0];
+                    zb[p] = Z[hasb ? kb : 0];
+                    zbm[p] = Z[hasb ? NFFT - kb : 0];
+                }
+#pragma unroll
+                for (int p = 0; p < NP / 2; ++p) {
+                    float* Pa = P + (2 * (h + p)) * PLD;
+                    {
+                        const double ar = za[p].x + zam[p].x, ai = za[p].y - zam[p].y, br = za[p].y + zam[p].y, bi = za[p].x - zam[p].x;
+                        Pa[ka] = (float)(0.25 * (ar * ar + ai * ai));
+                        Pa[PLD + ka] = (float)(0.25 * (br * br + bi * bi));
+                    }
+                    if (hasb) {
+                        const double ar = zb[p].x + zbm[p].x, ai = zb[p].y - zbm[p].y, br = zb[p].y + zbm[p].y, bi = zb[p].x - zbm[p].x;
+                        Pa[kb] = (float)(0.25 * (ar * ar + ai * ai));
+                        Pa[PLD + kb] = (float)(0.25 * (br * br + bi * bi));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        LM_STAMP(4);
+
+        float* stage = reinterpret_cast<float*>(Yb);      // [frame][80] (Z is dead)
+        if (mf < MPW) {
+            // the first four taps of all of this lane's filters are requested together (8 serial read -> multiply -> log chains
+            // otherwise, each two LDS latencies long); wider filters finish in a short loop
+            const float* pw0 = P + fr * PLD;
+            float sum[NPASS];
+            int mlc[NPASS];
+#pragma unroll
+            for (int pi = 0; pi < NPASS; ++pi) {
+                const int m = (pi * (NTH / 64) + w) * MPW + mf;
+                mlc[pi] = mellc[m < NMEL ? m : 0];
+            }
+            if (compact) {
+#pragma unroll
+                for (int pi = 0; pi < NPASS; ++pi) {
+                    const int lc = mlc[pi];
+                    const float* pw = pw0 + (lc & 255);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(melw + (lc >> 16));
+                    const float q0 = pw[0], q1 = pw[1], q2 = pw[2], q3 = pw[3];
+                    sum[pi] = q0 * wv.x;
+                    sum[pi] = fmaf(q1, wv.y, sum[pi]);
+                    sum[pi] = fmaf(q2, wv.z, sum[pi]);
+                    sum[pi] = fmaf(q3, wv.w, sum[pi]);
+                }
+                // taps 4..7 the same way (filters of up to 4 taps: zero weights; the reads stay inside the lane's own tile row and the table)
+#pragma unroll
+                for (int pi = 0; pi < NPASS; ++pi) {
+                    const int lc = mlc[pi];
+                    const bool more = ((lc >> 8) & 255) > 4;
+                    const float* pw = pw0 + (lc & 255);
+                    f32x4 wv = *reinterpret_cast<const f32x4*>(melw + (lc >> 16) + 4);
+                    const float q0 = pw[4], q1 = pw[5], q2 = pw[6], q3 = pw[7];
+                    if (!more) wv = f32x4{0.f, 0.f, 0.f, 0.f};
+                    sum[pi] = fmaf(more ? q0 : 0.f, wv.x, sum[pi]);
+                    sum[pi] = fmaf(more ? q1 : 0.f, wv.y, sum[pi]);
+                    sum[pi] = fmaf(more ? q2 : 0.f, wv.z, sum[pi]);
+                    sum[pi] = fmaf(more ? q3 : 0.f, wv.w, sum[pi]);
+                }
+#pragma unroll
+                for (int pi = 0; pi < NPASS; ++pi) {
+                    const int lc = mlc[pi];
+                    const int cnt = (lc >> 8) & 255;
+                    const float* pw = pw0 + (lc & 255);
+                    const float* wm = melw + (lc >> 16);
+                    for (int i = 8; i < cnt; i += 4) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wm + i);
+                        const float q0 = pw[i], q1 = pw[i + 1], q2 = pw[i + 2], q3 = pw[i + 3];
+                        sum[pi] = fmaf(q0, wv.x, sum[pi]);
+                        sum[pi] = fmaf(q1, wv.y, sum[pi]);
+                        sum[pi] = fmaf(q2, wv.z, sum[pi]);
+                        sum[pi] = fmaf(q3, wv.w, sum[pi]);
+                    }
+                }
+            } else {                                  // (a filterbank whose supports do not fit the compact table: weights from memory)
+#pragma unroll 1
+                for (int pi = 0; pi < NPASS; ++pi) {
+                    const int m = (pi * (NTH / 64) + w) * MPW + mf;
+                    const int lc = mellc[m < NMEL ? m : 0];
+                    const int cnt = (lc >> 8) & 255;
+                    const float* pw = pw0 + (lc & 255);
+                    const float* wm = plan->mel_w + (m < NMEL ? m : 0) * MAXW;
+                    float acc = 0.f;
+                    for (int i = 0; i < cnt; ++i) acc = fmaf(pw[i], wm[i], acc);
+                    if (m < NMEL) stage[fr * NMEL + m] = logf(acc + eps);
+                }
+            }
+            if (compact)
+#pragma unroll
+            for (int pi = 0; pi < NPASS; ++pi) {
+                const int m = (pi * (NTH / 64) + w) * MPW + mf;
+                if (m < NMEL) stage[fr * NMEL + m] = logf(sum[pi] + eps);
+            }
+        }
+        __syncthreads();
+        LM_STAMP(5);
+        {
+            const int64_t nf = T - f0 < FBK ? T - f0 : FBK;           // frames of this block that exist
+            float* ob = out + (b * T + f0) * NMEL;
+            for (int idx = tid; idx < (int)nf * NMEL; idx += NTH) {
+                const float v = stage[idx];
+                ob[idx] = v;
+                local += (double)v;
+            }
+        }
+        __syncthreads();                                  // (the next block's samples and hand-over overwrite P and the staged outputs)
+        LM_STAMP(6);
+        ++lm_it;
+        blk = nxt;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if (lane == 0) red[w] = local;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = red[0] + red[1];
+}
+
 // fixed-order reduction of the per-workgroup partial sums -> {sum, count} and the float mean
 __global__ __launch_bounds__(256) void logmel_mean_kernel(const double* __restrict__ partial, int64_t n, double count,
                                                          float* __restrict__ mean_out, double* __restrict__ sum_out,
@@ -296,6 +595,12 @@ static int launch_subtract(float* x, int64_t n, const float* mean, hipStream_t s
 }  // namespace tal
 
 using namespace tal;
+
+#ifdef LM_TIMELINE
+extern "C" int tal_debug_logmel_timeline(void* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tal::g_lm_tl), sizeof(tal::g_lm_tl)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int64_t tal_logmel_num_frames(int64_t L) { return 1 + L / HOP; }
 
@@ -371,6 +676,13 @@ extern "C" int tal_logmel_plan_init(const float* window, const float* fb, void* 
                     hp->hbasis[((((j * 2 + par) * NHALF + h) * 16) + c) * 2 + 0] = re;
                     hp->hbasis[((((j * 2 + par) * NHALF + h) * 16) + c) * 2 + 1] = im;
                 }
+    for (int n2 = 0; n2 < 20; ++n2)
+        for (int k1 = 0; k1 < 20; ++k1) {
+            const double ang = two_pi * (double)(n2 * k1) / (double)NFFT;     // n2 k1 <= 361: no reduction needed
+            hp->tw[(n2 * 20 + k1) * 2 + 0] = cos(ang);
+            hp->tw[(n2 * 20 + k1) * 2 + 1] = -sin(ang);
+        }
+    for (int n = 0; n < NFFT; ++n) hp->win[n] = hwin[n];
     for (int m = 0; m < NMEL; ++m) {
         int lo = -1, hi = -1;
         for (int k = 0; k < NBIN; ++k)
@@ -384,6 +696,20 @@ extern "C" int tal_logmel_plan_init(const float* window, const float* fb, void* 
         hp->mel_cnt[m] = cnt;
         for (int i = 0; i < MAXW; ++i) hp->mel_w[m * MAXW + i] = i < cnt ? hfb[(lo + i) * NMEL + m] : 0.f;
     }
+    {
+        int total = 0;
+        for (int m = 0; m < NMEL; ++m) total += (hp->mel_cnt[m] + 3) / 4 * 4;
+        hp->mel_compact = total + 4 <= MELC ? 1 : 0;          // (a filterbank with wider supports: weights from the [80][48] table)
+        int off = 0;
+        for (int i = 0; i < MELC; ++i) hp->mel_wc[i] = 0.f;
+        for (int m = 0; m < NMEL; ++m) {
+            hp->mel_off[m] = hp->mel_compact ? off : 0;
+            if (hp->mel_compact) {
+                for (int i = 0; i < hp->mel_cnt[m]; ++i) hp->mel_wc[off + i] = hp->mel_w[m * MAXW + i];
+                off += (hp->mel_cnt[m] + 3) / 4 * 4;
+            }
+        }
+    }
     if (hipMemcpyAsync(plan, hp, sizeof(LogmelPlan), hipMemcpyHostToDevice, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
         set_error("tal_logmel_plan_init: cannot upload the plan");
@@ -394,7 +720,7 @@ extern "C" int tal_logmel_plan_init(const float* window, const float* fb, void* 
 
 extern "C" size_t tal_logmel_workspace_bytes(int B, int64_t L) {
     const int64_t T = 1 + L / HOP;
-    return (size_t)(B * cdiv(T, FB_SHORT) + 4) * sizeof(double);
+    return (size_t)(B * cdiv(T, FFT_FB) + 4) * sizeof(double);      // (12-frame workgroups: the most partial sums any form writes)
 }
 
 template <typename AT>
@@ -411,23 +737,32 @@ static int logmel_fwd_impl(const void* plan, const AT* audio, int B, int64_t L, 
         set_error("%s: workspace %zu < %zu bytes", what, workspace_bytes, tal_logmel_workspace_bytes(B, L));
         return TAL_ENOMEM;
     }
-    // short inputs (fewer than two 32-frame workgroups per CU): 16 frames per workgroup
-    const bool short_in = (int64_t)B * cdiv(T, FB) < 2 * (int64_t)device_cus() && workspace_bytes >= tal_logmel_workspace_bytes(B, L);
-    const int64_t nblk = cdiv(T, short_in ? FB_SHORT : FB);
+    // the fast-transform form (default) or the matrix form (`logmel_mfma`; a workspace sized before the fast form existed)
+    const bool fft = !opt(OPT_LOGMEL_MFMA) && workspace_bytes >= tal_logmel_workspace_bytes(B, L);
+    // matrix form, short inputs (fewer than two 32-frame workgroups per CU): 16 frames per workgroup
+    const bool short_in = !fft && (int64_t)B * cdiv(T, FB) < 2 * (int64_t)device_cus() &&
+                          workspace_bytes >= (size_t)(B * cdiv(T, FB_SHORT) + 4) * sizeof(double);
+    const int64_t nblk = cdiv(T, fft ? FFT_FB : (short_in ? FB_SHORT : FB));
+    // fast form: persistent workgroups (three per CU) walk the blocks of the whole batch, one partial sum each
+    const int64_t fft_wgs = B * nblk < 3 * (int64_t)device_cus() ? B * nblk : 3 * (int64_t)device_cus();
+    const int64_t nparts = fft ? fft_wgs : B * nblk;
     double* partial = reinterpret_cast<double*>(workspace);
-    float* mean_ws = reinterpret_cast<float*>(partial + B * nblk + 2);
+    float* mean_ws = reinterpret_cast<float*>(partial + nparts + 2);
     {
         // algorithmic HBM bytes: read L samples, write T*80 floats per item
         ProfScope prof(PROF_LOGMEL, (double)B * ((double)L * sizeof(AT) + (double)T * NMEL * 4.0), s);
-        if (short_in)
-            hipLaunchKernelGGL((logmel_kernel<FB_SHORT, AT>), dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, s,
-                               reinterpret_cast<const LogmelPlan*>(plan), audio, L, T, eps, out, partial);
+        const LogmelPlan* pl = reinterpret_cast<const LogmelPlan*>(plan);
+        const dim3 grid((unsigned)nblk, (unsigned)B);
+        if (fft)
+            hipLaunchKernelGGL((logmel_fft_kernel<FFT_FB / 2, AT>), dim3((unsigned)fft_wgs), dim3(128), 0, s, pl, audio, L, T, nblk,
+                               (int64_t)B * nblk, eps, out, partial);
+        else if (short_in)
+            hipLaunchKernelGGL((logmel_kernel<FB_SHORT, AT>), grid, dim3(256), 0, s, pl, audio, L, T, eps, out, partial);
         else
-            hipLaunchKernelGGL((logmel_kernel<FB, AT>), dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, s,
-                               reinterpret_cast<const LogmelPlan*>(plan), audio, L, T, eps, out, partial);
+            hipLaunchKernelGGL((logmel_kernel<FB, AT>), grid, dim3(256), 0, s, pl, audio, L, T, eps, out, partial);
     }
     TAL_CHECK_LAUNCH(what);
-    hipLaunchKernelGGL(logmel_mean_kernel, dim3(1), dim3(256), 0, s, partial, (int64_t)B * nblk,
+    hipLaunchKernelGGL(logmel_mean_kernel, dim3(1), dim3(256), 0, s, partial, nparts,
                        (double)B * (double)T * (double)NMEL, mean_out, sum_out, mean_ws);
     TAL_CHECK_LAUNCH(what);
     if (subtract_mean) return launch_subtract(out, (int64_t)B * T * NMEL, mean_ws, s);

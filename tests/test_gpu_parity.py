@@ -289,6 +289,74 @@ def test_logmel_silence_and_stats():
     np.testing.assert_allclose(stats[0].item() / stats[1].item(), mean.item(), rtol=1e-6)
 
 
+def _logmel_f64(audio, window, fb, eps):
+    """float64 restatement for an ARBITRARY window / filterbank (reflect pad 200, frames of 400 @ 160, rfft, power, fb, log)."""
+    a = np.asarray(audio, dtype=np.float64)
+    ap = np.pad(a, ((0, 0), (200, 200)), mode="reflect")
+    T = 1 + a.shape[1] // 160
+    idx = np.arange(400)[None, :] + 160 * np.arange(T)[:, None]
+    spec = np.fft.rfft(ap[:, idx] * np.asarray(window, dtype=np.float64)[None, None, :], axis=-1)
+    return np.log((spec.real ** 2 + spec.imag ** 2) @ np.asarray(fb, dtype=np.float64) + eps)
+
+
+@pytest.mark.parametrize("B,L", [(1, 16000), (3, 48000), (2, 5281), (1, 201)])
+def test_logmel_both_forms_match_the_oracle(B, L):
+    """The front-end has two forms: the fast transform on the float64 vector ALU (default: two frames per complex 400 = 20 x 20
+    transform, csrc/logmel.hip logmel_fft_kernel) and the float64 matrix-core DFT of rounds 1-4 (tal_set_option("logmel_mfma", 1)).
+    Both against the float32 and float64 oracles; the fast form within 5e-5 of the float64 one (it applies the float32 window as given,
+    the matrix form symmetrises it); a half-precision waveform gives exactly what the same samples give as float32."""
+    from oracle import tal_oracle as O
+    from tal_asrd_amd import LogMelSpec, synth, ops, _native as N_
+    audio = synth.synth_audio_batch(B, L, 321)
+    m = LogMelSpec().to(dev())
+    x = torch.from_numpy(audio).to(dev())
+    ref32, ref64 = O.logmel(audio, subtract_mean=False).numpy(), O.logmel_f64(audio, subtract_mean=False)
+    try:
+        for form in (0, 1):
+            N_.set_option("logmel_mfma", form)
+            got, mean, stats = ops.logmel(m.plan(), x, eps=m.eps, subtract_mean=False, return_stats=True)
+            g = got.cpu().numpy()
+            assert np.abs(g - ref32).max() < MEL_TOL and np.abs(g - ref64).max() < MEL_TOL, form
+            if form == 0:
+                assert np.abs(g - ref64).max() < 5e-5
+            np.testing.assert_allclose(float(mean), ref64.mean(), atol=2e-6)
+            assert float(stats[1]) == B * (1 + L // 160) * 80
+            h = ops.logmel(m.plan(), x.half(), eps=m.eps, subtract_mean=False)
+            assert torch.equal(h, ops.logmel(m.plan(), x.half().float(), eps=m.eps, subtract_mean=False))
+    finally:
+        N_.set_option("logmel_mfma", 0)
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_logmel_custom_window_and_filterbank(wide):
+    """The buffers a checkpoint may carry: a window that is NOT symmetric (the matrix form then takes its direct 400-term DFT,
+    the fast form applies any window in the time domain) and a filterbank other than the HTK one -- `wide`: supports of 40 bins,
+    which do not fit the fast form's compact filter table (weights then come from the [80][48] table in memory).  Both forms
+    against a float64 restatement with the same buffers."""
+    from tal_asrd_amd import LogMelSpec, synth, ops, _native as N_
+    rng = np.random.default_rng(5 + int(wide))
+    m = LogMelSpec().to(dev())
+    window = (0.2 + 0.8 * np.sin(np.pi * np.arange(400) / 400.0) ** 2 * (1.0 + 0.3 * np.arange(400) / 400.0)).astype(np.float32)
+    fb = np.zeros((201, 80), dtype=np.float32)
+    width = 40 if wide else 6
+    for j in range(80):
+        lo = int(round(j * (201 - width) / 79.0))
+        fb[lo:lo + width, j] = rng.uniform(0.1, 1.0, size=width).astype(np.float32)
+    with torch.no_grad():
+        m.mel_transform.spectrogram.window.copy_(torch.from_numpy(window))
+        m.mel_transform.mel_scale.fb.copy_(torch.from_numpy(fb))
+    audio = synth.synth_audio_batch(2, 20000, 77)
+    x = torch.from_numpy(audio).to(dev())
+    want = _logmel_f64(audio, window, fb, m.eps)
+    try:
+        for form in (0, 1):
+            N_.set_option("logmel_mfma", form)
+            got = ops.logmel(m.plan(), x, eps=m.eps, subtract_mean=False).cpu().numpy()
+            np.testing.assert_allclose(got, want, atol=2e-5 if form == 0 else MEL_TOL, rtol=0, err_msg="form %d" % form)
+    finally:
+        N_.set_option("logmel_mfma", 0)
+
+
 # ------------------------------------------------------------------ grouped convs
 @pytest.mark.parametrize("cig,cog,T,B", [(1, 10, 333, 2), (10, 14, 300, 1), (14, 18, 277, 2), (2, 3, 64, 1)])
 def test_gconv_s2_matches_torch(cig, cog, T, B):

@@ -343,9 +343,10 @@ __global__ __launch_bounds__(128, 2) void logmel_fft_kernel(const LogmelPlan* __
         for (int i = tid; i < MELC / 4; i += NTH) reinterpret_cast<f32x4*>(melw)[i] = reinterpret_cast<const f32x4*>(plan->mel_wc)[i];
         if (tid < NMEL) mellc[tid] = plan->mel_lo[tid] | (plan->mel_cnt[tid] << 8) | (plan->mel_off[tid] << 16);
     }
-    // mel stage roles: a wave takes MPW filters at a time, lane = (filter, frame); the lane's NPASS filters never change
-    constexpr int MPW = 64 / FBK, NPASS = (NMEL + (NTH / 64) * MPW - 1) / ((NTH / 64) * MPW);
-    const int mf = lane / FBK, fr = lane - mf * FBK;
+    // mel stage roles: a wave takes MPW filters at a time, lane = (filter, frame PAIR): the two frames of a lane share the weight
+    // reads and ride packed fp32 multiply-adds; the lane's NPASS filters never change
+    constexpr int MPW = 64 / NP, NPASS = (NMEL + (NTH / 64) * MPW - 1) / ((NTH / 64) * MPW);
+    const int mf = lane / NP, fr = 2 * (lane - mf * NP);
     __syncthreads();                                  // (the filter table is in LDS)
     double local = 0.0;
     int lm_it = 0;
@@ -353,9 +354,13 @@ __global__ __launch_bounds__(128, 2) void logmel_fft_kernel(const LogmelPlan* __
         const int64_t b = blk / nblk;
         const int64_t f0 = (blk - b * nblk) * FBK;
         LM_STAMP(0);
+        // (an opaque zero per block: the window taps, the lane's filter words and their addresses are loop-invariant, and hoisted
+        //  out of the block loop -- the taps already widened to float64 -- they are ~70 registers that get spilled around the passes)
+        int oz = 0;
+        asm volatile("" : "+v"(oz));
         float wn[20];
 #pragma unroll
-        for (int i = 0; i < 20; ++i) wn[i] = wp[20 * i];
+        for (int i = 0; i < 20; ++i) wn[i] = wp[20 * i + oz];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * NTH;
@@ -451,55 +456,68 @@ __global__ __launch_bounds__(128, 2) void logmel_fft_kernel(const LogmelPlan* __
 
         float* stage = reinterpret_cast<float*>(Yb);      // [frame][80] (Z is dead)
         if (mf < MPW) {
-            // the first four taps of all of this lane's filters are requested together (8 serial read -> multiply -> log chains
-            // otherwise, each two LDS latencies long); wider filters finish in a short loop
-            const float* pw0 = P + fr * PLD;
-            float sum[NPASS];
+            // the first four taps of all of this lane's filters are requested together (NPASS serial read -> multiply -> log chains
+            // otherwise, each two LDS latencies long), then taps 4..7; wider filters finish in a short loop
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const float* pa0 = P + fr * PLD + oz;
+            f32x2 sum[NPASS];
             int mlc[NPASS];
 #pragma unroll
             for (int pi = 0; pi < NPASS; ++pi) {
                 const int m = (pi * (NTH / 64) + w) * MPW + mf;
-                mlc[pi] = mellc[m < NMEL ? m : 0];
+                mlc[pi] = mellc[(m < NMEL ? m : 0) + oz];
             }
             if (compact) {
 #pragma unroll
                 for (int pi = 0; pi < NPASS; ++pi) {
                     const int lc = mlc[pi];
-                    const float* pw = pw0 + (lc & 255);
+                    const float* pa = pa0 + (lc & 255);
+                    const float* pb = pa + PLD;
                     const f32x4 wv = *reinterpret_cast<const f32x4*>(melw + (lc >> 16));
-                    const float q0 = pw[0], q1 = pw[1], q2 = pw[2], q3 = pw[3];
+                    const f32x2 q0 = {pa[0], pb[0]}, q1 = {pa[1], pb[1]}, q2 = {pa[2], pb[2]}, q3 = {pa[3], pb[3]};
                     sum[pi] = q0 * wv.x;
-                    sum[pi] = fmaf(q1, wv.y, sum[pi]);
-                    sum[pi] = fmaf(q2, wv.z, sum[pi]);
-                    sum[pi] = fmaf(q3, wv.w, sum[pi]);
+                    sum[pi] = __builtin_elementwise_fma(q1, f32x2{wv.y, wv.y}, sum[pi]);
+                    sum[pi] = __builtin_elementwise_fma(q2, f32x2{wv.z, wv.z}, sum[pi]);
+                    sum[pi] = __builtin_elementwise_fma(q3, f32x2{wv.w, wv.w}, sum[pi]);
                 }
-                // taps 4..7 the same way (filters of up to 4 taps: zero weights; the reads stay inside the lane's own tile row and the table)
+                // (filters of up to 4 taps: zero weights and zero operands; the reads stay inside the lane's own tile rows and the table)
 #pragma unroll
                 for (int pi = 0; pi < NPASS; ++pi) {
                     const int lc = mlc[pi];
                     const bool more = ((lc >> 8) & 255) > 4;
-                    const float* pw = pw0 + (lc & 255);
+                    const float* pa = pa0 + (lc & 255);
+                    const float* pb = pa + PLD;
                     f32x4 wv = *reinterpret_cast<const f32x4*>(melw + (lc >> 16) + 4);
-                    const float q0 = pw[4], q1 = pw[5], q2 = pw[6], q3 = pw[7];
-                    if (!more) wv = f32x4{0.f, 0.f, 0.f, 0.f};
-                    sum[pi] = fmaf(more ? q0 : 0.f, wv.x, sum[pi]);
-                    sum[pi] = fmaf(more ? q1 : 0.f, wv.y, sum[pi]);
-                    sum[pi] = fmaf(more ? q2 : 0.f, wv.z, sum[pi]);
-                    sum[pi] = fmaf(more ? q3 : 0.f, wv.w, sum[pi]);
+                    f32x2 q0 = {pa[4], pb[4]}, q1 = {pa[5], pb[5]}, q2 = {pa[6], pb[6]}, q3 = {pa[7], pb[7]};
+                    const f32x2 z2 = {0.f, 0.f};
+                    if (!more) { wv = f32x4{0.f, 0.f, 0.f, 0.f}; q0 = z2; q1 = z2; q2 = z2; q3 = z2; }
+                    sum[pi] = __builtin_elementwise_fma(q0, f32x2{wv.x, wv.x}, sum[pi]);
+                    sum[pi] = __builtin_elementwise_fma(q1, f32x2{wv.y, wv.y}, sum[pi]);
+                    sum[pi] = __builtin_elementwise_fma(q2, f32x2{wv.z, wv.z}, sum[pi]);
+                    sum[pi] = __builtin_elementwise_fma(q3, f32x2{wv.w, wv.w}, sum[pi]);
                 }
 #pragma unroll
                 for (int pi = 0; pi < NPASS; ++pi) {
                     const int lc = mlc[pi];
                     const int cnt = (lc >> 8) & 255;
-                    const float* pw = pw0 + (lc & 255);
+                    const float* pa = pa0 + (lc & 255);
+                    const float* pb = pa + PLD;
                     const float* wm = melw + (lc >> 16);
                     for (int i = 8; i < cnt; i += 4) {
                         const f32x4 wv = *reinterpret_cast<const f32x4*>(wm + i);
-                        const float q0 = pw[i], q1 = pw[i + 1], q2 = pw[i + 2], q3 = pw[i + 3];
-                        sum[pi] = fmaf(q0, wv.x, sum[pi]);
-                        sum[pi] = fmaf(q1, wv.y, sum[pi]);
-                        sum[pi] = fmaf(q2, wv.z, sum[pi]);
-                        sum[pi] = fmaf(q3, wv.w, sum[pi]);
+                        const f32x2 q0 = {pa[i], pb[i]}, q1 = {pa[i + 1], pb[i + 1]}, q2 = {pa[i + 2], pb[i + 2]}, q3 = {pa[i + 3], pb[i + 3]};
+                        sum[pi] = __builtin_elementwise_fma(q0, f32x2{wv.x, wv.x}, sum[pi]);
+                        sum[pi] = __builtin_elementwise_fma(q1, f32x2{wv.y, wv.y}, sum[pi]);
+                        sum[pi] = __builtin_elementwise_fma(q2, f32x2{wv.z, wv.z}, sum[pi]);
+                        sum[pi] = __builtin_elementwise_fma(q3, f32x2{wv.w, wv.w}, sum[pi]);
+                    }
+                }
+#pragma unroll
+                for (int pi = 0; pi < NPASS; ++pi) {
+                    const int m = (pi * (NTH / 64) + w) * MPW + mf;
+                    if (m < NMEL) {
+                        stage[fr * NMEL + m] = logf(sum[pi].x + eps);
+                        stage[(fr + 1) * NMEL + m] = logf(sum[pi].y + eps);
                     }
                 }
             } else {                                  // (a filterbank whose supports do not fit the compact table: weights from memory)
@@ -508,18 +526,19 @@ __global__ __launch_bounds__(128, 2) void logmel_fft_kernel(const LogmelPlan* __
                     const int m = (pi * (NTH / 64) + w) * MPW + mf;
                     const int lc = mellc[m < NMEL ? m : 0];
                     const int cnt = (lc >> 8) & 255;
-                    const float* pw = pw0 + (lc & 255);
+                    const float* pa = pa0 + (lc & 255);
+                    const float* pb = pa + PLD;
                     const float* wm = plan->mel_w + (m < NMEL ? m : 0) * MAXW;
-                    float acc = 0.f;
-                    for (int i = 0; i < cnt; ++i) acc = fmaf(pw[i], wm[i], acc);
-                    if (m < NMEL) stage[fr * NMEL + m] = logf(acc + eps);
+                    float acc0 = 0.f, acc1 = 0.f;
+                    for (int i = 0; i < cnt; ++i) {
+                        acc0 = fmaf(pa[i], wm[i], acc0);
+                        acc1 = fmaf(pb[i], wm[i], acc1);
+                    }
+                    if (m < NMEL) {
+                        stage[fr * NMEL + m] = logf(acc0 + eps);
+                        stage[(fr + 1) * NMEL + m] = logf(acc1 + eps);
+                    }
                 }
-            }
-            if (compact)
-#pragma unroll
-            for (int pi = 0; pi < NPASS; ++pi) {
-                const int m = (pi * (NTH / 64) + w) * MPW + mf;
-                if (m < NMEL) stage[fr * NMEL + m] = logf(sum[pi] + eps);
             }
         }
         __syncthreads();

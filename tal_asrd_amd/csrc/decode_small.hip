@@ -40,8 +40,11 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_multi_kernel(const ArgPac
 // partial buffers and tickets), so results are bit-identical to the narrow form and to a session's solo step.
 template <int MODE, int MT, int NW, int NT>
 __device__ __forceinline__ void skinny_gemm_wide_body(const SkinnyArgs& g, const Blk blk) {
-    __shared__ __attribute__((aligned(16))) float part[NW * MT * 256];   // [wave][m tile][row 16][col 16]
-    __shared__ unsigned ticket;
+    // Round 5: the NT blocks' products first, back to back, and then ONE pass of partial tiles -> LDS -> wave-order sums -> K-slice
+    // hand-over (stores, one drain, NT tickets taken side by side) -> epilogues, instead of that whole chain once per block: a
+    // merged step's 2048-deep layer took 20.8 us with four serial hand-overs per workgroup where a session alone takes 6.6.
+    __shared__ __attribute__((aligned(16))) float part[NT * NW * MT * 256];   // [block][wave][m tile][row 16][col 16]
+    __shared__ unsigned ticket[NT];
     constexpr int UNR = 8;                          // Kw == 128: the wave's K slice is exactly one batch of 8 chunks
     const int m0 = blk.y * 32;
     const int lane = threadIdx.x & 63, w = wave_id();
@@ -83,57 +86,73 @@ __device__ __forceinline__ void skinny_gemm_wide_body(const SkinnyArgs& g, const
                 acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u].w, bw[nt & 1][u].w, acc[mt], 0, 0, 0);
             }
         }
-        if (nt > 0) __syncthreads();                // the previous block's sums have been read out of `part`
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) part[((w * MT + mt) * 16 + 4 * kq + i) * 16 + r16] = acc[mt][i];
-        __syncthreads();
-        const int n0 = (nb0 + nt) * 16;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (t < MT * 64) {
-            v = *reinterpret_cast<const f32x4*>(&part[((0 * MT + mt_t) * 16 + r) * 16 + 4 * c4]);
+            for (int i = 0; i < 4; ++i) part[(((nt * NW + w) * MT + mt) * 16 + 4 * kq + i) * 16 + r16] = acc[mt][i];
+    }
+    __syncthreads();
+    f32x4 v[NT];
+    if (t < MT * 64) {
 #pragma unroll
-            for (int q = 1; q < NW; ++q) v += *reinterpret_cast<const f32x4*>(&part[((q * MT + mt_t) * 16 + r) * 16 + 4 * c4]);   // wave order
+        for (int nt = 0; nt < NT; ++nt) {
+            v[nt] = *reinterpret_cast<const f32x4*>(&part[(((nt * NW + 0) * MT + mt_t) * 16 + r) * 16 + 4 * c4]);
+#pragma unroll
+            for (int q = 1; q < NW; ++q) v[nt] += *reinterpret_cast<const f32x4*>(&part[(((nt * NW + q) * MT + mt_t) * 16 + r) * 16 + 4 * c4]);   // wave order
         }
-        bool finish = true;
-        if (KS > 1) {
-            const unsigned gx = blk.gx * NT;        // the narrow form's grid extent: same tile numbers, partial buffers and tickets
-            const unsigned tile = blk.y * gx + (unsigned)(nb0 + nt), ntile = gx * blk.gy;
-            float* mine = g.sk_part + ((size_t)blk.z * ntile + tile) * 512 + t * 4;
-            if (t < MT * 64) { st_agent(mine, v.x); st_agent(mine + 1, v.y); st_agent(mine + 2, v.z); st_agent(mine + 3, v.w); }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t == 0) ticket = take_ticket(&g.sk_tickets[tile]);
-            __syncthreads();
-            finish = ticket == (unsigned)(KS - 1);
-            if (finish) {
-                if (t == 0) reset_ticket(&g.sk_tickets[tile]);
+    }
+    bool finish[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) finish[nt] = true;
+    if (KS > 1) {
+        const unsigned gx = blk.gx * NT;            // the narrow form's grid extent: same tile numbers, partial buffers and tickets
+        const unsigned ntile = gx * blk.gy;
+        const unsigned tile0 = blk.y * gx + (unsigned)nb0;
+        if (t < MT * 64) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float* mine = g.sk_part + ((size_t)blk.z * ntile + tile0 + nt) * 512 + t * 4;
+                st_agent(mine, v[nt].x); st_agent(mine + 1, v[nt].y); st_agent(mine + 2, v[nt].z); st_agent(mine + 3, v[nt].w);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t < NT) ticket[t] = take_ticket(&g.sk_tickets[tile0 + t]);
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            finish[nt] = ticket[nt] == (unsigned)(KS - 1);
+            if (finish[nt]) {
+                if (t == 0) reset_ticket(&g.sk_tickets[tile0 + nt]);
                 if (t < MT * 64) {
-                    const float* p0 = g.sk_part + (size_t)tile * 512 + t * 4;
-                    v = {0.f, 0.f, 0.f, 0.f};
+                    const float* p0 = g.sk_part + (size_t)(tile0 + nt) * 512 + t * 4;
+                    v[nt] = {0.f, 0.f, 0.f, 0.f};
                     for (int q = 0; q < KS; ++q) {                 // split order
                         const float* pq = p0 + (size_t)q * ntile * 512;
-                        v.x += ld_agent(pq); v.y += ld_agent(pq + 1); v.z += ld_agent(pq + 2); v.w += ld_agent(pq + 3);
+                        v[nt].x += ld_agent(pq); v[nt].y += ld_agent(pq + 1); v[nt].z += ld_agent(pq + 2); v[nt].w += ld_agent(pq + 3);
                     }
                 }
             }
         }
-        if (finish && t < MT * 64 && m < g.M) {
-            const int col = n0 + 4 * c4;
-            if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
-            if (MODE == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (MODE == 2) v = *reinterpret_cast<const f32x4*>(g.res + (int64_t)m * g.ldres + col) + g.alpha * v;
-            if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) v = g.alpha * v;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (finish[nt] && t < MT * 64 && m < g.M) {
+            const int col = (nb0 + nt) * 16 + 4 * c4;
+            f32x4 o = v[nt];
+            if (g.bias) o += *reinterpret_cast<const f32x4*>(g.bias + col);
+            if (MODE == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (MODE == 2) o = *reinterpret_cast<const f32x4*>(g.res + (int64_t)m * g.ldres + col) + g.alpha * o;
+            if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) o = g.alpha * o;
             if (g.Yt && col >= g.vt_begin) {
                 const int b = m / g.U, u = m - b * g.U;
                 float* yt = g.Yt + (int64_t)b * g.vt_bs + (int64_t)(col - g.vt_begin) * g.ldt + u;
-                yt[0] = v.x;
-                yt[g.ldt] = v.y;
-                yt[2 * g.ldt] = v.z;
-                yt[3 * g.ldt] = v.w;
+                yt[0] = o.x;
+                yt[g.ldt] = o.y;
+                yt[2 * g.ldt] = o.z;
+                yt[3 * g.ldt] = o.w;
             } else
-                *reinterpret_cast<f32x4*>(g.Y + (int64_t)m * g.ldy + col) = v;
+                *reinterpret_cast<f32x4*>(g.Y + (int64_t)m * g.ldy + col) = o;
         }
     }
 }

@@ -400,8 +400,9 @@ class System:
         taken alone, flags that came back to Python) -- measurement only.
 
         streams / group left at None: four host threads (the device runs four chains of launches side by side), each with a group
-        of ceil(episodes / 4) sessions, at most 4 -- the best or near-best measured split for 8 one-hour episodes (4 x 2: 3.9-4.3x
-        the one-at-a-time loop) and for 32 ten-minute ones (4 x 4: 5.4x; 2 x 16: 5.7x), profiles/r4_episode_streams*.txt.
+        of ceil(episodes / 4) sessions, at most 4 -- the best measured split for 8 one-hour episodes (4 x 2: 4.0-4.3x the
+        one-at-a-time loop); from 32 episodes on, two threads with groups of 16 (32 ten-minute episodes: 6.2x against 5.5x for
+        4 x 4), profiles/r5_episode_streams*.txt.
 
         Device memory: every session in flight (streams x group, plus the producer's queue of max(2, group) + 1 prepared episodes in
         group mode) holds its encoder output and -- while it fits -- an episode-wide K | V table of decoder layers x encoder frames x
@@ -413,6 +414,8 @@ class System:
         Returns [(utterance dicts, generated, alignments)] in episode order, identical to the solo runs in either mode."""
         if not episodes:
             return []
+        if group is None and streams is None and len(episodes) >= 32:
+            streams, group = 2, N.TAL_GROUP_MAX         # (a corpus: two chains of 16-session merged steps, 6.2x against 5.5x for 4 x 4)
         if group is None:
             group = 1 if streams is not None else max(1, min(4, -(-len(episodes) // 4)))
         if streams is None:

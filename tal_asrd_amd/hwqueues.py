@@ -55,8 +55,9 @@ def classes(device):
             out = []
             for s in pool:
                 for c in out:
-                    # same queue: the two chains take ~2x one chain; different queues: ~1x (the midpoint decides; best of two)
-                    if min(_timed(dev, [c[0], s]) for _ in range(2)) > 1.5 * one:
+                    # same queue: the two chains take ~2x one chain; different queues: ~1x (the midpoint decides; best of three:
+                    # chains that share a queue never overlap, so one overlapping look settles it)
+                    if min(_timed(dev, [c[0], s]) for _ in range(3)) > 1.5 * one:
                         c.append(s)
                         break
                 else:

@@ -158,8 +158,10 @@ __global__ __launch_bounds__(256, F16X3 ? 2 : 1) void gemm_glds_kernel(const Gem
     __builtin_amdgcn_s_setprio(0);
     __builtin_assume(kt0 < nk);       // (K >= 32: without this the accumulators are initialised twice, 160 moves)
     for (int kt = kt0; kt < nk; ++kt) {
-        // tile kt has landed (vmcnt(0) is part of the barrier while LDS-DMA is in flight) and every
-        // wave is done reading the other buffer (it finished step kt-1 before arriving here)
+        // tile kt has landed -- this wave's part of it by the explicit wait: the compiler orders an LDS-DMA load only in front of
+        // the wave's OWN LDS reads, not in front of a barrier (csrc/head.hip had a barrier with no wait in front, round 5) -- and
+        // every wave is done reading the other buffer (it finished step kt-1 before arriving here)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const float* As = lds + (kt & 1) * (ROWS * 32) + (wm * 32 + frow) * 32;

@@ -122,15 +122,24 @@ __global__ __launch_bounds__(256, 2) void head_argmax_kernel(const float* __rest
         }
         float bv[HNSUB];
 #pragma unroll
-        for (int j = 0; j < HNSUB; ++j) bv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, (n * HBN + j * 32 + frow) * 4, 0, 0));
-#pragma unroll
         for (int kt = 0; kt < HK / 32; ++kt) {
             const int buf = kt & 1;
+            // THIS wave's quarter of chunk (n, kt) has landed before it arrives at the barrier: nothing orders an LDS-DMA load in
+            // front of a barrier by itself (the compiler only waits for it in front of this wave's OWN LDS reads; at the kt == 0
+            // barrier of a unit that does not start a row block it emitted vmcnt(21), i.e. no wait) -- the other waves then read
+            // rows that are still in flight: a few wrong ids per ~10 calls on 239 k rows (round 5, scripts/r5_head_determinism.py)
+#ifndef HEAD_NO_DMA_WAIT      // (ablation build of the measurement in profiles/r5_head_lds_dma_race.txt only)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             __syncthreads();      // chunk (n, kt) has landed; everyone is done with the other buffer
             if (kt + 1 < HK / 32)
                 issue(n, kt + 1, buf ^ 1);
             else if (u + 1 < u1)
                 issue((int)((u + 1) % NT), 0, buf ^ 1);
+            if (kt == 0) {        // (behind the barrier: the wait above is not for these)
+#pragma unroll
+                for (int j = 0; j < HNSUB; ++j) bv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, (n * HBN + j * 32 + frow) * 4, 0, 0));
+            }
             const float* Bs = lds + buf * (HBN * 32) + frow * 32;
             if (F16X3) {
                 // a 128-byte W row of this K block is [32 hi | 32 lo]: 16-byte slot 2g + half (hi), 4 + 2g + half (lo)

@@ -1018,6 +1018,29 @@ def test_one_hour_prefix_consistency_and_determinism(sd_model):
     np.testing.assert_array_equal(l1.argmax(-1).cpu().numpy(), i1.cpu().numpy())
 
 
+def test_head_argmax_is_the_same_call_after_call(sd_model):
+    """The arg-max head on the row count of BASELINE.json configs[3] (64 x 3,733 rows), 40 calls on one input: ids and features of
+    every call equal the first call's.  Round 5 found a race here (csrc/head.hip: a barrier with no wait for the LDS-DMA loads in
+    front of it -- a few wrong ids in 14-100 % of the calls, profiles/r5_head_lds_dma_race.txt); the ids are also checked against
+    the float64 arg-max of the logits on sampled rows whose margin is not within round-off."""
+    from tal_asrd_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(23)
+    x = torch.randn(64, 3733, 1440, generator=g, device=dev())
+    heads = (sd_model.spk_embed_proj.weight, sd_model.spk_embed_proj.bias, sd_model.spk_logit_proj.weight, sd_model.spk_logit_proj.bias)
+    with torch.no_grad():
+        f0, _, i0 = ops.sd_head(x, *heads, False, True)
+        for k in range(40):
+            f, _, i = ops.sd_head(x, *heads, False, True)
+            assert torch.equal(i, i0), "call %d: %d ids differ" % (k, int((i != i0).sum()))
+            assert torch.equal(f, f0)
+        rows = torch.randint(0, 64 * 3733, (4096,), generator=torch.Generator().manual_seed(1)).to(dev())
+        feat = f0.reshape(-1, 128)[rows].double()
+        logits = feat @ heads[2].double().t() + heads[3].double()
+        top2 = torch.topk(logits, 2, dim=-1)
+        safe = (top2.values[:, 0] - top2.values[:, 1]) > 1e-4
+        assert bool((i0.reshape(-1)[rows][safe].long() == top2.indices[:, 0][safe]).all())
+
+
 def test_config3_batch_shape_items_match_single_calls(sd_model):
     """BASELINE.json configs[3] shape on one GPU: a batch of 64 five-minute segments through the
     encoder + fused head in ONE call; any item must equal its own B=1 call (round-off only: the

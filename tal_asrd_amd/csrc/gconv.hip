@@ -952,7 +952,7 @@ template <int TT>
 __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __restrict__ x, const _Float16* __restrict__ wfrag,
                                                              const _Float16* __restrict__ wshift, const float* __restrict__ bias, float alpha,
                                                              _Float16* __restrict__ ysplit, int64_t T, int C, int* __restrict__ range_flag,
-                                                             int n_tt, int n_gb) {
+                                                             int n_tt, int n_gb, int nb_total) {
     using LY = GcLayout<18, 1>;
     static_assert(LY::NSEG == 1 && LY::pitch(0) == 20 && LY::PERM && LY::nk(0) == 14, "the shift-packed kernel is built for 40-byte slab rows");
     constexpr int CG = 18, GB = 2, P = 20, NK = 14, NKP = LY::NKP, PADT = KS / 2;
@@ -964,7 +964,22 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
     _Float16* s_lo = slab + GB * GS;
     _Float16* s_wl = slab + 2 * GB * GS;
 
+#ifdef GC_S18_PERSIST
+    // persistent form (ablation): two resident workgroups per CU walk the blocks their slots would have been dealt, in the same order
+    // (physical block p runs on XCD p % 8; p, p + gridDim.x, ... keep that), so no workgroup is dispatched after the first wave of them
+    for (unsigned pb_ = blockIdx.x; pb_ < (unsigned)nb_total; pb_ += gridDim.x) {
+    int b, g0;
+    int64_t t0;
+    {
+        const unsigned L = xcd_logical_block((unsigned)nb_total, pb_);
+        const unsigned gbi = L % (unsigned)n_gb, rest = L / (unsigned)n_gb;
+        g0 = (int)gbi * GB;
+        t0 = (int64_t)(rest % (unsigned)n_tt) * TT;
+        b = (int)(rest / (unsigned)n_tt);
+    }
+#else
     GC_BLOCK_INDEX(n_tt, n_gb)
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = wave_id();
     const float* xb = x + (int64_t)b * T * C;
@@ -1267,6 +1282,10 @@ __global__ __launch_bounds__(256, 2) void gconv18_shift_kernel(const float* __re
         }
     }
     GC_STAMP(7);
+#ifdef GC_S18_PERSIST
+    __syncthreads();       // (the next block's fill overwrites the slab the store phase has just read)
+    }
+#endif
 }
 
 // weight lines of the shifted tile: [g][channel 16 / 17][hi, lo][S18_WLP] halves = S18_WPRE zeros | the channel's 420 weights in
@@ -1437,10 +1456,14 @@ int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias
             attr_done[shortt] = reinterpret_cast<const void*>(kern);
         }
         int n_tt, n_gb;
-        const dim3 grid = gconv_grid(cdiv(T, shortt ? 64 : 256), groups / 2, B, n_tt, n_gb);
+        dim3 grid = gconv_grid(cdiv(T, shortt ? 64 : 256), groups / 2, B, n_tt, n_gb);
+        const int nb_total = n_tt > 0 ? (int)grid.x : 0;
+#ifdef GC_S18_PERSIST
+        if (n_tt > 0 && grid.x > 2u * (unsigned)device_cus()) grid = dim3(2u * (unsigned)device_cus());
+#endif
         ProfScope prof(PROF_GCONV_RES, 2.0 * (double)B * (double)T * C * cg * KS, s);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, reinterpret_cast<const _Float16*>(w_frag), wshift, bias, alpha,
-                           reinterpret_cast<_Float16*>(y_split), T, C, range_flag, n_tt, n_gb);
+                           reinterpret_cast<_Float16*>(y_split), T, C, range_flag, n_tt, n_gb, nb_total);
         TAL_CHECK_LAUNCH("gconv (fp16x3, shifted tile)");
         return TAL_OK;
     }

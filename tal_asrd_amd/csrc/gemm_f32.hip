@@ -223,7 +223,11 @@ __global__ __launch_bounds__(256, F16X3 ? 2 : 1) void gemm_glds_kernel(const Gem
             }
         }
     }
-    __syncthreads();  // all waves done with the operand buffers before they become the store stage
+    // all waves done with the operand buffers before they become the store stage.  (No LDS-DMA load is in flight here: the last
+    // step issues none.  The wait says so in the instruction stream, where tests/test_isa_sync.py checks every barrier of this
+    // kernel without knowing the trip count; it retires nothing and costs nothing.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     __builtin_amdgcn_s_setprio(3);
     if (F16X3) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--no-clip-latency", action="store_true", help="clip workload: skip the 30 s / 5 min call latencies (clip_latency)")
     ap.add_argument("--no-one-gpu-reference", action="store_true", help="segments workload at N > 1: skip rank 0's solo pass over all segments")
     ap.add_argument("--cpu-threads", type=str, default="8,16,32,64,128", help="thread counts the CPU baseline is swept over")
+    ap.add_argument("--passes", type=int, default=3, help="timed passes of --steps steps each; `value` is the MEDIAN pass (BASELINE.md section 3: median of >= 3 runs)")
+    ap.add_argument("--no-clock-sampler", action="store_true", help="do not sample the shader clock / socket power during the timed passes")
     a = ap.parse_args()
     if a.workload is None:
         a.workload = "clip" if a.gpus == 1 else "segments"
@@ -124,6 +126,62 @@ def self_launch(args):
     sys.stdout.write("".join(out0))
     sys.stdout.flush()
     return max(abs(c) for c in codes)
+
+
+class ClockSampler:
+    """Shader clock and socket power of one GPU, sampled by a host thread while a timed pass runs (amdsmi: the driver's
+    gpu_metrics table, no HIP call, nothing enqueued on the device).  The dense layers of the headline step are power-limited
+    (1.4-1.9 GHz of 2.4 sustained), so box-to-box and pass-to-pass differences of `value` show up here."""
+
+    def __init__(self, device_index=0, period_s=0.02):
+        self.period, self.h, self.why = period_s, None, None
+        try:
+            import amdsmi
+            self.smi = amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            self.h = hs[device_index if device_index < len(hs) else 0]
+            self._read()
+        except BaseException as e:      # noqa: B902 -- measurement garnish: never fatal
+            self.h, self.why = None, "%s: %s" % (type(e).__name__, str(e)[:120])
+
+    @staticmethod
+    def _num(v):
+        return float(v) if isinstance(v, (int, float)) and 0 < v < 65535 else None
+
+    def _read(self):
+        m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
+        clks = [c for c in (self._num(v) for v in (m.get("current_gfxclks") or [])) if c is not None]
+        sclk = sum(clks) / len(clks) if clks else self._num(m.get("current_gfxclk")) or self._num(m.get("average_gfxclk_frequency"))
+        power = self._num(m.get("current_socket_power")) or self._num(m.get("average_socket_power"))
+        return sclk, power
+
+    def start(self):
+        if self.h is None:
+            return
+        import threading
+        self.samples, self._stop = [], threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                try:
+                    self.samples.append(self._read())
+                except BaseException:      # noqa: B902
+                    pass
+                self._stop.wait(self.period)
+        self._t = threading.Thread(target=loop, daemon=True)
+        self._t.start()
+
+    def stop(self):
+        """-> {"sclk_mhz": mean, "sclk_mhz_min": ..., "power_w": mean, "samples": n} of the samples since start()."""
+        if self.h is None:
+            return {"sclk_mhz": None, "power_w": None, "samples": 0, "unavailable": self.why}
+        self._stop.set()
+        self._t.join()
+        sc = [s for s, _ in self.samples if s is not None]
+        pw = [p for _, p in self.samples if p is not None]
+        return {"sclk_mhz": sum(sc) / len(sc) if sc else None, "sclk_mhz_min": min(sc) if sc else None,
+                "power_w": sum(pw) / len(pw) if pw else None, "samples": len(self.samples)}
 
 
 def build_sd_model(dev):
@@ -715,9 +773,33 @@ def main():
         for _ in range(args.warmup):
             step()
         drain()
-        # `value` comes from a pass WITHOUT the per-launch event recording; the roofline numbers from a second pass of the
-        # same K steps with it (the events cost a little host and queue time inside the region they measure)
-        elapsed = timed_pass(False)
+        # `value` comes from passes WITHOUT the per-launch event recording: --passes (>= 3) passes of exactly K steps each, every
+        # one bracketed by barrier + synchronize and max-reduced over the ranks; `value` is the MEDIAN pass (one pass is a draw: the
+        # step is power-limited and round 5's single pass landed 8 % off the same process's next one).  The roofline numbers come from
+        # a further pass of the same K steps with the events (they cost a little host and queue time inside the region they measure).
+        sampler = None if (args.no_clock_sampler or fake or rank != 0) else ClockSampler(local if world > 1 else 0)
+        pass_s, pass_clk = [], []
+        for _ in range(max(1, args.passes)):
+            if sampler is not None:
+                sampler.start()
+            dt_p = timed_pass(False)
+            if sampler is not None:
+                pass_clk.append(sampler.stop())
+            if dist is not None:
+                t = torch.tensor([dt_p], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_p = float(t.item())
+            pass_s.append(dt_p)
+        order = sorted(range(len(pass_s)), key=lambda i: pass_s[i])
+        med = order[(len(order) - 1) // 2]          # (the lower median for an even count: never an average of two passes)
+        elapsed = pass_s[med]
+        extra["ms_per_step_passes"] = [1e3 * t / args.steps for t in pass_s]
+        extra["passes"] = {"n": len(pass_s), "value_is": "median pass (index %d)" % med,
+                           "spread": (max(pass_s) - min(pass_s)) / elapsed}
+        if pass_clk:
+            extra["gpu_sclk_mhz"] = pass_clk[med]["sclk_mhz"]
+            extra["gpu_power_w"] = pass_clk[med]["power_w"]
+            extra["passes"]["clocks"] = pass_clk
         if prof and args.workload != "decode":
             elapsed_prof = timed_pass(True)
             extra["ms_per_step_with_launch_events"] = 1e3 * elapsed_prof / args.steps
@@ -737,10 +819,6 @@ def main():
             extra["value_exact_f32"] = units_per_step * args.steps / elapsed_exact
             extra["ms_per_step_exact_f32"] = 1e3 * elapsed_exact / args.steps
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     with torch.no_grad():
         if args.workload == "segments" and world > 1 and not args.no_one_gpu_reference:
             # the SAME workload on one GPU: rank 0 alone runs all n_seg segments as one batched call (the other ranks wait),

@@ -235,7 +235,11 @@ size_t tal_tds_workspace_bytes(const tal_tds_desc* d, int B, int64_t T);
  * status word is cleared by a kernel, not a memset node), so a caller may capture them into a HIP graph once every one-off
  * build (plans, weight packs) has run eagerly; the status word is read after each replay like after each call. */
 size_t tal_tds_status_offset(const tal_tds_desc* d, int B, int64_t T);
-/* 1: tal_tds_fwd / tal_tds_premean_fwd with TAL_TDS_OUT_SPLIT in d->flags writes y in the split form for these shapes; 0: fp32 */
+/* 1: tal_tds_fwd / tal_tds_premean_fwd with TAL_TDS_OUT_SPLIT in d->flags writes y in the split form for these shapes; 0: fp32.
+ * A PREDICTION (made for a 16-byte aligned x under the options in force at the time of the query): the call itself records the
+ * form it wrote in word 1 of its status block (int32 at tal_tds_status_offset() + 4: 1 = split, 0 = fp32), and a caller that
+ * hands y to tal_sd_head_split_fwd on the strength of the prediction reads that word together with the range flag.
+ * tal_tds_tiled_fwd always writes fp32 (the flag is ignored there). */
 int tal_tds_out_split(const tal_tds_desc* d, int B, int64_t T);
 /* x [B, T, channels[0]] -> y [B, T', channels[n_stages]] */
 int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t T, float* y,
@@ -400,7 +404,8 @@ typedef struct tal_greedy_ctx {
                               * NULL: the unmerged forms (more launches).  One context per stream. */
     float* picked_host_dev;  /* device alias of picked_host; NULL: resolved (hipHostGetDevicePointer) by the first sync 2 / 3 step */
     uint32_t seq;            /* library-owned: sequence value of the latest sync 2 / 3 step (start at 0) */
-    uint32_t _pad;
+    uint32_t needs_reset;    /* library-owned (start at 0): a step of this context failed part-way (option decode_persist: a phase barrier gave
+                              * up) and left counters in `tickets`; the next step on the context waits for the stream and zeroes the block */
     int64_t k_pitch;         /* floats between the K rows k_cache[l] points at; 0: E (a window of its own) */
     /* episode-wide K | V table (tal_greedy_set_window; all 0 / NULL: windows are projected one by one with tal_cross_kv_fwd):
      * kv_all[l] = [enc_frames, kv_pitch] floats, K in columns [0, E), V (no bias) in [E, 2E) of a frame's row -- one dense layer
@@ -408,6 +413,12 @@ typedef struct tal_greedy_ctx {
     const float* const* kv_all;
     const uint8_t* kpm_all;  /* key-padding bytes of the whole episode [enc_frames] or NULL */
     int64_t enc_frames, kv_pitch;
+    /* [V] floats or NULL: added to the last position's logits before the arg-max -- the LM shallow fusion of
+     * System.generate_unaligned (tal/asr/system.py:368-384: logprobs[:, :n] += lm_weight * log_softmax(lm(prefix)[-1])[:n];
+     * arg max (log_softmax(x) + b) = arg max (x + b)): the caller fills lm_weight * LM log-probabilities on the shared part of the
+     * two vocabularies and 0 beyond it, before every step.  Honoured by tal_greedy_step_fwd and tal_greedy_step_multi_fwd; the
+     * one-launch form (option decode_persist) is not taken while it is set. */
+    const float* pick_bias;
 } tal_greedy_ctx;
 size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H, int FF, int V, int E0, int n_layers);
 /* sync: 0 = enqueue only; 1 = copy {token, attention row} to picked_host and wait for the stream; 2 = the last kernel writes
@@ -416,8 +427,10 @@ size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H, int FF, i
  * the polling -- the caller asks tal_greedy_step_poll, which lets ONE host thread keep several sessions (one context and
  * one stream each) in flight. */
 int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int64_t n_gen, int sync, void* stream);
-/* 1: the context's latest sync 2 / 3 step has delivered; 0: not after wait_ms milliseconds (0 = one look); < 0: error. */
-int tal_greedy_step_poll(const tal_greedy_ctx* c, int wait_ms);
+/* 1: the context's latest sync 2 / 3 step has delivered; 0: not after wait_ms milliseconds (0 = one look); < 0: error -- TAL_EHIP
+ * when the step delivered the failure marker (token -1: the one-launch form's phase barrier gave up); the context is then marked
+ * (needs_reset) and its next step starts from a zeroed ticket block. */
+int tal_greedy_step_poll(tal_greedy_ctx* c, int wait_ms);
 /* The same step for G sessions (1 <= G <= 16) in SHARED launches: one chain of 34 launches advances every session by one token
  * (the decode loop of System.generate_unaligned is batch 1 -- .item() at tal/asr/system.py:331,411,417 --, so a corpus of
  * episodes is decoded as concurrent sessions; a chain of small dependent launches per session tops out at the device's four

@@ -397,7 +397,7 @@ def ngram_repeat_mask(xs, n):
 # ----------------------------------------------------------------------------
 def generate_unaligned(audio, generated, audio_lens, sd, eos=1, chunk_size=357, max_iters=1000000, max_positions=512,
                        thresh_prct=0.5, shift_prct=0.25, stall_patience=25, rep_n=5, skip_prct=0.1,
-                       n_layers=4, nhead=4, on_step=None):
+                       n_layers=4, nhead=4, on_step=None, lm=None, lm_weight=0.0, lm_clamp=None):
     """System.generate_unaligned (tal/asr/system.py:254-524) for ONE episode on the CPU, doing the work the reference
     does per generated token: the whole live prefix through all decoder layers (no cache: the loop decodes with
     causal_mask=False, :350-351), the memory window re-projected in every layer, the LM head over every prefix position
@@ -405,6 +405,9 @@ def generate_unaligned(audio, generated, audio_lens, sd, eos=1, chunk_size=357, 
     -> (token ids [n], recorded window starts [n-1], attention rows: list of [S] arrays).
     on_step(token, row, win, hist, n_tokens, finished): called after every step with the step's raw result and the state the
     control flow left behind (tests drive the product's host-side control flow with it).
+    lm / lm_weight / lm_clamp: the shallow-fusion branch (:368-384) -- lm(tokens [1, U], causal_mask=False) -> [1, U, vocab], called
+    on the prefix with ids clamped to lm_clamp = len(tokenizer) - 1; its last-position log-probabilities times lm_weight are added
+    on the shared part of the two vocabularies before the arg-max.
     Pinned by tests/golden/flow_unaligned*.npz, recorded from the reference's own function (tests/test_oracle_golden.py)."""
     audio = np.asarray(audio, dtype=np.float32).astype(np.float16).astype(np.float32)          # :285
     with torch.no_grad():
@@ -425,7 +428,13 @@ def generate_unaligned(audio, generated, audio_lens, sd, eos=1, chunk_size=357, 
             last = logits[:, -1, :]
             if torch.isnan(last).any():
                 raise Exception("Logits contain nans!")
-            picked = int(F.log_softmax(last, dim=-1).argmax(dim=-1)[0])                        # :366-387
+            logprobs = F.log_softmax(last, dim=-1)                                             # :366
+            if lm is not None and lm_weight > 0:                                               # :368-384
+                lm_in = torch.clamp(torch.as_tensor([prefix], dtype=torch.long), max=lm_clamp)
+                lm_lp = F.log_softmax(lm(lm_in, causal_mask=False)[:, -1, :].float(), dim=-1)
+                k = min(lm_lp.size(-1), logprobs.size(-1))
+                logprobs[:, :k] += lm_lp[:, :k] * lm_weight
+            picked = int(logprobs.argmax(dim=-1)[0])                                           # :386-387
             toks.append(picked)
             row = torch.stack(attn, dim=0).mean(dim=0)[0, -1]                                  # :392-397
             starts.append(win)

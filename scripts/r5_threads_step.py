@@ -32,7 +32,7 @@ for k in range(16):
     s.set_window({"encoder_out": enc["encoder_out"][:, sl].contiguous(), "encoder_padding_mask": enc["encoder_padding_mask"][:, sl].contiguous()})
     sessions.append(s)
 torch.cuda.synchronize()
-streams = hwqueues.spread(dev, 4)
+streams = hwqueues.spread(dev, 4)      # (leased for the life of this script)
 REPS = int(os.environ.get("REPS", "400"))
 
 

@@ -374,7 +374,9 @@ static size_t tds_buf_floats(const tal_tds_desc* d, int B, int64_t T) {
 // Clears the 64-byte status block of a call.  A kernel, not hipMemsetAsync: a memset node captured into a HIP graph replays
 // with a stale fill pattern on ROCm 7.2 (measured: the block came back holding two pointers, profiles/r4_short_clip_graph.txt),
 // which read as "out of fp16 range" on every replay of a captured SD call (tests/test_gpu_parity.py).
-__global__ void clear_status_kernel(int* __restrict__ status) { status[threadIdx.x] = 0; }
+// Word 1 receives the FORM the call writes y in (1: hi / lo split, TAL_TDS_OUT_SPLIT honoured; 0: fp32), decided by the call
+// itself from its real arguments and the options in force when it runs.
+__global__ void clear_status_kernel(int* __restrict__ status, int y_form = 0) { status[threadIdx.x] = threadIdx.x == 1 ? y_form : 0; }
 
 extern "C" size_t tal_tds_status_offset(const tal_tds_desc* d, int B, int64_t T) {
     if (!d || B <= 0 || T <= 0) return 0;
@@ -388,13 +390,14 @@ extern "C" size_t tal_tds_workspace_bytes(const tal_tds_desc* d, int B, int64_t 
 
 static int tds_fwd_impl(const tal_tds_desc* d, const float* x, const float* x_mean, int B, int64_t T, float* y, void* workspace,
                         size_t workspace_bytes, void* stream);
-static bool tds_last_stage_allsplit(const tal_tds_desc* d, int B, int64_t T);
+static bool tds_last_stage_allsplit(const tal_tds_desc* d, int B, int64_t T, const float* x0);
 
 // 1: a call with TAL_TDS_OUT_SPLIT in d->flags leaves y in the hi / lo split form (the last stage runs all-split: long inputs on
 // the fp16x3 kernels); 0: y is fp32 as always (short inputs, odd widths, the exact mode)
 extern "C" int tal_tds_out_split(const tal_tds_desc* d, int B, int64_t T) {
     if (check_desc(d) || B <= 0 || tal_tds_out_len(d, T) <= 0 || !(d->flags & TAL_TDS_OUT_SPLIT)) return 0;
-    return tds_last_stage_allsplit(d, B, T) ? 1 : 0;
+    // (a PREDICTION for a 16-byte aligned x under the options in force now; the call records what it did in its status block)
+    return tds_last_stage_allsplit(d, B, T, reinterpret_cast<const float*>(static_cast<uintptr_t>(16))) ? 1 : 0;
 }
 
 extern "C" int tal_tds_fwd(const tal_tds_desc* d, const float* x, int B, int64_t T, float* y, void* workspace,
@@ -437,7 +440,7 @@ static bool tds_stage_allsplit(const tal_tds_desc* d, int B, int64_t T, int i, c
 }
 // the last stage's form, with the input form it will see (the previous stage's output is split iff that stage and the matrix-core
 // resize conv between them allow it: the same chain of decisions tds_fwd_impl makes)
-static bool tds_last_stage_allsplit(const tal_tds_desc* d, int B, int64_t T) {
+static bool tds_last_stage_allsplit(const tal_tds_desc* d, int B, int64_t T, const float* x0) {
     const bool force_f32 = opt(OPT_TDS_EXACT_F32) != 0 || (d->flags & TAL_TDS_EXACT_F32) != 0;
     const bool no_allsplit = opt(OPT_TDS_FP32_ACTIVATIONS) != 0;
     bool cur_split = false;
@@ -445,8 +448,8 @@ static bool tds_last_stage_allsplit(const tal_tds_desc* d, int B, int64_t T) {
     bool allsplit = false;
     for (int i = 0; i < d->n_stages; ++i) {
         const int64_t To = conv_out_len(Tc);
-        // (stage 0 reads the caller's fp32 x; its alignment matters only to the 1 -> 10 kernel, which tal_tds_fwd checks again)
-        allsplit = tds_stage_allsplit(d, B, T, i, reinterpret_cast<const float*>(static_cast<uintptr_t>(16)), cur_split, force_f32, no_allsplit);
+        // (stage 0 reads the caller's fp32 x: its alignment matters to the 1 -> 10 kernel; later stages read workspace buffers)
+        allsplit = tds_stage_allsplit(d, B, T, i, i == 0 ? x0 : reinterpret_cast<const float*>(static_cast<uintptr_t>(16)), cur_split, force_f32, no_allsplit);
         const bool last_stage = i == d->n_stages - 1;
         const bool next_split = !last_stage && d->channels[i + 1] % 32 == 0 && tds_s2_mfma_ok(d, B, i + 1, To, force_f32) &&
                                 tds_stage_allsplit(d, B, T, i + 1, nullptr, true, force_f32, no_allsplit);
@@ -474,7 +477,10 @@ static int tds_fwd_impl(const tal_tds_desc* d, const float* x, const float* x_me
     const bool force_f32 = opt(OPT_TDS_EXACT_F32) != 0 || (d->flags & TAL_TDS_EXACT_F32) != 0;
     // status word: raised by any kernel that turns an fp32 value outside the finite fp16 range into hi / lo halves
     int* range_flag = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + tal_tds_status_offset(d, B, T));
-    clear_status_kernel<<<1, 16, 0, s>>>(range_flag);
+    // the form y will be written in, from the real x and the options of THIS call (tal_tds_out_split is a prediction made earlier,
+    // for an aligned x): recorded in word 1 of the status block, where the caller that consumes y in the split form checks it
+    const bool y_split_out = (d->flags & TAL_TDS_OUT_SPLIT) != 0 && tds_last_stage_allsplit(d, B, T, x);
+    clear_status_kernel<<<1, 16, 0, s>>>(range_flag, y_split_out ? 1 : 0);
     if (hipGetLastError() != hipSuccess) {
         set_error("tal_tds_fwd: cannot clear the status word");
         return TAL_EHIP;
@@ -582,6 +588,10 @@ static int tds_fwd_impl(const tal_tds_desc* d, const float* x, const float* x_me
         cur = a;
         Tc = To;
     }
+    if (cur_split != y_split_out) {      // (the two decision chains disagree: never silently)
+        set_error("tal_tds_fwd: internal: y was written %s but the status block says %s", cur_split ? "split" : "fp32", y_split_out ? "split" : "fp32");
+        return TAL_EINVAL;
+    }
     return TAL_OK;
 }
 
@@ -662,7 +672,11 @@ extern "C" size_t tal_tds_tiled_workspace_bytes(const tal_tds_desc* d, int64_t T
 
 extern "C" int tal_tds_tiled_fwd(const tal_tds_desc* d, const float* x, int64_t T, float* y, int64_t out_tile, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-    TAL_CHECK_ARG(x && y && workspace, "tal_tds_tiled_fwd: null pointer");
+    TAL_CHECK_ARG(x && y && workspace && d, "tal_tds_tiled_fwd: null pointer");
+    // tiles are stitched as fp32 rows: the split output form is not offered here, whatever the caller's flags say
+    tal_tds_desc fp32_out = *d;
+    fp32_out.flags &= ~(uint32_t)TAL_TDS_OUT_SPLIT;
+    d = &fp32_out;
     size_t so, tb;
     int64_t longest;
     int rc = tiled_layout(d, T, out_tile, &so, &tb, &longest);

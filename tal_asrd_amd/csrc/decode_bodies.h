@@ -598,6 +598,7 @@ struct LmPickArgs {
     float* out;              // {token, row [S] (, sequence word)}
     int64_t* token_out;
     unsigned host_seq;
+    const float* bias;       // [V] added to the logits before the arg-max (LM shallow fusion, system.py:368-384) or NULL
 };
 __device__ __forceinline__ void lm_pick_body(const LmPickArgs& q, const float* __restrict__ proj_t, int E, int K0,
                                              const float* __restrict__ emb, int V, int n_layers, int H, const unsigned bx, const unsigned gx) {
@@ -610,6 +611,7 @@ __device__ __forceinline__ void lm_pick_body(const LmPickArgs& q, const float* _
     float* __restrict__ out = q.out;
     int64_t* __restrict__ token_out = q.token_out;
     const unsigned host_seq = q.host_seq;
+    const float* __restrict__ bias = q.bias;
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [E] h | [K0] t | [128] logits
     float* hs = sm;
     float* ts = sm + E;
@@ -691,7 +693,7 @@ __device__ __forceinline__ void lm_pick_body(const LmPickArgs& q, const float* _
 #pragma unroll
             for (int ps = 0; ps < 8; ++ps) {
                 const int v = bx * LMP_ROWS + grp + 16 * ps;
-                lg[grp + 16 * ps] = v < V ? a[ps] : -INFINITY;
+                lg[grp + 16 * ps] = v < V ? (bias ? a[ps] + bias[v] : a[ps]) : -INFINITY;
             }
     } else {   // two threads per row, half of K0 each (K0 % 8 == 0)
         const int r = tid >> 1, half = tid & 1, Kh = K0 >> 1;
@@ -706,7 +708,7 @@ __device__ __forceinline__ void lm_pick_body(const LmPickArgs& q, const float* _
             }
         }
         a += __shfl_xor(a, 1, 64);
-        if (half == 0) lg[r] = v < V ? a : -INFINITY;
+        if (half == 0) lg[r] = v < V ? (bias ? a + bias[v] : a) : -INFINITY;
     }
     __syncthreads();
     if (tid < 64) {

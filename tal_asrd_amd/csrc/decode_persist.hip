@@ -45,7 +45,25 @@ struct PsBarrier {
     unsigned* err;
     unsigned G, phase;
     int tl;
+    float* out;              // the session's result buffer {token, row [S] (, sequence word)}: receives the failure marker
+    int S;
+    unsigned host_seq;
+    bool wg0;                // the session's first workgroup: writes the marker whenever it sees the step fail
 };
+// A step that cannot finish (a barrier wait gave up: its workgroups were not resident together, or one of them died) must not look
+// like a step that did: the FIRST workgroup to raise the error word writes the token -1 and, for a host-polled step, the sequence
+// word, so that the host's poll returns and finds the marker (tal_greedy_step_fwd / tal_greedy_step_poll then report TAL_EHIP and
+// the context's ticket block -- phase counters, error word, half-counted attention / split-K tickets -- is zeroed before its next
+// step).  Every workgroup checks the error word before, inside and after its wait, so none runs a phase behind a failed barrier;
+// the session's first workgroup writes the marker too when it finds the word raised (a word left raised by an earlier failure
+// has no first raiser in this launch).
+__device__ __forceinline__ void ps_mark(PsBarrier& b) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(b.out), 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (b.host_seq) __hip_atomic_store(reinterpret_cast<unsigned*>(b.out + 1 + b.S), b.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void ps_raise(PsBarrier& b) {
+    if (__hip_atomic_exchange(b.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) ps_mark(b);      // (the first to raise it)
+}
 // -> false: a wait gave up (or another workgroup's did): the caller leaves the kernel without delivering a result
 __device__ __forceinline__ bool ps_sync(PsBarrier& b) {
     __shared__ unsigned ok_sh;
@@ -58,16 +76,20 @@ __device__ __forceinline__ bool ps_sync(PsBarrier& b) {
         __hip_atomic_fetch_add(b.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = b.phase * b.G;
         const long long t0 = wall_clock64();
-        unsigned ok = 1u;
-        while (__hip_atomic_load(b.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        // (the error word is looked at before the wait too: a counter left at or beyond the target by a step that failed earlier
+        //  would let every wait fall through without ordering anything)
+        unsigned ok = __hip_atomic_load(b.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u ? 1u : 0u;
+        while (ok && __hip_atomic_load(b.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > 20000000ll ||                                     // 200 ms at 100 MHz
-                __hip_atomic_load(b.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                __hip_atomic_store(b.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wall_clock64() - t0 > 20000000ll) {                                     // 200 ms at 100 MHz
+                ps_raise(b);
                 ok = 0u;
-                break;
+            } else if (__hip_atomic_load(b.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                ok = 0u;
             }
         }
+        if (ok && __hip_atomic_load(b.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ok = 0u;
+        if (!ok && b.wg0) ps_mark(b);
 #ifdef PS_TIMELINE
         --b.phase; PS_STAMP(b, 2); ++b.phase;
 #endif
@@ -101,7 +123,7 @@ __global__ __launch_bounds__(256) void greedy_persist_kernel(const PsArgs a) {
     const int E = m.E, H = m.H, FF = m.FF, U = s.U, S = s.S, K0 = m.K0;
     const int64_t U4 = (U + 3) & ~3, S4 = (S + 3) & ~3;
     const float qscale = m.qscale;
-    PsBarrier bar{s.tickets + PS_BAR, s.tickets + PS_ERR, G, 0u, si == 0 ? (wg == 0 ? 0 : (wg == G - 1 ? 1 : -1)) : -1};
+    PsBarrier bar{s.tickets + PS_BAR, s.tickets + PS_ERR, G, 0u, si == 0 ? (wg == 0 ? 0 : (wg == G - 1 ? 1 : -1)) : -1, s.out, S, s.host_seq, wg == 0};
 
     // ---- embed (models.py:218-223)
     for (unsigned row = wg; row < (unsigned)U; row += G) {
@@ -186,6 +208,7 @@ __global__ __launch_bounds__(256) void greedy_persist_kernel(const PsArgs a) {
         q.out = s.out;
         q.token_out = s.token_out;
         q.host_seq = s.host_seq;
+        q.bias = nullptr;          // (a context with an LM row does not take the one-launch form: greedy_persist_ok)
         const unsigned gx = (unsigned)((m.V + LMP_ROWS - 1) / LMP_ROWS);
         for (unsigned bx = wg; bx < gx; bx += G) {
             lm_pick_body(q, m.proj_t, E, K0, m.emb, m.V, m.n_layers, H, bx, gx);

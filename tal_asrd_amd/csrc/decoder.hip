@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void log_softmax_row_block_kernel(const float*
 // the arithmetic of the softmax kernels' head average.
 __global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restrict__ x, int N, const float* __restrict__ attn,
                                                          int n_layers, int64_t layer_stride, int H, int64_t head_stride, int S,
-                                                         float* __restrict__ out, int64_t* __restrict__ token_out) {
+                                                         float* __restrict__ out, int64_t* __restrict__ token_out,
+                                                         const float* __restrict__ bias = nullptr) {
     __shared__ float red[4];
     __shared__ int redi[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -233,7 +234,8 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restric
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = threadIdx.x; i < N; i += 256) {
-        const float v = (x[i] - m) - lse;
+        float v = (x[i] - m) - lse;
+        if (bias) v += bias[i];          // (system.py:383-384: the LM's weighted log-probabilities on top of the decoder's)
         if (v > best || (v == best && i < bi)) {
             best = v;
             bi = i;
@@ -619,7 +621,7 @@ static int decoder_layer_small_multi(const tal_decoder_layer_w* w, const Session
 static bool greedy_persist_ok(const tal_greedy_ctx* c, int U, int S) {
     const int E = c->E, H = c->H, FF = c->FF, K0 = c->E0 > 0 ? c->E0 : c->E, hd = E / H;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    return c->tickets && c->n_layers <= TAL_PS_MAX_LAYERS && (hd == 128 || hd == 64) && E <= 512 && FF / 4 <= 512 && E % 64 == 0 &&
+    return c->tickets && !c->pick_bias && c->n_layers <= TAL_PS_MAX_LAYERS && (hd == 128 || hd == 64) && E <= 512 && FF / 4 <= 512 && E % 64 == 0 &&
            small_layer_applicable(1, U, S, E, H, FF, true) && S > 64 && attn_split_tickets(1, U, H) <= 64 && FF >= 2048 && FF % 256 == 0 &&
            64 + (E / 16) * ((U + 31) / 32) <= PS_BAR && E % 16 == 0 && K0 % 8 == 0 && al16(c->emb) && (!c->proj_t || al16(c->proj_t));
 }
@@ -843,7 +845,28 @@ extern "C" size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H
 
 // 1: the result of the context's latest host-direct step (sync 2 / 3) is in picked_host; 0: not yet, after waiting up to
 // wait_ms milliseconds (0: one look); < 0: bad argument.  Host-only: reads the sequence word the pick kernel writes last.
-extern "C" int tal_greedy_step_poll(const tal_greedy_ctx* c, int wait_ms) {
+// A context whose last step failed part-way (needs_reset) starts its next step from a zeroed ticket block, behind everything the
+// failed step may still have in flight.
+static int greedy_reset_if_needed(tal_greedy_ctx* c, hipStream_t s) {
+    if (!c->needs_reset) return TAL_OK;
+    if (hipStreamSynchronize(s) != hipSuccess ||
+        (c->tickets && hipMemsetAsync(c->tickets, 0, (size_t)TAL_GREEDY_TICKETS * sizeof(unsigned), s) != hipSuccess)) {
+        set_error("greedy step: could not reset the context's ticket block after a failed step: %s", hipGetErrorString(hipGetLastError()));
+        return TAL_EHIP;
+    }
+    c->needs_reset = 0;
+    return TAL_OK;
+}
+// the failure marker of the one-launch step (csrc/decode_persist.hip, ps_raise): token -1 in the result buffer
+static int greedy_failed_marker(tal_greedy_ctx* c, const char* who) {
+    if (reinterpret_cast<const volatile int*>(c->picked_host)[0] != -1) return TAL_OK;
+    c->needs_reset = 1;
+    set_error("%s: the one-launch decode step gave up at a phase barrier (its workgroups were not resident together, or one of them "
+              "died); no token was produced, the context's ticket block is reset before its next step", who);
+    return TAL_EHIP;
+}
+
+extern "C" int tal_greedy_step_poll(tal_greedy_ctx* c, int wait_ms) {
     TAL_CHECK_ARG(c && c->picked_host && c->S > 0 && wait_ms >= 0, "tal_greedy_step_poll: bad argument");
     volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(c->picked_host + 1 + c->S);
     const unsigned seq = c->seq;
@@ -855,6 +878,7 @@ extern "C" int tal_greedy_step_poll(const tal_greedy_ctx* c, int wait_ms) {
     }
     if (*flag != seq) return 0;
     std::atomic_thread_fence(std::memory_order_acquire);
+    if (greedy_failed_marker(c, "tal_greedy_step_poll")) return TAL_EHIP;
     return 1;
 }
 
@@ -877,6 +901,7 @@ extern "C" int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int
         return TAL_ENOMEM;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (int rr = greedy_reset_if_needed(c, s)) return rr;
     float* base = reinterpret_cast<float*>(c->workspace);
     LayerWs ws = carve(base, 1, U, S, E, H, FF);
     float* p = base + ws.total_floats;
@@ -920,12 +945,15 @@ extern "C" int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int
         q.host_seq = host_direct ? c->seq : 0u;
         int rc = launch_greedy_persist(a, s);
         if (rc) return rc;
+        // sync 0: the caller reads picked_dev itself -- a token of -1 there is the failure marker (include/tal_asrd.h); sync 3: the
+        // caller's tal_greedy_step_poll finds it
         if (sync == 3 || sync == 0) return TAL_OK;
         if (host_direct) {
             const int got = tal_greedy_step_poll(c, 20000);
             if (got == 1) return TAL_OK;
             if (got == 0) {
                 const hipError_t e = hipStreamSynchronize(s);
+                c->needs_reset = 1;          // (whatever it was: the counters of the phases that did run are still in the block)
                 set_error("tal_greedy_step_fwd: no result of the one-launch step after 20 s (stream after the wait: %s)", hipGetErrorString(e));
             }
             return TAL_EHIP;
@@ -935,7 +963,7 @@ extern "C" int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int
             set_error("tal_greedy_step_fwd: device-to-host copy failed: %s", hipGetErrorString(hipGetLastError()));
             return TAL_EHIP;
         }
-        return TAL_OK;
+        return greedy_failed_marker(c, "tal_greedy_step_fwd");
     }
     int rc = tal_embed_tokens_fwd(c->tokens + history_start, 1, U, c->emb, V, E0 > 0 ? E0 : E, E0 > 0 ? c->proj : nullptr, E, c->pe,
                                   c->max_len, h0, stream);
@@ -982,6 +1010,7 @@ extern "C" int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int
         q.out = host_direct ? c->picked_host_dev : c->picked_dev;
         q.token_out = c->tokens + n_gen;
         q.host_seq = host_direct ? seq : 0u;
+        q.bias = c->pick_bias;
         hipLaunchKernelGGL(lm_pick_kernel, dim3((unsigned)cdiv(V, LMP_ROWS)), dim3(256), (size_t)(E + K0 + LMP_ROWS) * sizeof(float), s, q,
                            E0 > 0 ? c->proj_t : nullptr, E, K0, c->emb, V, L, small ? H : 1);
         TAL_CHECK_LAUNCH("tal_greedy_step_fwd(lm head + pick)");
@@ -1005,10 +1034,10 @@ extern "C" int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int
     if (rc) return rc;
     if (small)
         hipLaunchKernelGGL(greedy_pick_kernel, dim3(1), dim3(256), 0, s, logits, V, probs, L, (int64_t)H * S, H, (int64_t)S, S,
-                           c->picked_dev, c->tokens + n_gen);
+                           c->picked_dev, c->tokens + n_gen, c->pick_bias);
     else
         hipLaunchKernelGGL(greedy_pick_kernel, dim3(1), dim3(256), 0, s, logits, V, avg + (size_t)(U - 1) * S, L, (int64_t)U * S, 1,
-                           (int64_t)0, S, c->picked_dev, c->tokens + n_gen);
+                           (int64_t)0, S, c->picked_dev, c->tokens + n_gen, c->pick_bias);
     TAL_CHECK_LAUNCH("tal_greedy_step_fwd(pick)");
     }
     if (sync) {       // (sync 2 without the merged kernels: the copy form)
@@ -1058,6 +1087,7 @@ extern "C" int tal_greedy_step_multi_fwd(tal_greedy_ctx* const* ctxs, const int6
         TAL_CHECK_ARG(tal_greedy_group_ok(c, history_start[i], n_gen[i]),
                       "tal_greedy_step_multi_fwd: session %d (prefix [%lld, %lld), window %d) does not take the merged kernels' forms: step it alone",
                       i, (long long)history_start[i], (long long)n_gen[i], c->S);
+        if (int rr = greedy_reset_if_needed(c, s)) return rr;
         const int U = (int)(n_gen[i] - history_start[i]), S = c->S;
         if (c->workspace_bytes < tal_greedy_step_workspace_bytes(U, S, E, H, FF, V, E0, L)) {
             set_error("tal_greedy_step_multi_fwd: session %d: workspace %zu < %zu bytes", i, c->workspace_bytes, tal_greedy_step_workspace_bytes(U, S, E, H, FF, V, E0, L));
@@ -1126,6 +1156,7 @@ extern "C" int tal_greedy_step_multi_fwd(tal_greedy_ctx* const* ctxs, const int6
         q.out = c->picked_host_dev;
         q.token_out = c->tokens + n_gen[i];
         q.host_seq = c->seq;
+        q.bias = c->pick_bias;
     }
     hipLaunchKernelGGL(lm_pick_multi_kernel, dim3((unsigned)cdiv(V, LMP_ROWS), (unsigned)G), dim3(256), (size_t)(E + K0 + LMP_ROWS) * sizeof(float), s, pk,
                        E0 > 0 ? c0->proj_t : nullptr, E, K0, c0->emb, V, L, H);

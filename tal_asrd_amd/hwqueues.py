@@ -9,6 +9,12 @@ share a queue run one after the other, not side by side -- System.transcribe_una
 `spread(device, k)` returns k streams on as many DIFFERENT hardware queues as there are, found by measurement, once per process and
 device: two short chains of spin kernels take the time of one when their streams sit on different queues and twice that when they
 share one.  Speed only: any set of streams is correct.
+
+The probe costs ~40 short timed looks (a few tens of milliseconds, with device-wide synchronisations) the first time a process asks;
+it measures by timing, so other GPU work running during it can mislead it: when its own baseline (one chain, three looks) is not
+stable, or the result is implausible, the pool is treated as ONE class and the probe is repeated at the next call instead of being
+cached.  Pooled streams are LEASED: `spread` hands a stream to one caller at a time (`release` gives them back); a second caller
+that overlaps the first gets the remaining pooled streams and then fresh ones, never a stream somebody else is running chains on.
 """
 import threading
 import time
@@ -17,6 +23,7 @@ import torch
 
 _lock = threading.Lock()
 _classes = {}            # device index -> list of queue classes, each a list of torch.cuda.Stream
+_leased = set()          # ids of pooled streams handed out by spread() and not yet released
 POOL = 12                # streams probed per device
 _SPIN = 60000            # spin-kernel length (device clock ticks, ~30 us)
 _CHAIN = 10
@@ -51,7 +58,10 @@ def classes(device):
                 return _classes[idx]
             for s in pool[:2]:
                 _timed(dev, [s])                                  # (first launches: code upload, clocks)
-            one = min(_timed(dev, [pool[0]]) for _ in range(3))
+            looks = [_timed(dev, [pool[0]]) for _ in range(3)]
+            one = min(looks)
+            if max(looks) > 1.5 * one:                            # the baseline itself is unstable (other work on the device):
+                return [pool]                                     # one class now, NOT cached -- the next call probes again
             out = []
             for s in pool:
                 for c in out:
@@ -62,24 +72,35 @@ def classes(device):
                         break
                 else:
                     out.append([s])
-            if len(out) > 8:                                      # (implausible: timing noise) -- treat the pool as one class
-                out = [pool]
+            if len(out) > 8:                                      # (implausible: timing noise) -- one class, probed again next time
+                return [pool]
         _classes[idx] = out
         return out
 
 
 def spread(device, k):
-    """k streams, dealt round-robin over the hardware queues (the first min(k, queues) of them pairwise on different queues)."""
+    """k streams, dealt round-robin over the hardware queues (the first min(k, queues) of them pairwise on different queues).
+    Pooled streams are leased to the caller until `release(streams)`; streams another caller holds are skipped."""
     cl = classes(device)
     order = []
-    depth = 0
-    while len(order) < k:
-        took = False
-        for c in cl:
-            if depth < len(c) and len(order) < k:
-                order.append(c[depth])
-                took = True
-        depth += 1
-        if not took:                                              # more streams asked for than probed: fresh ones
-            order.append(torch.cuda.Stream(device=torch.device(device)))
+    with _lock:
+        free = [[s for s in c if id(s) not in _leased] for c in cl]
+        depth = 0
+        while len(order) < k:
+            took = False
+            for c in free:
+                if depth < len(c) and len(order) < k:
+                    order.append(c[depth])
+                    _leased.add(id(c[depth]))
+                    took = True
+            depth += 1
+            if not took:                                          # more streams asked for than the pool has free: fresh ones
+                order.append(torch.cuda.Stream(device=torch.device(device)))
     return order
+
+
+def release(streams):
+    """Give leased streams back to the pool (fresh streams that never were in it are ignored)."""
+    with _lock:
+        for s in streams:
+            _leased.discard(id(s))

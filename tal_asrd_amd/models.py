@@ -69,11 +69,28 @@ def _note_parameter_registration(module, name, param):
         cell[0] += 1
 
 
-def _adopt(root):
-    """Give every module of `root`'s tree the tree's parameter-registration counter; -> the counter cell."""
+def _note_module_registration(module, name, child):
+    # a submodule attached (or replaced) after the tree was adopted: it joins the tree's counter, and the counter moves -- the
+    # cached parameter lists of the tree were built without it
+    cell = module.__dict__.get(_EPOCH_ATTR)
+    if cell is not None and child is not None:
+        for m in child.modules():
+            m.__dict__[_EPOCH_ATTR] = cell
+        cell[0] += 1
+
+
+def _install_hooks():
+    """Idempotent; called wherever a counter is read or handed out -- a module tree restored by torch.load / pickle in a fresh
+    process carries its cell in the modules' __dict__ without any constructor of this package having run."""
     if not _hook_installed[0]:
         torch.nn.modules.module.register_module_parameter_registration_hook(_note_parameter_registration)
+        torch.nn.modules.module.register_module_module_registration_hook(_note_module_registration)
         _hook_installed[0] = True
+
+
+def _adopt(root):
+    """Give every module of `root`'s tree the tree's parameter-registration counter; -> the counter cell."""
+    _install_hooks()
     cell = root.__dict__.get(_EPOCH_ATTR)
     if cell is None:
         cell = [0]
@@ -84,6 +101,7 @@ def _adopt(root):
 
 def param_epoch(root):
     """The tree's counter value (the tree is adopted on first use: modules built by other code, e.g. a deep copy, too)."""
+    _install_hooks()
     cell = root.__dict__.get(_EPOCH_ATTR)
     if cell is None:
         cell = _adopt(root)

@@ -220,9 +220,17 @@ class RangeCheck:
         self.y_split = y_split          # y holds the hi / lo split form (tds_forward(out_split=True)); an exact re-run writes fp32
 
     def flagged(self):
-        if self.desc.flags & N.TAL_TDS_EXACT_F32:
+        """One 8-byte read of the call's status block: word 0 = an activation left the fp16 range; word 1 = the form the call
+        wrote y in, which must be the form `y_split` promised the consumer (tal_tds_out_split is a prediction: another thread's
+        tal_set_option between the query and the call, or a misaligned x, changes what the call does -- never silently)."""
+        if self.desc.flags & N.TAL_TDS_EXACT_F32 and not self.y_split:
             return False
-        return int(self.ws[self.off:self.off + 4].view(torch.int32)[0]) != 0
+        flag, form = self.ws[self.off:self.off + 8].view(torch.int32).tolist()
+        if bool(form) != bool(self.y_split):
+            raise N.NativeError("tal_tds_fwd wrote its output in the %s form but its consumer was enqueued for the %s form "
+                                "(a kernel-selection option changed between tal_tds_out_split and the call?)"
+                                % ("split" if form else "fp32", "split" if self.y_split else "fp32"))
+        return flag != 0 and not (self.desc.flags & N.TAL_TDS_EXACT_F32)
 
     def rerun_exact(self):
         global range_fallbacks

@@ -159,6 +159,9 @@ class _GreedySession:
         return int(self.picked_np[:1].view(np.int32)[0]), self.picked_np[1:].copy()
 
 
+_TABLE_LOCK = threading.Lock()      # serialises "does the episode-wide K | V table fit?" + its allocation across runs
+
+
 class _UnalignedRun:
     """One episode's sliding-window greedy decode (System.generate_unaligned, tal/asr/system.py:254-524) as a state machine, so that
     the same decisions drive a session decoded alone and a session decoded in a group whose steps share their launches
@@ -212,18 +215,32 @@ class _UnalignedRun:
         # K | V of every encoder frame for every decoder layer, once per episode (windows become views: _GreedySession.set_episode)
         # -- whenever whole windows fit the episode; shorter episodes (python-slice windows that wrap) project window by window
         self.kv_all = self.kpm_all = None
-        if self.enc.shape[1] >= chunk_size and st.encoder_len >= chunk_size and self.EPISODE_TABLE and self._table_fits(model):
-            E = self.enc.shape[2]
-            self.kv_all = []
-            for layer in model.decoder.layers:
-                at = layer.multihead_attn
-                bias = torch.cat([at.in_proj_bias.detach()[E:2 * E], torch.zeros(E, dtype=torch.float32, device=dev)])   # (V's bias is added after P.V)
-                self.kv_all.append(ops.linear(self.enc[0], at.in_proj_weight.detach()[E:3 * E], bias))
-            self.kpm_all = self.mask[0].to(torch.uint8).contiguous()
+        if self.enc.shape[1] >= chunk_size and st.encoder_len >= chunk_size and self.EPISODE_TABLE:
+            # the fit decision and the allocations it licenses are ONE step under a lock: runs that start side by side (the worker
+            # threads of transcribe_unaligned_many) would otherwise each see the same free memory and each take a quarter of it.
+            # The table is optional, so running out of memory while building it is not an error either: the run falls back to
+            # window-by-window projection (same results).
+            with _TABLE_LOCK:
+                if self._table_fits(model):
+                    E = self.enc.shape[2]
+                    try:
+                        kv_all = []
+                        for layer in model.decoder.layers:
+                            at = layer.multihead_attn
+                            bias = torch.cat([at.in_proj_bias.detach()[E:2 * E], torch.zeros(E, dtype=torch.float32, device=dev)])   # (V's bias is added after P.V)
+                            kv_all.append(ops.linear(self.enc[0], at.in_proj_weight.detach()[E:3 * E], bias))
+                        self.kv_all = kv_all
+                        self.kpm_all = self.mask[0].to(torch.uint8).contiguous()
+                    except torch.cuda.OutOfMemoryError:
+                        kv_all = None
+                        self.kv_all = self.kpm_all = None
         self.gen_dev = torch.empty(max(self.DEV_TOKENS0, 2 * prime.size), dtype=torch.int64, device=dev)
         self.dev_len = -1                # how many tokens of the device copy of the stream are current (-1: none)
         self.session, self.session_window = None, None
         self._consume = N.lib().tal_unaligned_consume
+        # LM shallow fusion (system.py:368-384): lm_weight * log_softmax(lm(prefix)[-1]) is handed to the step as an additive row
+        self.lm_active = system.lm is not None and system.args.lm_weight > 0
+        self._lm_bias = None
 
     HOST_TOKENS0, DEV_TOKENS0 = 4096, 1024      # initial capacities of the token stream (host / device); both grow by doubling
     EPISODE_TABLE = True                        # False: every window is projected on its own (tal_cross_kv_fwd), as in round 3
@@ -315,14 +332,38 @@ class _UnalignedRun:
         if self.session is not None:
             self.session._stream = N.stream_handle()
 
+    def _lm_logprobs(self, y):
+        """system.py:368-384 on the live prefix y [1, U]: the LM never sees speaker tokens (clamped to len(tokenizer) - 1); its
+        last-position log-probabilities, times lm_weight -> [1, LM vocabulary].  The LM is the caller's module; the log-softmax
+        runs on the HIP row kernel."""
+        system = self.system
+        lm_input = torch.clamp(y, max=len(system.tokenizer) - 1)
+        lm_logits = system.lm(lm_input, causal_mask=False)[:, -1, :]
+        return log_softmax(lm_logits.float().contiguous()) * system.args.lm_weight
+
+    def _lm_bias_row(self, y, V):
+        """The additive row of tal_greedy_ctx.pick_bias for the step on prefix y: the weighted LM log-probabilities on the shared
+        part of the two vocabularies, 0 beyond it."""
+        lp = self._lm_logprobs(y)
+        if self._lm_bias is None:
+            self._lm_bias = torch.zeros(V, dtype=torch.float32, device=self.dev)
+        nl = min(lp.size(-1), V)
+        self._lm_bias[:nl] = lp[0, :nl]
+        return self._lm_bias
+
     def can_merge(self):
-        """May the next step run inside a merged launch (tal_greedy_group_ok)?  Never the first step (module API)."""
-        return self.st.it > 0 and bool(self.session.lib.tal_greedy_group_ok(self.session._ctx_ref, self.st.history_start, self.st.n))
+        """May the next step run inside a merged launch (tal_greedy_group_ok)?  Never the first step (module API); never with an
+        LM (its forward pass runs between the steps, on this side of the C ABI)."""
+        return self.st.it > 0 and not self.lm_active and bool(self.session.lib.tal_greedy_group_ok(self.session._ctx_ref, self.st.history_start, self.st.n))
 
     def step_alone(self):
         """The step on this session's own launches -> (token, attention row)."""
         st = self.st
         if st.it > 0:
+            if self.lm_active:
+                # (the device copy of the prefix is current: prepare() uploaded it, the previous step appended its token)
+                bias = self._lm_bias_row(self.gen_dev[st.history_start:st.n].view(1, -1), self.session.ctx.V)
+                self.session.ctx.pick_bias = bias.data_ptr()
             return self.session.step(st.history_start, st.n)
         # first step through the module API: validates the priming tokens (nn.Embedding raises on out-of-range
         # ids) and the logits (system.py:363-364)
@@ -333,6 +374,11 @@ class _UnalignedRun:
             all_w = model.decoder.src_attn_weights_all                              # [n_layers, B, U, S]
         if bool(torch.isnan(logits).any()):
             raise Exception("Logits contain nans!")
+        if self.lm_active:          # system.py:366-384 as written: log-probabilities, the LM's added on the shared vocabulary
+            logits = log_softmax(logits)
+            lp = self._lm_logprobs(y)
+            nl = min(lp.size(-1), logits.size(-1))
+            logits[:, :nl] += lp[:, :nl]
         # token = argmax(log_softmax(logits)) and the attention of the new token averaged over layers (heads
         # are already averaged by the softmax kernel): one launch, one D2H copy (system.py:366-399 does the
         # same arithmetic with a log_softmax, an argmax, a .cpu() per quantity and a numpy mean)
@@ -368,7 +414,7 @@ class System:
         self.args = SimpleNamespace(spk_weight=spk_weight, lm_weight=lm_weight)
         self.tokenizer = tokenizer if tokenizer is not None else SimpleNamespace(
             eos_token_id=eos_token_id, bos_token_id=bos_token_id, pad_token_id=pad_token_id)
-        # shallow fusion in `generate` (system.py:127-138): any caller-side module called as lm(tokens [rows, U], causal_mask=False)
+        # shallow fusion in `generate` (system.py:127-138) and `generate_unaligned` (:368-384): any caller-side module called as lm(tokens [rows, U], causal_mask=False)
         # -> logits [rows, U, vocab]; needs a tokenizer with __len__ (speaker tokens are clamped to len(tokenizer) - 1 for the LM)
         self.lm = lm
         # the module API keeps per-call results on the modules themselves (layer.src_attn_weights, the cached window K / V^T):
@@ -414,6 +460,10 @@ class System:
         Returns [(utterance dicts, generated, alignments)] in episode order, identical to the solo runs in either mode."""
         if not episodes:
             return []
+        if self.lm is not None and self.args.lm_weight > 0:
+            # the LM's forward pass runs between the steps in Python: sessions cannot share launches (the merged loop stays inside the
+            # library); they still overlap as one launch chain per session
+            group = 1
         if group is None and streams is None and len(episodes) >= 32:
             streams, group = 2, N.TAL_GROUP_MAX         # (a corpus: two chains of 16-session merged steps, 6.2x against 5.5x for 4 x 4)
         if group is None:
@@ -442,6 +492,7 @@ class System:
         n_workers = max(1, min(int(streams), (len(episodes) + group - 1) // group)) if group > 1 else 0
         # (group mode: its worker threads + the producer; otherwise one thread per session in flight)
         stream_pool = hwqueues.spread(dev, n_workers + 1 if group > 1 else max(1, min(int(streams), len(episodes))))
+        leased = list(stream_pool)
         pool_lock = threading.Lock()
 
         def own_stream():
@@ -574,10 +625,13 @@ class System:
             threads = [threading.Thread(target=producer, daemon=True)] + [threading.Thread(target=group_worker, daemon=True) for _ in range(n_workers)]
         else:
             threads = [threading.Thread(target=worker, daemon=True) for _ in range(max(1, min(int(streams), len(episodes))))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        try:
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            hwqueues.release(leased)
         if errors:
             i, e = errors[0]
             which = "episode %d" % i if isinstance(i, int) else "one of the episodes %s (decoded in one group)" % (list(i),)

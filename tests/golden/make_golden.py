@@ -6,7 +6,7 @@ Imports /root/reference through tests/golden/_refload.py, fills the reference
 modules with the deterministic synthetic weights of tal_asrd_amd.synth, runs
 them on CPU fp32 and stores inputs/expected outputs as small .npz/.json
 fixtures next to this script.  The fixtures are data; no reference source is
-stored.  Sections: keys unit sd asr decode gru flow
+stored.  Sections: the keys of SECTIONS at the bottom
 """
 import json
 import os
@@ -299,6 +299,63 @@ def sec_flow_lm(ns):
         save("flow_generate_lm_beam%d" % beam, **out)
 
 
+def sec_flow_unaligned_lm(ns):
+    """The LM shallow-fusion branch of System.generate_unaligned (tal/asr/system.py:368-384), recorded from the reference's own
+    function with the stand-in LM (tests/golden/_lm_standin.py), lm_weight 0.5, on the 150 s clip of `flow_unaligned`: the LM
+    sees the live prefix with speaker tokens clamped to len(tokenizer) - 1, its last-position log-probabilities are added to
+    the decoder's before the arg-max.  The fused decision margins are recorded; the fixture is only kept if the closest call is
+    wider than 1e-4 ("identical means identical")."""
+    import types
+    from tests.golden._lm_standin import StandInLM
+    System = ns.system.System
+    model = _asr_model(ns)
+
+    class Tok(types.SimpleNamespace):
+        def __len__(self):
+            return 10000
+    tok = Tok(eos_token_id=1, bos_token_id=0, pad_token_id=2)
+    lm = StandInLM().eval()
+    L = 2400000
+    audio = synth.synth_audio_batch(1, L, 4321).astype(np.float16).astype(np.float32)
+    margins, last = [], {}
+    dec, lm_fwd = model.decode, lm.forward
+
+    def spy_dec(y_prev, e, **k):
+        lg = dec(y_prev, e, **k)
+        last["dec"] = lg[0, -1]
+        return lg
+
+    def spy_lm(t, causal_mask=True):
+        lg = lm_fwd(t, causal_mask=causal_mask)
+        fused = torch.log_softmax(last["dec"], -1)
+        ll = torch.log_softmax(lg[0, -1].float(), -1)
+        fused[:ll.numel()] += ll[:fused.numel()] * 0.5
+        t2 = torch.topk(fused, 2).values
+        margins.append(float(t2[0] - t2[1]))
+        return lg
+    model.decode, lm.forward = spy_dec, spy_lm
+    me = types.SimpleNamespace(model=model, lm=lm, tokenizer=tok, args=types.SimpleNamespace(spk_weight=0.0, lm_weight=0.5))
+    gen, align = System.generate_unaligned(me, torch.from_numpy(audio), torch.full((1, 1), 1, dtype=torch.long),
+                                           torch.tensor([L]), max_iters=260, stall_patience=25)
+    model.decode, lm.forward = dec, lm_fwd
+    plain = np.load(os.path.join(HERE, "flow_unaligned.npz"))["generated"]
+    n = min(gen.shape[1], plain.shape[1])
+    print("flow_unaligned_lm:", gen.shape, "tokens that differ from the run without the LM:", int((gen.numpy()[0, :n] != plain[0, :n]).sum()),
+          "closest fused decisions:", np.sort(np.asarray(margins))[:4])
+    assert (gen.numpy()[0, :n] != plain[0, :n]).any(), "the fusion must change the decode, or the fixture pins nothing"
+    assert min(margins) > 1e-4, min(margins)
+    save("flow_unaligned_lm", audio_seed=4321, audio_len=L, max_iters=260, lm_weight=0.5, generated=gen.numpy(),
+         chunk_start=np.asarray([int(c[0]) for c, _ in align]),
+         attn=np.stack([a.numpy()[0] for _, a in align]).astype(np.float32)[::4], min_margin=float(min(margins)))
+
+
+def sec_sd_b4(ns):
+    """ONE reference SDModel call on a batch of four 60 s segments (the call-wide log-mel mean couples the items,
+    tal/asr/models.py:52): what each rank of BASELINE configs[3] must land on when the call is split over ranks and the mean is
+    restored from the combined (sum, count)."""
+    _sd_fixture(ns, "sd_b4_60s", synth.synth_audio_batch(4, 960000, 1234), n_rows=8)
+
+
 SPLICE_CASES = [
     (["the quick brown fox jumps over the lazy dog and runs", "over the lazy dog and runs away to the hills",
       "away to the hills where nobody ever goes"], 5),
@@ -536,7 +593,7 @@ def sec_half(ns):
     save("flow_generate_beam1_half", **out)
 
 
-SECTIONS = {"flow_lm": sec_flow_lm, "half": sec_half, "flow_short": sec_flow_short, "variants": sec_variants, "keys": sec_keys, "unit": sec_unit, "sd": sec_sd, "asr": sec_asr,
+SECTIONS = {"flow_lm": sec_flow_lm, "flow_unaligned_lm": sec_flow_unaligned_lm, "sd_b4": sec_sd_b4, "half": sec_half, "flow_short": sec_flow_short, "variants": sec_variants, "keys": sec_keys, "unit": sec_unit, "sd": sec_sd, "asr": sec_asr,
             "decode": sec_decode, "gru": sec_gru, "flow": sec_flow,
             "transcribe": sec_transcribe, "uisrnn": sec_uisrnn}
 

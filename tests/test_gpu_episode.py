@@ -237,6 +237,40 @@ def test_one_launch_step_equals_the_launch_chain_bit_for_bit(asr_weights):
                 t2, r2 = s.step(0, U)
                 assert t2 == tok and np.array_equal(r2, row) and int(s.gen_dev[U]) == appended, (wgs, U)
                 assert int(s._tickets.abs().sum()) == 0, (wgs, U)
+        # A step that cannot finish must say so: with the session's error word raised -- what a phase barrier that gave
+        # up leaves behind -- and a phase counter beyond every target, the step reports TAL_EHIP instead of returning a stale token
+        # (sync 2: the failure marker wakes the poll; sync 3: tal_greedy_step_poll finds it); the NEXT step on the context starts
+        # from a zeroed ticket block and is bit-identical again -- on the one-launch form and on the launch chain that shares the block.
+        s, U = sessions[1]
+        tok, row, appended = chain[1]
+        for how in ("step", "enqueue"):
+            s._tickets[254] = 1          # PS_ERR
+            s._tickets[252] = 1 << 20    # PS_BAR: every wait would fall through
+            s._tickets[70] = 3           # a half-counted split-K ticket
+            torch.cuda.synchronize()
+            if how == "step":
+                with pytest.raises(N.NativeError, match="gave up at a phase barrier"):
+                    s.step(0, U)
+            else:
+                s.enqueue(0, U)
+                with pytest.raises(N.NativeError, match="gave up at a phase barrier"):
+                    for _ in range(2000):
+                        if s.ready(10):
+                            break
+            assert s.ctx.needs_reset == 1
+            s.gen_dev[U] = -1
+            t2, r2 = s.step(0, U)
+            assert s.ctx.needs_reset == 0
+            assert t2 == tok and np.array_equal(r2, row) and int(s.gen_dev[U]) == appended
+            assert int(s._tickets.abs().sum()) == 0
+        s._tickets[254] = 1
+        torch.cuda.synchronize()
+        with pytest.raises(N.NativeError):
+            s.step(0, U)
+        N.set_option("decode_persist", 0)          # ... and the chain after a failed one-launch step
+        s.gen_dev[U] = -1
+        t2, r2 = s.step(0, U)
+        assert t2 == tok and np.array_equal(r2, row) and int(s.gen_dev[U]) == appended and int(s._tickets.abs().sum()) == 0
     finally:
         N.set_option("decode_persist", 0)
         N.set_option("decode_persist_wgs", 32)
@@ -304,3 +338,12 @@ def test_streams_are_spread_over_the_hardware_queues():
         assert len(got) == k and len({id(s) for s in got}) == k
         head = got[:min(k, len(cl))]
         assert len({next(i for i, c in enumerate(cl) if s in c) for s in head}) == len(head)
+        hwqueues.release(got)
+    # pooled streams are leased: two callers that overlap never share a stream, and a released stream is dealt again
+    a = hwqueues.spread(dev, 5)
+    b = hwqueues.spread(dev, 5)
+    c = hwqueues.spread(dev, 5)          # (the pool of 12 is used up: fresh streams)
+    assert len({id(s) for s in a + b + c}) == 15
+    hwqueues.release(a + b + c)
+    assert {id(s) for s in hwqueues.spread(dev, 5)} == {id(s) for s in a}
+    hwqueues.release(a)

@@ -112,6 +112,42 @@ def test_generate_unaligned_trajectory(asr_model):
     assert got_turns == want_turns
 
 
+def test_generate_unaligned_with_lm_shallow_fusion(asr_model):
+    """The LM branch of System.generate_unaligned (tal/asr/system.py:368-384) against a trajectory recorded from the reference's own
+    function with the stand-in LM: per step the LM sees the live prefix (speaker tokens clamped), lm_weight x its last-position
+    log-probabilities reach the fused LM-head + pick kernel as an additive row (tal_greedy_ctx.pick_bias).  Tokens and window
+    starts identical (closest recorded decision 2.7e-3), attention rows 1e-4; 163 of the 261 tokens differ from the run without
+    the LM, so the fixture pins the fusion."""
+    from tal_asrd_amd import synth
+    from tal_asrd_amd.system import System
+    from tal_asrd_amd.tokenizer import SynthTokenizer
+    from tests.golden._lm_standin import StandInLM
+    g = golden("flow_unaligned_lm")
+    L = int(g["audio_len"])
+    audio = synth.synth_audio_batch(1, L, int(g["audio_seed"])).astype(np.float16).astype(np.float32)
+    lm = StandInLM().eval().to(dev())
+    sys_ = System(asr_model, tokenizer=SynthTokenizer(10000), lm=lm, lm_weight=float(g["lm_weight"]))
+    x = torch.from_numpy(audio).to(dev())
+    prime = torch.ones(1, 1, dtype=torch.long, device=dev())
+    gen, align = sys_.generate_unaligned(x, prime, torch.tensor([L]), max_iters=int(g["max_iters"]), stall_patience=25)
+    np.testing.assert_array_equal(gen.cpu().numpy(), g["generated"])
+    np.testing.assert_array_equal(np.array([int(c[0]) for c, _ in align]), g["chunk_start"])
+    np.testing.assert_allclose(np.stack([a.numpy()[0] for _, a in align])[::4], g["attn"], atol=1e-4, rtol=0)
+    plain = golden("flow_unaligned")["generated"]
+    n = min(plain.shape[1], g["generated"].shape[1])
+    assert (g["generated"][0, :n] != plain[0, :n]).sum() > 50
+    # a weight of 0 is the plain decode (the branch is skipped as in the reference: `self.args.lm_weight > 0`)
+    gen0, _ = System(asr_model, tokenizer=SynthTokenizer(10000), lm=lm, lm_weight=0.0).generate_unaligned(
+        x, prime, torch.tensor([L]), max_iters=40, stall_patience=25)
+    genp, _ = System(asr_model).generate_unaligned(x, prime, torch.tensor([L]), max_iters=40, stall_patience=25)
+    np.testing.assert_array_equal(gen0.cpu().numpy(), genp.cpu().numpy())
+    # several episodes in flight with an LM: one launch chain per session (no merged steps), same trajectory as the solo run
+    solo, _ = sys_.generate_unaligned(x, prime, torch.tensor([L]), max_iters=60, stall_patience=25)
+    outs = sys_.transcribe_unaligned_many([(x, torch.tensor([L]))] * 2, streams=2, group=4, max_iters=60, stall_patience=25)
+    for _, gen2, _ in outs:
+        np.testing.assert_array_equal(gen2.cpu().numpy(), solo.cpu().numpy())
+    assert (solo.cpu().numpy()[0, :41] != genp.cpu().numpy()[0]).any()
+
 def test_generate_unaligned_episode_shorter_than_the_window(asr_model):
     """20 s episode = 233 encoder frames < the 357-frame window: the window start is clamped to a NEGATIVE value and the
     reference's python slices wrap (tal/asr/system.py:347-348,480); windows of 233 and then 124 frames, recorded values

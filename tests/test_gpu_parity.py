@@ -682,6 +682,51 @@ def test_sd_5min_golden(sd_model):
     _check_sd_golden(sd_model, "sd_5min", False)
 
 
+def test_sd_b4_golden_one_call(sd_model):
+    """ONE reference SDModel call on four 60 s segments (fixture recorded from the reference's own module): module API."""
+    _check_sd_golden(sd_model, "sd_b4_60s", False)
+
+
+def test_sd_b4_split_over_two_ranks_with_the_combined_mean(sd_model):
+    """What each rank of BASELINE configs[3] does (bench.py `--workload segments`), pinned to the REFERENCE: the four segments of one
+    reference call (`tal/asr/models.py:52` subtracts the mean of the whole call) are computed as 2 + 2 -- each half's log-mel
+    without the mean and its (sum, count), the two (sum, count) pairs added as the scalar all-reduce adds them
+    (distributed.allreduce_logmel_stats), `SDModel.speaker_ids_from_logmel(mel_half, call_mean)` -- and as one 4-segment call with
+    its own statistics.  Speaker ids identical to the reference's on all 4 x 733 frames, features within 1e-3."""
+    from tal_asrd_amd import distributed as D, ops, synth
+    g = golden("sd_b4_60s")
+    B, L = int(g["batch"]), int(g["audio_len"])
+    assert B == 4
+    audio = torch.from_numpy(synth.synth_audio_batch(B, L, int(g["audio_seed"]))).to(dev())
+    lm = sd_model.logmelspec
+    with torch.no_grad():
+        halves = [audio[0:2].contiguous(), audio[2:4].contiguous()]
+        parts = [ops.logmel(lm.plan(), h, eps=lm.eps, subtract_mean=False, return_stats=True) for h in halves]
+        st = parts[0][2] + parts[1][2]                      # the all-reduce over the two ranks
+        mean = D.allreduce_logmel_stats(st.clone())         # (one process: returns sum / count as the float32 scalar)
+        # the combined mean is the mean of the one-call log-mel
+        mel4, mean4, st4 = ops.logmel(lm.plan(), audio, eps=lm.eps, subtract_mean=False, return_stats=True)
+        assert float(st4[1]) == float(st[1])
+        assert abs(float(mean) - float(mean4)) <= 1e-6
+        # a half's own mean is a different number: the test would not notice a missing all-reduce otherwise
+        assert abs(float(parts[0][1]) - float(mean)) > 1e-4 or abs(float(parts[1][1]) - float(mean)) > 1e-4
+        feats, idss = [], []
+        for mel_h, _, _ in parts:
+            f, i = sd_model.speaker_ids_from_logmel(mel_h, mean)
+            feats.append(f)
+            idss.append(i)
+        feat, ids = torch.cat(feats, 0), torch.cat(idss, 0)
+        np.testing.assert_array_equal(ids.cpu().numpy(), g["ids"])
+        np.testing.assert_allclose(feat.cpu().numpy(), g["feat"], atol=LOGIT_TOL, rtol=0)
+        # the same call in one piece
+        f1, i1 = sd_model.speaker_ids_from_logmel(mel4, mean4)
+        np.testing.assert_array_equal(i1.cpu().numpy(), g["ids"])
+        np.testing.assert_allclose(f1.cpu().numpy(), g["feat"], atol=LOGIT_TOL, rtol=0)
+        # and with each half's OWN mean at least the features move (the coupling is real on this fixture)
+        f_own, _ = sd_model.speaker_ids_from_logmel(parts[0][0], parts[0][1])
+        assert float((f_own - feats[0]).abs().max()) > 1e-5
+
+
 def test_speaker_ids_fused_path(sd_model):
     """reconcile.get_speaker_ids form: ids without materialised logits == ids with logits."""
     from tal_asrd_amd import synth

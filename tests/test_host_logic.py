@@ -1,4 +1,6 @@
 """CPU tests of the host-side decode helpers and of the multi-GPU sharding logic."""
+import os
+
 import numpy as np
 
 from oracle import tal_oracle as O
@@ -175,3 +177,40 @@ def test_parameter_registration_counter_is_scoped_to_this_packages_modules():
     k0 = tds._param_key()
     conv.weight = nn.Parameter(conv.weight.detach().clone())
     assert tds._param_key() != k0                           # the cached list was rebuilt (new storage)
+
+
+def test_param_epoch_notices_late_submodules_and_survives_pickle(tmp_path):
+    """The counter behind the cached parameter lists (models.param_epoch): a submodule attached after construction joins the tree
+    and moves the counter; a Parameter replaced inside it moves it again; a tree restored by pickle in a FRESH process -- no
+    constructor of this package has run there -- still notices a replaced Parameter (the hooks are installed wherever the
+    counter is read)."""
+    import pickle
+    import subprocess
+    import sys
+    import textwrap
+    import torch
+    from tal_asrd_amd import models as M
+    m = M.TDSBlock(32, 21, 8)
+    e0 = M.param_epoch(m)
+    m.extra = torch.nn.Linear(3, 3)
+    assert M.param_epoch(m) == e0 + 1
+    m.extra.weight = torch.nn.Parameter(torch.zeros(3, 3))
+    assert M.param_epoch(m) == e0 + 2
+    p = tmp_path / "m.pkl"
+    with open(p, "wb") as f:
+        pickle.dump(m, f)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import sys, pickle
+        sys.path.insert(0, %r)
+        import torch
+        m = pickle.load(open(%r, "rb"))
+        from tal_asrd_amd import models as M
+        e = M.param_epoch(m)
+        conv = next(x for x in m.modules() if isinstance(x, torch.nn.Conv1d))
+        conv.weight = torch.nn.Parameter(conv.weight.detach().clone())
+        assert M.param_epoch(m) == e + 1, (e, M.param_epoch(m))
+        print("ok")
+    ''') % (root, str(p))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

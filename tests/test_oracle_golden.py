@@ -119,6 +119,11 @@ def test_sd_b2_ragged(sd_weights):
     _check_sd("sd_b2_ragged", sd_weights, True)
 
 
+def test_sd_b4_one_reference_call(sd_weights):
+    g = _check_sd("sd_b4_60s", sd_weights, False)
+    assert g["ids"].shape == (4, 733)
+
+
 def test_sd_5min(sd_weights):
     g = _check_sd("sd_5min", sd_weights, False)
     assert g["ids"].shape == (1, 3733)
@@ -202,3 +207,18 @@ def test_generate_unaligned_port(asr_weights, name):
     else:
         assert [r.shape[0] for r in rows] == g["attn_len"].tolist()
         np.testing.assert_allclose(np.concatenate(rows), g["attn_flat"], atol=1e-5, rtol=0)
+
+
+def test_generate_unaligned_port_with_lm(asr_weights):
+    """The port's shallow-fusion branch (tal/asr/system.py:368-384) against the trajectory recorded from the reference's own function
+    with the stand-in LM."""
+    from tests.golden._lm_standin import StandInLM
+    g = golden("flow_unaligned_lm")
+    L = int(g["audio_len"])
+    audio = synth.synth_audio_batch(1, L, int(g["audio_seed"]))
+    with torch.no_grad():
+        toks, starts, rows = O.generate_unaligned(audio, [[1]], [L], asr_weights, max_iters=int(g["max_iters"]), stall_patience=25,
+                                                  lm=StandInLM().eval(), lm_weight=float(g["lm_weight"]), lm_clamp=9999)
+    np.testing.assert_array_equal(toks, g["generated"][0])
+    np.testing.assert_array_equal(starts, g["chunk_start"])
+    np.testing.assert_allclose(np.stack(rows)[::4], g["attn"], atol=1e-5, rtol=0)

@@ -122,6 +122,7 @@ enum Option {
     OPT_DECODE_PERSIST,           // decode steps as ONE launch (csrc/decode_persist.hip) where the step's shapes allow: 0 = launch chain, 1 = one launch
     OPT_DECODE_PERSIST_WGS,       // workgroups per session of the one-launch step (default 32)
     OPT_LOGMEL_MFMA,              // log-mel as the float64 matrix-core DFT of rounds 1-4 instead of the fast transform on the vector ALU
+    OPT_GRU_UNFUSED,              // GRU cell as two dense launches + a gate kernel (rounds 1-5) instead of the one-launch step
     OPT_COUNT
 };
 int opt(Option o);

@@ -180,6 +180,44 @@ def test_core_rnn_golden():
     np.testing.assert_allclose(h.cpu().numpy(), g2["h3"], atol=2e-5, rtol=0)
 
 
+@pytest.mark.parametrize("B,In,H", [(1, 256, 512), (5, 256, 512), (16, 256, 512), (17, 256, 512), (64, 256, 512), (100, 256, 512),
+                                    (3, 512, 512), (7, 16, 32), (4, 48, 80)])
+def test_gru_cell_one_launch_against_float64_and_the_three_launch_form(B, In, H):
+    """tal_gru_cell_fwd as ONE launch (gru_step_kernel: both weight matrices streamed once, gate math on the MFMA tile's registers)
+    against torch.nn.GRUCell arithmetic in float64 (`tal/diarization/uisrnn/uisrnn.py:27-38`) and against the three-launch form of
+    rounds 1-5 (option gru_unfused): same results to fp32 rounding; row counts that are not multiples of the 16-row tile, the
+    second GRU layer's square shape, widths that are not multiples of 64."""
+    import ctypes as C
+    from tal_asrd_amd import _native as N, ops
+    g = torch.Generator().manual_seed(B * 1000 + In + H)
+    x, h = torch.randn(B, In, generator=g), torch.randn(B, H, generator=g) * 0.7
+    w_ih, w_hh = torch.randn(3 * H, In, generator=g) / In ** 0.5, torch.randn(3 * H, H, generator=g) / H ** 0.5
+    b_ih, b_hh = torch.randn(3 * H, generator=g) * 0.3, torch.randn(3 * H, generator=g) * 0.3
+    gi, gh = x.double() @ w_ih.double().T + b_ih.double(), h.double() @ w_hh.double().T + b_hh.double()
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    want = ((1 - z) * n + z * h.double()).numpy()
+    lib = N.lib()
+    d = [t.to(dev()).contiguous() for t in (x, h, w_ih, w_hh, b_ih, b_hh)]
+    nws = lib.tal_gru_cell_workspace_bytes(B, H)
+    ws = ops._ws(nws, dev())
+    got = {}
+    try:
+        for unfused in (0, 1):
+            N.set_option("gru_unfused", unfused)
+            out = torch.full((B + 1, H), 7.0, device=dev())          # (a guard row behind the last one)
+            N.check(lib.tal_gru_cell_fwd(*[N.ptr(t) for t in d[:2]], B, In, H, *[N.ptr(t) for t in d[2:]], N.ptr(out), N.ptr(ws), nws,
+                                         N.stream_handle()), "tal_gru_cell_fwd")
+            assert bool((out[B] == 7.0).all())
+            got[unfused] = out[:B].cpu().numpy()
+    finally:
+        N.set_option("gru_unfused", 0)
+    np.testing.assert_allclose(got[0], want, atol=2e-6, rtol=0)
+    np.testing.assert_allclose(got[1], want, atol=2e-6, rtol=0)
+    np.testing.assert_allclose(got[0], got[1], atol=2e-6, rtol=0)
+
+
 VARIANTS = {"1x_spk": dict(model_type="1x", num_speakers=6008, vocab_size=10000, use_speaker_head=True),
             "2x_tok": dict(model_type="2x", num_speakers=6008, vocab_size=10000, use_speaker_head=False),
             # embed_size=0 (tal/asr/models.py:104-117,243-246): no factorised embedding -- the `proj_t == nullptr` arms of the LM head

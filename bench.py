@@ -128,60 +128,79 @@ def self_launch(args):
     return max(abs(c) for c in codes)
 
 
+_SAMPLER_CHILD = r"""
+import sys, time
+idx, period = int(sys.argv[1]), float(sys.argv[2])
+try:
+    import amdsmi
+    amdsmi.amdsmi_init()
+    hs = amdsmi.amdsmi_get_processor_handles()
+    h = hs[idx if idx < len(hs) else 0]
+except BaseException as e:
+    print("ERR %s: %s" % (type(e).__name__, str(e)[:120]), flush=True)
+    sys.exit(0)
+def num(v):
+    return float(v) if isinstance(v, (int, float)) and 0 < v < 65535 else None
+print("OK", flush=True)
+import select
+while True:
+    if select.select([sys.stdin], [], [], period)[0]:
+        break                                   # the parent closed (or wrote to) our stdin: done
+    try:
+        m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+        clks = [c for c in (num(v) for v in (m.get("current_gfxclks") or [])) if c is not None]
+        sclk = sum(clks) / len(clks) if clks else (num(m.get("current_gfxclk")) or num(m.get("average_gfxclk_frequency")))
+        power = num(m.get("current_socket_power")) or num(m.get("average_socket_power"))
+        print("%.6f %s %s" % (time.time(), sclk, power), flush=True)
+    except BaseException:
+        pass
+"""
+
+
 class ClockSampler:
-    """Shader clock and socket power of one GPU, sampled by a host thread while a timed pass runs (amdsmi: the driver's
-    gpu_metrics table, no HIP call, nothing enqueued on the device).  The dense layers of the headline step are power-limited
+    """Shader clock and socket power of one GPU while the timed passes run, sampled by a CHILD PROCESS (amdsmi: the driver's
+    gpu_metrics table; the child never touches HIP, enqueues nothing on the device and -- unlike a thread of this process, which
+    round 6 measured at up to +2 % on a pass -- cannot hold this interpreter's lock while a step's launch is due).  Samples carry
+    wall-clock stamps; `window(t0, t1)` averages those inside a pass.  The dense layers of the headline step are power-limited
     (1.4-1.9 GHz of 2.4 sustained), so box-to-box and pass-to-pass differences of `value` show up here."""
 
-    def __init__(self, device_index=0, period_s=0.02):
-        self.period, self.h, self.why = period_s, None, None
+    def __init__(self, device_index=0, period_s=0.01):
+        self.proc, self.why, self.samples = None, None, None
         try:
-            import amdsmi
-            self.smi = amdsmi
-            amdsmi.amdsmi_init()
-            hs = amdsmi.amdsmi_get_processor_handles()
-            self.h = hs[device_index if device_index < len(hs) else 0]
-            self._read()
+            self.proc = subprocess.Popen([sys.executable, "-c", _SAMPLER_CHILD, str(int(device_index)), str(period_s)],
+                                         stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            first = self.proc.stdout.readline().strip()
+            if first != "OK":
+                self.why = first or "the sampler child exited"
+                self.close()
         except BaseException as e:      # noqa: B902 -- measurement garnish: never fatal
-            self.h, self.why = None, "%s: %s" % (type(e).__name__, str(e)[:120])
+            self.why = "%s: %s" % (type(e).__name__, str(e)[:120])
+            self.proc = None
 
-    @staticmethod
-    def _num(v):
-        return float(v) if isinstance(v, (int, float)) and 0 < v < 65535 else None
-
-    def _read(self):
-        m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
-        clks = [c for c in (self._num(v) for v in (m.get("current_gfxclks") or [])) if c is not None]
-        sclk = sum(clks) / len(clks) if clks else self._num(m.get("current_gfxclk")) or self._num(m.get("average_gfxclk_frequency"))
-        power = self._num(m.get("current_socket_power")) or self._num(m.get("average_socket_power"))
-        return sclk, power
-
-    def start(self):
-        if self.h is None:
+    def close(self):
+        """Stop the child and read what it sampled."""
+        if self.proc is None:
             return
-        import threading
-        self.samples, self._stop = [], threading.Event()
+        try:
+            out, _ = self.proc.communicate(input="\n", timeout=10)
+        except BaseException:      # noqa: B902
+            self.proc.kill()
+            out = ""
+        self.proc = None
+        self.samples = []
+        for ln in out.splitlines():
+            p = ln.split()
+            if len(p) == 3:
+                self.samples.append((float(p[0]), None if p[1] == "None" else float(p[1]), None if p[2] == "None" else float(p[2])))
 
-        def loop():
-            while not self._stop.is_set():
-                try:
-                    self.samples.append(self._read())
-                except BaseException:      # noqa: B902
-                    pass
-                self._stop.wait(self.period)
-        self._t = threading.Thread(target=loop, daemon=True)
-        self._t.start()
-
-    def stop(self):
-        """-> {"sclk_mhz": mean, "sclk_mhz_min": ..., "power_w": mean, "samples": n} of the samples since start()."""
-        if self.h is None:
+    def window(self, t0, t1):
+        """-> {"sclk_mhz": mean, "sclk_mhz_min": ..., "power_w": mean, "samples": n} of the samples stamped in [t0, t1] (time.time())."""
+        if self.samples is None or self.why:
             return {"sclk_mhz": None, "power_w": None, "samples": 0, "unavailable": self.why}
-        self._stop.set()
-        self._t.join()
-        sc = [s for s, _ in self.samples if s is not None]
-        pw = [p for _, p in self.samples if p is not None]
+        sc = [s for t, s, _ in self.samples if t0 <= t <= t1 and s is not None]
+        pw = [p for t, _, p in self.samples if t0 <= t <= t1 and p is not None]
         return {"sclk_mhz": sum(sc) / len(sc) if sc else None, "sclk_mhz_min": min(sc) if sc else None,
-                "power_w": sum(pw) / len(pw) if pw else None, "samples": len(self.samples)}
+                "power_w": sum(pw) / len(pw) if pw else None, "samples": len(sc)}
 
 
 def build_sd_model(dev):
@@ -777,19 +796,21 @@ def main():
         # one bracketed by barrier + synchronize and max-reduced over the ranks; `value` is the MEDIAN pass (one pass is a draw: the
         # step is power-limited and round 5's single pass landed 8 % off the same process's next one).  The roofline numbers come from
         # a further pass of the same K steps with the events (they cost a little host and queue time inside the region they measure).
-        sampler = None if (args.no_clock_sampler or fake or rank != 0) else ClockSampler(local if world > 1 else 0)
-        pass_s, pass_clk = [], []
+        sampler = None if (args.no_clock_sampler or fake or rank != 0) else ClockSampler(dev.index or 0)
+        pass_s, pass_win = [], []
         for _ in range(max(1, args.passes)):
-            if sampler is not None:
-                sampler.start()
+            w0 = time.time()
             dt_p = timed_pass(False)
-            if sampler is not None:
-                pass_clk.append(sampler.stop())
+            pass_win.append((w0, time.time()))
             if dist is not None:
                 t = torch.tensor([dt_p], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt_p = float(t.item())
             pass_s.append(dt_p)
+        pass_clk = []
+        if sampler is not None:
+            sampler.close()
+            pass_clk = [sampler.window(a, b) for a, b in pass_win]
         order = sorted(range(len(pass_s)), key=lambda i: pass_s[i])
         med = order[(len(order) - 1) // 2]          # (the lower median for an even count: never an average of two passes)
         elapsed = pass_s[med]

@@ -36,7 +36,8 @@ class TdsDesc(C.Structure):
 class DecoderLayerW(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ca_in_w", "ca_in_b",
                                           "ca_out_w", "ca_out_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b")] + \
-               [("resweight", C.c_float), ("resweight_src", C.c_float)]
+               [("resweight", C.c_float), ("resweight_src", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("fold_sa_w", "fold_sa_b", "fold_ca_w", "fold_ca_b")]
 
 
 class GreedyCtx(C.Structure):

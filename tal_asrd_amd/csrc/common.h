@@ -123,6 +123,7 @@ enum Option {
     OPT_DECODE_PERSIST_WGS,       // workgroups per session of the one-launch step (default 32)
     OPT_LOGMEL_MFMA,              // log-mel as the float64 matrix-core DFT of rounds 1-4 instead of the fast transform on the vector ALU
     OPT_GRU_UNFUSED,              // GRU cell as two dense launches + a gate kernel (rounds 1-5) instead of the one-launch step
+    OPT_DECODE_NO_FOLD,           // latency-oriented decoder layer on its eight launches even when the folded weights are there (six)
     OPT_COUNT
 };
 int opt(Option o);
@@ -256,6 +257,12 @@ struct SkinnyArgs {
     int ksplit;
     float* sk_part;
     unsigned* sk_tickets;
+    // A in TWO column segments (round 6, the folded decoder layers): k < K1 comes from A (pitch lda), k >= K1 from A2 (pitch lda2)
+    // at column k - K1; a wave's K slice never straddles K1 (K1 is a multiple of every slice width).  A2 == NULL: one segment.
+    const float* A2;
+    int64_t lda2;
+    int K1;
+    int relu_begin;   // mode 1: the relu applies to columns >= relu_begin only (0 = all)
 };
 
 struct AttnArgs {

@@ -50,10 +50,12 @@ __device__ __forceinline__ void skinny_gemm_body(const SkinnyArgs& g, const Blk 
     const int kofs = ((int)blk.z * NW + w) * Kw;
     const float* wp = g.W + (int64_t)(n0 + r16) * g.ldw + kofs + 4 * kq;
     const float* ap[MT];
+    const bool seg2 = g.A2 && kofs >= g.K1;         // (wave-uniform: this wave's K slice lies in the second column segment of A)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int row = m0 + mt * 16 + r16;
-        ap[mt] = g.A + (int64_t)(row < g.M ? row : g.M - 1) * g.lda + kofs + 4 * kq;
+        const int64_t rc = row < g.M ? row : g.M - 1;
+        ap[mt] = seg2 ? g.A2 + rc * g.lda2 + (kofs - g.K1) + 4 * kq : g.A + rc * g.lda + kofs + 4 * kq;
     }
     f32x4 acc[MT];
 #pragma unroll
@@ -137,7 +139,7 @@ __device__ __forceinline__ void skinny_gemm_body(const SkinnyArgs& g, const Blk 
     if (t >= MT * 64 || m >= g.M) return;
     const int col = n0 + 4 * c4;
     if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
-    if (MODE == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (MODE == 1 && col >= g.relu_begin) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (MODE == 2) v = *reinterpret_cast<const f32x4*>(g.res + (int64_t)m * g.ldres + col) + g.alpha * v;
     if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) v = g.alpha * v;
     if (g.Yt && col >= g.vt_begin) {

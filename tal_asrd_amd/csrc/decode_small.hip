@@ -53,10 +53,12 @@ __device__ __forceinline__ void skinny_gemm_wide_body(const SkinnyArgs& g, const
     const int Kw = g.K / (NW * KS);
     const int kofs = ((int)blk.z * NW + w) * Kw;
     f32x4 av[MT][UNR], bw[2][UNR];
+    const bool seg2 = g.A2 && kofs >= g.K1;         // (as in skinny_gemm_body: the second column segment of A)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int row = m0 + mt * 16 + r16;
-        const float* ap = g.A + (int64_t)(row < g.M ? row : g.M - 1) * g.lda + kofs + 4 * kq;
+        const int64_t rc = row < g.M ? row : g.M - 1;
+        const float* ap = seg2 ? g.A2 + rc * g.lda2 + (kofs - g.K1) + 4 * kq : g.A + rc * g.lda + kofs + 4 * kq;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) av[mt][u] = *reinterpret_cast<const f32x4*>(ap + u * 16);
     }
@@ -141,7 +143,7 @@ __device__ __forceinline__ void skinny_gemm_wide_body(const SkinnyArgs& g, const
             const int col = (nb0 + nt) * 16 + 4 * c4;
             f32x4 o = v[nt];
             if (g.bias) o += *reinterpret_cast<const f32x4*>(g.bias + col);
-            if (MODE == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (MODE == 1 && col >= g.relu_begin) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             if (MODE == 2) o = *reinterpret_cast<const f32x4*>(g.res + (int64_t)m * g.ldres + col) + g.alpha * o;
             if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) o = g.alpha * o;
             if (g.Yt && col >= g.vt_begin) {
@@ -170,7 +172,10 @@ bool skinny_gemm_applicable(const SkinnyArgs& g) {
     if (g.ksplit > 1 && (!g.sk_part || !g.sk_tickets || g.K % (64 * g.ksplit) != 0)) return false;
     return g.M >= 1 && g.M <= 512 && g.N % 16 == 0 && g.K % 64 == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0 && g.ldy % 4 == 0 &&
            al16(g.A) && al16(g.W) && al16(g.Y) && (!g.bias || al16(g.bias)) && (!g.res || (al16(g.res) && g.ldres % 4 == 0)) &&
-           (!g.Yt || g.vt_begin % 16 == 0);
+           (!g.Yt || g.vt_begin % 16 == 0) &&
+           // two column segments of A: the boundary must fall between the K slices of every form (a wave's slice is K / (NW ksplit), NW <= 16)
+           (!g.A2 || (al16(g.A2) && g.lda2 % 4 == 0 && g.K1 > 0 && g.K1 < g.K && g.K1 % 256 == 0 && (g.K - g.K1) % 256 == 0 && g.ksplit <= 1)) &&
+           g.relu_begin % 16 == 0;
 }
 
 template <int MODE, int NW>
@@ -213,6 +218,16 @@ static void launch_skinny_multi_nw(const ArgPack<SkinnyArgs>& p, int mmax, int K
                            (int64_t)(p.a[0].N / (16 * NT)) * row_tiles * KS * 4 >= 3 * (int64_t)device_cus()))) {
         const dim3 grid((unsigned)(p.a[0].N / (16 * NT)), (unsigned)((mmax + 31) / 32), (unsigned)(KS * p.n));
         hipLaunchKernelGGL((skinny_gemm_wide_multi_kernel<MODE, 2, 4, NT>), grid, dim3(256), 0, s, p, KS);
+        return;
+    }
+    // the folded decoder layers' K = 1024 (eight waves of 128): the same form with two column blocks per workgroup (its partial
+    // tiles fill the 64 KB of static LDS at four)
+    constexpr int NT8 = 2;
+    if (k == 1024 && KS == 1 && p.a[0].N % (16 * NT8) == 0 && mmax > 16 && wide_opt != 1 &&
+        (wide_opt == 2 || ((int64_t)(p.a[0].N / 16) * row_tiles >= 2 * (int64_t)device_cus() &&
+                           (int64_t)(p.a[0].N / (16 * NT8)) * row_tiles * 4 >= 3 * (int64_t)device_cus()))) {
+        const dim3 grid((unsigned)(p.a[0].N / (16 * NT8)), (unsigned)((mmax + 31) / 32), (unsigned)p.n);
+        hipLaunchKernelGGL((skinny_gemm_wide_multi_kernel<MODE, 2, 8, NT8>), grid, dim3(512), 0, s, p, KS);
         return;
     }
     if (k >= 2048 && k % 256 == 0) launch_skinny_multi_mt<MODE, 16>(p, mmax, KS, s);

@@ -404,6 +404,8 @@ struct LayerWs {
     float* x1;   // [B, U, E]
     float* x2;   // [B, U, E]
     float* ff;   // [B, U, FF]
+    float* y3;   // [B, U, 2E]      folded layer: x1 | q_c
+    float* y5;   // [B, U, E + FF]  folded layer: x2 | ff
     size_t total_floats;
 };
 
@@ -422,6 +424,8 @@ static LayerWs carve(float* base, int B, int U, int S, int E, int H, int FF) {
     w.x1 = take((size_t)B * U * E);
     w.x2 = take((size_t)B * U * E);
     w.ff = take((size_t)B * U * FF);
+    w.y3 = take((size_t)B * U * 2 * E);
+    w.y5 = take((size_t)B * U * (E + FF));
     w.total_floats = o;
     return w;
 }
@@ -435,6 +439,11 @@ static SkinnyArgs skinny(const float* A, int64_t lda, const float* W, const floa
     g.lda = lda; g.ldw = K; g.ldy = ldy; g.ldres = ldy;
     g.alpha = alpha;
     return g;
+}
+
+// does this layer run in the folded form (6 launches)?  All sessions of a merged step share the layer structs, hence the answer.
+static bool layer_folded(const tal_decoder_layer_w* w) {
+    return w->fold_sa_w && w->fold_sa_b && w->fold_ca_w && w->fold_ca_b && !opt(OPT_DECODE_NO_FOLD);
 }
 
 static bool small_layer_applicable(int B, int U, int S, int E, int H, int FF, bool have_kv_cache) {
@@ -490,14 +499,30 @@ static int decoder_layer_small(const tal_decoder_layer_w* w, const float* tgt, i
     a.U = U; a.S = U; a.H = H;
     rc = launch_attn_small(a, B, hd, s);
     if (rc) return rc;
-    rc = launch_skinny_gemm(skinny(ws.mha.ctx, E, w->sa_out_w, w->sa_out_b, tgt, ws.x1, E, M, E, E, w->resweight), 2, s);
-    if (rc) return rc;
-    // cross attention over the cached K / V^T of the encoder window
-    float* qc = ws.mha.q;
-    rc = launch_skinny_gemm(skinny(ws.x1, E, w->ca_in_w, w->ca_in_b, nullptr, qc, E, M, E, E, qscale), 3, s);
-    if (rc) return rc;
+    // Folded form (tal_decoder_layer_w.fold_*): the self-attention's out-projection + ReZero and the cross-attention's q projection are
+    // ONE dense layer over [ctx | tgt] (x1 | q_c side by side in y3), and so are the cross-attention's out-projection + ReZero and
+    // FFN-1 over [ctx2 | x1] (x2 | ff in y5): 6 dependent launches per layer instead of 8.
+    const bool fold = layer_folded(w);
+    const float* qc;
+    int64_t ldq;
+    if (fold) {
+        SkinnyArgs g3 = skinny(ws.mha.ctx, E, w->fold_sa_w, w->fold_sa_b, nullptr, ws.y3, 2 * E, M, 2 * E, 2 * E, 0.f);
+        g3.A2 = tgt; g3.lda2 = E; g3.K1 = E;
+        rc = launch_skinny_gemm(g3, 0, s);
+        if (rc) return rc;
+        qc = ws.y3 + E;
+        ldq = 2 * E;
+    } else {
+        rc = launch_skinny_gemm(skinny(ws.mha.ctx, E, w->sa_out_w, w->sa_out_b, tgt, ws.x1, E, M, E, E, w->resweight), 2, s);
+        if (rc) return rc;
+        // cross attention over the cached K / V^T of the encoder window
+        rc = launch_skinny_gemm(skinny(ws.x1, E, w->ca_in_w, w->ca_in_b, nullptr, ws.mha.q, E, M, E, E, qscale), 3, s);
+        if (rc) return rc;
+        qc = ws.mha.q;
+        ldq = E;
+    }
     AttnArgs c = {};
-    c.q = qc; c.ldq = E; c.q_bs = (int64_t)U * E;
+    c.q = qc; c.ldq = ldq; c.q_bs = (int64_t)U * ldq;
     c.k = ck; c.ldk = k_pitch ? k_pitch : E; c.k_bs = (int64_t)S * c.ldk;      // (k_pitch: the window is a view of an episode-wide K | V table)
     c.vt = cvt; c.ldvt = S4; c.vt_bs = (int64_t)E * S4;
     c.vbias = w->ca_in_b + 2 * E;
@@ -516,12 +541,24 @@ static int decoder_layer_small(const tal_decoder_layer_w* w, const float* tgt, i
         rc = launch_head_average(ws.mha.scores, xattn_avg, B, H, U, S, s);
         if (rc) return rc;
     }
-    rc = launch_skinny_gemm(skinny(ws.mha.ctx, E, w->ca_out_w, w->ca_out_b, ws.x1, ws.x2, E, M, E, E, w->resweight_src), 2, s);
-    if (rc) return rc;
-    // feed-forward
-    rc = launch_skinny_gemm(skinny(ws.x2, E, w->lin1_w, w->lin1_b, nullptr, ws.ff, FF, M, FF, E, 0.f), 1, s);
-    if (rc) return rc;
-    SkinnyArgs f2 = skinny(ws.ff, FF, w->lin2_w, w->lin2_b, ws.x2, out, E, M, E, FF, w->resweight);
+    SkinnyArgs f2;
+    if (fold) {
+        SkinnyArgs g5 = skinny(ws.mha.ctx, E, w->fold_ca_w, w->fold_ca_b, nullptr, ws.y5, E + FF, M, E + FF, 2 * E, 0.f);
+        g5.A2 = ws.y3; g5.lda2 = 2 * E; g5.K1 = E;          // x1 = the first E columns of y3
+        g5.relu_begin = E;                                   // x2 plain, ff through the relu
+        rc = launch_skinny_gemm(g5, 1, s);
+        if (rc) return rc;
+        f2 = skinny(ws.y5 + E, E + FF, w->lin2_w, w->lin2_b, ws.y5, out, E, M, E, FF, w->resweight);
+        f2.ldw = FF;
+        f2.ldres = E + FF;
+    } else {
+        rc = launch_skinny_gemm(skinny(ws.mha.ctx, E, w->ca_out_w, w->ca_out_b, ws.x1, ws.x2, E, M, E, E, w->resweight_src), 2, s);
+        if (rc) return rc;
+        // feed-forward
+        rc = launch_skinny_gemm(skinny(ws.x2, E, w->lin1_w, w->lin1_b, nullptr, ws.ff, FF, M, FF, E, 0.f), 1, s);
+        if (rc) return rc;
+        f2 = skinny(ws.ff, FF, w->lin2_w, w->lin2_b, ws.x2, out, E, M, E, FF, w->resweight);
+    }
     if (sk && FF >= 2048 && FF % 256 == 0 && (E / 16) * ((M + 31) / 32) <= TAL_GREEDY_TICKETS - 64) {
         // K = FF is deep: four workgroups per tile, each pulling a quarter of the operands (tickets 64 .. 254)
         f2.ksplit = 4;
@@ -577,17 +614,28 @@ static int decoder_layer_small_multi(const tal_decoder_layer_w* w, const Session
     }
     rc = launch_attn_small_multi(a, G, hd, s);
     if (rc) return rc;
-    for (int i = 0; i < G; ++i) g[i] = skinny(io[i].ws.mha.ctx, E, w->sa_out_w, w->sa_out_b, io[i].tgt, io[i].ws.x1, E, io[i].U, E, E, w->resweight);
-    rc = launch_skinny_gemm_multi(g, G, 2, s);
-    if (rc) return rc;
-    for (int i = 0; i < G; ++i) g[i] = skinny(io[i].ws.x1, E, w->ca_in_w, w->ca_in_b, nullptr, io[i].ws.mha.q, E, io[i].U, E, E, qscale);
-    rc = launch_skinny_gemm_multi(g, G, 3, s);
-    if (rc) return rc;
+    const bool fold = layer_folded(w);           // (the same arguments per session as decoder_layer_small builds: bit-identical)
+    if (fold) {
+        for (int i = 0; i < G; ++i) {
+            g[i] = skinny(io[i].ws.mha.ctx, E, w->fold_sa_w, w->fold_sa_b, nullptr, io[i].ws.y3, 2 * E, io[i].U, 2 * E, 2 * E, 0.f);
+            g[i].A2 = io[i].tgt; g[i].lda2 = E; g[i].K1 = E;
+        }
+        rc = launch_skinny_gemm_multi(g, G, 0, s);
+        if (rc) return rc;
+    } else {
+        for (int i = 0; i < G; ++i) g[i] = skinny(io[i].ws.mha.ctx, E, w->sa_out_w, w->sa_out_b, io[i].tgt, io[i].ws.x1, E, io[i].U, E, E, w->resweight);
+        rc = launch_skinny_gemm_multi(g, G, 2, s);
+        if (rc) return rc;
+        for (int i = 0; i < G; ++i) g[i] = skinny(io[i].ws.x1, E, w->ca_in_w, w->ca_in_b, nullptr, io[i].ws.mha.q, E, io[i].U, E, E, qscale);
+        rc = launch_skinny_gemm_multi(g, G, 3, s);
+        if (rc) return rc;
+    }
+    const int64_t ldq = fold ? 2 * E : E;
     for (int i = 0; i < G; ++i) {
         const SessionLayerIo& x = io[i];
         const int64_t S4 = pad4(x.S);
         a[i] = AttnArgs{};
-        a[i].q = x.ws.mha.q; a[i].ldq = E; a[i].q_bs = (int64_t)x.U * E;
+        a[i].q = fold ? x.ws.y3 + E : x.ws.mha.q; a[i].ldq = ldq; a[i].q_bs = (int64_t)x.U * ldq;
         a[i].k = x.ck; a[i].ldk = x.k_pitch; a[i].k_bs = (int64_t)x.S * x.k_pitch;
         a[i].vt = x.cvt; a[i].ldvt = S4; a[i].vt_bs = (int64_t)E * S4;
         a[i].vbias = w->ca_in_b + 2 * E;
@@ -600,14 +648,29 @@ static int decoder_layer_small_multi(const tal_decoder_layer_w* w, const Session
     }
     rc = launch_attn_split_multi(a, scr, tik, G, hd, s);
     if (rc) return rc;
-    for (int i = 0; i < G; ++i) g[i] = skinny(io[i].ws.mha.ctx, E, w->ca_out_w, w->ca_out_b, io[i].ws.x1, io[i].ws.x2, E, io[i].U, E, E, w->resweight_src);
-    rc = launch_skinny_gemm_multi(g, G, 2, s);
-    if (rc) return rc;
-    for (int i = 0; i < G; ++i) g[i] = skinny(io[i].ws.x2, E, w->lin1_w, w->lin1_b, nullptr, io[i].ws.ff, FF, io[i].U, FF, E, 0.f);
-    rc = launch_skinny_gemm_multi(g, G, 1, s);
-    if (rc) return rc;
+    if (fold) {
+        for (int i = 0; i < G; ++i) {
+            g[i] = skinny(io[i].ws.mha.ctx, E, w->fold_ca_w, w->fold_ca_b, nullptr, io[i].ws.y5, E + FF, io[i].U, E + FF, 2 * E, 0.f);
+            g[i].A2 = io[i].ws.y3; g[i].lda2 = 2 * E; g[i].K1 = E;
+            g[i].relu_begin = E;
+        }
+        rc = launch_skinny_gemm_multi(g, G, 1, s);
+        if (rc) return rc;
+    } else {
+        for (int i = 0; i < G; ++i) g[i] = skinny(io[i].ws.mha.ctx, E, w->ca_out_w, w->ca_out_b, io[i].ws.x1, io[i].ws.x2, E, io[i].U, E, E, w->resweight_src);
+        rc = launch_skinny_gemm_multi(g, G, 2, s);
+        if (rc) return rc;
+        for (int i = 0; i < G; ++i) g[i] = skinny(io[i].ws.x2, E, w->lin1_w, w->lin1_b, nullptr, io[i].ws.ff, FF, io[i].U, FF, E, 0.f);
+        rc = launch_skinny_gemm_multi(g, G, 1, s);
+        if (rc) return rc;
+    }
     for (int i = 0; i < G; ++i) {
-        g[i] = skinny(io[i].ws.ff, FF, w->lin2_w, w->lin2_b, io[i].ws.x2, io[i].out, E, io[i].U, E, FF, w->resweight);
+        if (fold) {
+            g[i] = skinny(io[i].ws.y5 + E, E + FF, w->lin2_w, w->lin2_b, io[i].ws.y5, io[i].out, E, io[i].U, E, FF, w->resweight);
+            g[i].ldres = E + FF;
+        } else {
+            g[i] = skinny(io[i].ws.ff, FF, w->lin2_w, w->lin2_b, io[i].ws.x2, io[i].out, E, io[i].U, E, FF, w->resweight);
+        }
         g[i].ksplit = 4;
         g[i].sk_part = io[i].sk.part;
         g[i].sk_tickets = io[i].sk.tickets + 64;
@@ -621,7 +684,8 @@ static int decoder_layer_small_multi(const tal_decoder_layer_w* w, const Session
 static bool greedy_persist_ok(const tal_greedy_ctx* c, int U, int S) {
     const int E = c->E, H = c->H, FF = c->FF, K0 = c->E0 > 0 ? c->E0 : c->E, hd = E / H;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    return c->tickets && !c->pick_bias && c->n_layers <= TAL_PS_MAX_LAYERS && (hd == 128 || hd == 64) && E <= 512 && FF / 4 <= 512 && E % 64 == 0 &&
+    // (the one-launch form walks the UNFOLDED layer's phases: it is a measurement switch of round 5, valid beside option decode_no_fold)
+    return c->tickets && !c->pick_bias && !layer_folded(&c->layers[0]) && c->n_layers <= TAL_PS_MAX_LAYERS && (hd == 128 || hd == 64) && E <= 512 && FF / 4 <= 512 && E % 64 == 0 &&
            small_layer_applicable(1, U, S, E, H, FF, true) && S > 64 && attn_split_tickets(1, U, H) <= 64 && FF >= 2048 && FF % 256 == 0 &&
            64 + (E / 16) * ((U + 31) / 32) <= PS_BAR && E % 16 == 0 && K0 % 8 == 0 && al16(c->emb) && (!c->proj_t || al16(c->proj_t));
 }

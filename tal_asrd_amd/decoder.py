@@ -35,7 +35,39 @@ def _layer_struct(layer):
     w.lin2_w, w.lin2_b = layer.linear2.weight.data_ptr(), layer.linear2.bias.data_ptr()
     w.resweight = float(layer.resweight.detach())
     w.resweight_src = float(layer.resweight_src.detach())
+    folds = _folded_weights(layer)
+    if folds is not None:
+        w.fold_sa_w, w.fold_sa_b, w.fold_ca_w, w.fold_ca_b = (t.data_ptr() for t in folds)
+    layer.__dict__["_tal_folds"] = folds          # (kept alive beside the struct that points at them)
     return w
+
+
+FOLD_DECODER_LAYERS = True      # False: structs without the folded forms (every decode step on the eight-launch layer)
+
+
+def _folded_weights(layer):
+    """The two folded dense layers of include/tal_asrd.h (tal_decoder_layer_w.fold_*): products in float64, rounded once."""
+    if not FOLD_DECODER_LAYERS:
+        return None
+    sa, ca = layer.self_attn, layer.multihead_attn
+    E = sa.embed_dim
+    if E % 32 != 0 or layer.linear1.out_features % 16 != 0:
+        return None
+    d = torch.float64
+    s = float(E // sa.num_heads) ** -0.5
+    rw, rws = float(layer.resweight.detach()), float(layer.resweight_src.detach())
+    Wo, bo = sa.out_proj.weight.detach().to(d), sa.out_proj.bias.detach().to(d)
+    Wq, bq = ca.in_proj_weight.detach()[:E].to(d), ca.in_proj_bias.detach()[:E].to(d)
+    Wo2, bo2 = ca.out_proj.weight.detach().to(d), ca.out_proj.bias.detach().to(d)
+    W1, b1 = layer.linear1.weight.detach().to(d), layer.linear1.bias.detach().to(d)
+    eye = torch.eye(E, dtype=d, device=Wo.device)
+    # (the layer scales q with a single fp32 multiply by s after the bias; here s rides in the weights)
+    s32 = float(torch.tensor(s, dtype=torch.float32))
+    f_sa_w = torch.cat([torch.cat([rw * Wo, eye], 1), torch.cat([s32 * rw * (Wq @ Wo), s32 * Wq], 1)], 0)
+    f_sa_b = torch.cat([rw * bo, s32 * (rw * (Wq @ bo) + bq)])
+    f_ca_w = torch.cat([torch.cat([rws * Wo2, eye], 1), torch.cat([rws * (W1 @ Wo2), W1], 1)], 0)
+    f_ca_b = torch.cat([rws * bo2, rws * (W1 @ bo2) + b1])
+    return tuple(t.to(torch.float32).contiguous() for t in (f_sa_w, f_sa_b, f_ca_w, f_ca_b))
 
 
 def layer_weights(layer):

@@ -196,14 +196,22 @@ def test_decode_steps_are_the_same_step_after_step(asr_model, contended):
                     t2, r2 = s.result()
                     bad["merged"] += int(not (t2 == tok and np.array_equal(r2, row) and int(s.gen_dev[U]) == app))
             try:
+                # (the one-launch form is the UNFOLDED layer: its reference is the chain under option decode_no_fold)
+                N.set_option("decode_no_fold", 1)
+                want_nf = []
+                for s, U in sessions:
+                    s.gen_dev[U] = -1
+                    tok, row = s.step(0, U)
+                    want_nf.append((tok, row, int(s.gen_dev[U])))
                 N.set_option("decode_persist", 1)
                 for _ in range(50):                                # the step as one launch
-                    for (s, U), (tok, row, app) in zip(sessions, want):
+                    for (s, U), (tok, row, app) in zip(sessions, want_nf):
                         s.gen_dev[U] = -1
                         t2, r2 = s.step(0, U)
                         bad["one-launch"] += int(not (t2 == tok and np.array_equal(r2, row) and int(s.gen_dev[U]) == app))
             finally:
                 N.set_option("decode_persist", 0)
+                N.set_option("decode_no_fold", 0)
         assert bad == {"chain": 0, "merged": 0, "one-launch": 0}, bad
         for s, _ in sessions:
             assert int(s._tickets.abs().sum()) == 0

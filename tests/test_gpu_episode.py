@@ -221,6 +221,9 @@ def test_one_launch_step_equals_the_launch_chain_bit_for_bit(asr_weights):
     enc = asr.encode(audio.half(), torch.tensor([L]))
     rng = np.random.default_rng(5)
     sessions, chain = [], []
+    # (the one-launch form walks the UNFOLDED layer's phases -- round 6's folded layer, 6 launches instead of 8, is the default of the
+    #  launch chain and keeps this form off: both sides of this comparison run with option decode_no_fold)
+    N.set_option("decode_no_fold", 1)
     for k, U in enumerate((1, 17, 40, 96, 200)):
         toks = torch.from_numpy(rng.integers(3, 10000, size=U + 8).astype(np.int64)).to(dev)
         s = _GreedySession(asr, toks, 512)
@@ -274,6 +277,63 @@ def test_one_launch_step_equals_the_launch_chain_bit_for_bit(asr_weights):
     finally:
         N.set_option("decode_persist", 0)
         N.set_option("decode_persist_wgs", 32)
+        N.set_option("decode_no_fold", 0)
+
+
+def test_folded_decoder_layer_against_the_eight_launch_layer(asr_weights):
+    """Round 6: the decode step's layer with its two pairs of dependent dense layers folded (tal_decoder_layer_w.fold_*: out-projection
+    + ReZero + the next projection as ONE dense layer over [ctx | x] with pre-multiplied weights; 6 launches per layer instead of 8)
+    against the unfolded layer (option decode_no_fold) on the same states: prefixes of 1, 17, 40, 96 and 200 tokens -- the same
+    token, attention rows within 1e-5 (fp32 re-association of the weight products), and the merged step of several sessions
+    bit-identical to each session's solo step in the folded form too (narrow and wide dense launches)."""
+    import ctypes as C
+    from tal_asrd_amd import ASRModel, synth, _native as N
+    from tal_asrd_amd.system import _GreedySession
+    dev = torch.device("cuda:0")
+    asr = _load(ASRModel("2x", num_speakers=6008, vocab_size=10000, use_speaker_head=True), asr_weights, dev)
+    L = 60 * 16000
+    audio = torch.from_numpy(synth.synth_audio_batch(1, L, 99)).to(dev)
+    enc = asr.encode(audio.half(), torch.tensor([L]))
+    rng = np.random.default_rng(5)
+    lib = N.lib()
+    sessions = []
+    for k, U in enumerate((1, 17, 40, 96, 200)):
+        toks = torch.from_numpy(rng.integers(3, 10000, size=U + 8).astype(np.int64)).to(dev)
+        s = _GreedySession(asr, toks, 512)
+        sl = slice(40 * k, 40 * k + 357)
+        s.set_window({"encoder_out": enc["encoder_out"][:, sl].contiguous(), "encoder_padding_mask": enc["encoder_padding_mask"][:, sl].contiguous()})
+        sessions.append((s, U))
+    assert bool(s.ctx.layers)
+    folded, plain = [], []
+    try:
+        for (s, U) in sessions:
+            folded.append(s.step(0, U))
+        N.set_option("decode_no_fold", 1)
+        for (s, U) in sessions:
+            plain.append(s.step(0, U))
+    finally:
+        N.set_option("decode_no_fold", 0)
+    worst = 0.0
+    for (t1, r1), (t0, r0), (_, U) in zip(folded, plain, sessions):
+        assert t1 == t0, U
+        worst = max(worst, float(np.abs(r1 - r0).max()))
+    print("folded vs eight-launch layer: largest attention-row difference %.2e" % worst)
+    assert worst < 1e-5
+    assert folded[0][1].sum() > 0.99
+    # merged steps in the folded form: bit-identical to the solo steps
+    ctxs = (C.POINTER(N.GreedyCtx) * 8)(*[C.pointer(s.ctx) for s, _ in sessions[:4]])
+    hs = (C.c_int64 * 8)(0, 0, 0, 0)
+    ng = (C.c_int64 * 8)(*[U for _, U in sessions[:4]])
+    try:
+        for wide in (0, 1, 2):
+            N.set_option("decode_wide_gemm", wide)
+            N.check(lib.tal_greedy_step_multi_fwd(ctxs, hs, ng, 4, N.stream_handle()), "tal_greedy_step_multi_fwd")
+            for (s, U), (tok, row) in zip(sessions[:4], folded):
+                assert s.ready(20000)
+                t2, r2 = s.result()
+                assert t2 == tok and np.array_equal(r2, row), (wide, U)
+    finally:
+        N.set_option("decode_wide_gemm", 0)
 
 
 def test_a_failing_episode_ends_the_whole_call(asr_weights):

@@ -325,10 +325,11 @@ typedef struct tal_decoder_layer_w {
      * eight launches).  Two pairs of dependent dense layers of ModRZTXDecoderLayer.forward (tal/asr/models.py:512-528) read the
      * same two activations, so each pair is ONE dense layer over the concatenated K axis with a pre-multiplied weight:
      *   x1 = tgt + rw (ctx Wo^T + bo)  and  q_c = s (x1 Wq^T + bq)          [s = head_dim^-0.5]
-     *     = [ctx | tgt] . fold_sa_w^T + fold_sa_b,   fold_sa_w [2E, 2E] = [[rw Wo, I], [s rw Wq Wo, s Wq]]
+     *     = [ctx | tgt] . fold_sa_w^T + fold_sa_b,   fold_sa_w [2E, 2E] = [[rw Wo, *], [s rw Wq Wo, s Wq]]
      *   x2 = x1 + rws (ctx2 Wo2^T + bo2)  and  ff = relu(x2 W1^T + b1)
-     *     = [ctx2 | x1] . fold_ca_w^T + fold_ca_b,   fold_ca_w [E + FF, 2E] = [[rws Wo2, I], [rws W1 Wo2, W1]]
-     * (products formed in float64, rounded once).  6 launches per layer instead of 8; the results differ from the unfolded layer by
+     *     = [ctx2 | x1] . fold_ca_w^T + fold_ca_b,   fold_ca_w [E + FF, 2E] = [[rws Wo2, *], [rws W1 Wo2, W1]]
+     * (products formed in float64, rounded once; * = never read: the first E output columns contract over the first E inputs only
+     * and the kernel adds the skip path tgt / x1 to them).  6 launches per layer instead of 8; the results differ from the unfolded layer by
      * fp32 re-association (attention rows ~1e-6). */
     const float* fold_sa_w;   /* [2E, 2E]  */
     const float* fold_sa_b;   /* [2E]      */

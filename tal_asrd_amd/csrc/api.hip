@@ -20,8 +20,8 @@ void set_error(const char* fmt, ...) {
 // ---- behaviour switches (tal_set_option) ---------------------------------------------------
 static const char* const g_opt_names[OPT_COUNT] = {
     "tds_exact_f32", "tds_fp32_activations", "gconv_fuse_split", "gconv_c1_generic", "head_no_astationary", "gemm_global_loads",
-    "gemm_no_splitk4", "gemm_no_glds", "gemm_no_splitk_tail", "gemm_no_w64", "logmel_no_fold", "decode_no_small", "decode_small_rows", "gemm_no_row_split", "gemm_no_n96", "gemm_s64_below", "gconv_short_below", "gconv_no_shift18", "gconv_grid_xyz", "gemm_w64_stagger", "gemm_s64_order", "decode_wide_gemm", "gemm_s64_rows", "decode_persist", "decode_persist_wgs", "logmel_mfma", "gru_unfused", "decode_no_fold"};
-static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {256}, {0}, {0}, {2}, {4}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {32}, {0}, {0}, {0}};
+    "gemm_no_splitk4", "gemm_no_glds", "gemm_no_splitk_tail", "gemm_no_w64", "logmel_no_fold", "decode_no_small", "decode_small_rows", "gemm_no_row_split", "gemm_no_n96", "gemm_s64_below", "gconv_short_below", "gconv_no_shift18", "gconv_grid_xyz", "gemm_w64_stagger", "gemm_s64_order", "decode_wide_gemm", "gemm_s64_rows", "decode_persist", "decode_persist_wgs", "logmel_mfma", "gru_unfused", "decode_no_fold", "gconv_no_c1_fuse", "decode_fold_rows"};
+static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {256}, {0}, {0}, {2}, {4}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {32}, {0}, {0}, {0}, {0}, {64}};
 int opt(Option o) { return g_opt[o].load(std::memory_order_relaxed); }
 
 int device_cus() {
@@ -511,7 +511,13 @@ static int tds_fwd_impl(const tal_tds_desc* d, const float* x, const float* x_me
         // resize conv: cur -> a (a buffer other than cur's)
         const int io = (ia + 1) % 4;
         float* a = (last_stage && d->depths[i] == 0) ? y : buf[io];
-        if (allsplit) {
+        // the first stage's resize conv (1 mel bin -> 10 channels per group) runs INSIDE the first TDSBlock conv's launch (round 6):
+        // its output is computed straight into that kernel's LDS slab and never touches memory
+        const bool c1_fused = allsplit && i == 0 && !cur_split && !s2_mfma_ok(i, Tc) && d->depths[i] > 0 && !opt(OPT_GCONV_NO_C1_FUSE) &&
+                              !opt(OPT_GCONV_C1_GENERIC) && gconv_c1_res_fusable(cin, c, d->groups, cur);
+        if (c1_fused) {
+            rc = TAL_OK;
+        } else if (allsplit) {
             if (s2_mfma_ok(i, Tc))
                 rc = launch_gconv_s2_f16x3(cur, d->down_w_frag[i], d->down_b[i], B, Tc, cin, c, d->groups, nullptr, s, range_flag, cur_split, a);
             else
@@ -540,7 +546,10 @@ static int tds_fwd_impl(const tal_tds_desc* d, const float* x, const float* x_me
             float* outp = (last_stage && last_block) ? y : buf[ia];
             if (allsplit) {
                 // x1 = x + rw * relu(gconv(x)): a (split) -> x1 (split); h = relu(fc0(x1)) (split); out = x1 + rw * fc3(h)
-                rc = launch_gconv_res_f16x3(a, bw.conv_w_frag, bw.conv_b, bw.resweight, B, To, c, d->groups, nullptr, x1, s, range_flag, true);
+                if (c1_fused && j == 0)
+                    rc = launch_gconv_c1_res_f16x3(cur, d->down_w[i], d->down_b[i], x_mean, bw.conv_w_frag, bw.conv_b, bw.resweight, B, Tc, d->groups, x1, s, range_flag);
+                else
+                    rc = launch_gconv_res_f16x3(a, bw.conv_w_frag, bw.conv_b, bw.resweight, B, To, c, d->groups, nullptr, x1, s, range_flag, true);
                 if (rc) return rc;
                 rc = launch_linear_f16x3(x1, bw.fc0_w_split, bw.fc0_b, nullptr, 0.f, 1, M, c, c, h, 1, skws, gemm_splitk_ws_bytes(), s, range_flag);
                 if (rc) return rc;

@@ -124,6 +124,8 @@ enum Option {
     OPT_LOGMEL_MFMA,              // log-mel as the float64 matrix-core DFT of rounds 1-4 instead of the fast transform on the vector ALU
     OPT_GRU_UNFUSED,              // GRU cell as two dense launches + a gate kernel (rounds 1-5) instead of the one-launch step
     OPT_DECODE_NO_FOLD,           // latency-oriented decoder layer on its eight launches even when the folded weights are there (six)
+    OPT_GCONV_NO_C1_FUSE,         // first resize conv and first TDSBlock conv as two launches (rounds 1-5) instead of one
+    OPT_DECODE_FOLD_ROWS,         // the folded decoder layer is taken up to this many rows (prefix tokens) per problem (default 64)
     OPT_COUNT
 };
 int opt(Option o);
@@ -223,6 +225,10 @@ int launch_gconv_res(const float* x, const float* wp, const float* bias, float a
                      int groups, float* y, hipStream_t s);
 size_t gconv_f16x3_weight_bytes(int C_in, int C_out, int groups, int stride);
 bool gconv_f16x3_fits(int64_t T, int C);
+// first resize conv (1 -> 10 channels per group) + first TDSBlock conv of the stage in one launch (gconv_mfma_kernel<.., FROMC1>)
+bool gconv_c1_res_fusable(int C_in, int C_out, int groups, const float* mel);
+int launch_gconv_c1_res_f16x3(const float* mel, const float* w1, const float* b1, const float* in_mean, const void* w_frag, const float* bias,
+                              float alpha, int B, int64_t T_mel, int groups, void* y_split, hipStream_t s, int* range_flag);
 int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C_in, int C_out, int groups, int stride, hipStream_t s);
 int launch_gconv_s2_f16x3(const float* x, const void* w_frag, const float* bias, int B, int64_t T_in, int C_in, int C_out, int groups,
                           float* y, hipStream_t s, int* range_flag = nullptr, bool x_split = false, void* y_split = nullptr);
@@ -263,6 +269,9 @@ struct SkinnyArgs {
     int64_t lda2;
     int K1;
     int relu_begin;   // mode 1: the relu applies to columns >= relu_begin only (0 = all)
+    // columns < k1_cols (a multiple of 64) contract over the FIRST segment only and get A2[m][col] added (the ReZero skip path of the
+    // folded layers: y = x + (ctx . W'^T + b')): the waves of the second segment neither load nor multiply for those column blocks
+    int k1_cols;
 };
 
 struct AttnArgs {

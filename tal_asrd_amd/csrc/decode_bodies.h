@@ -60,6 +60,7 @@ __device__ __forceinline__ void skinny_gemm_body(const SkinnyArgs& g, const Blk 
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = {0.f, 0.f, 0.f, 0.f};
+    const bool idle = seg2 && n0 < g.k1_cols;      // (wave-uniform: this column block stops at K1 -- a zero partial tile)
     // A lane's 16-byte load holds k = 4 kq + {0..3} of a chunk; MFMA j of the chunk contracts the k set {j, 4+j, 8+j, 12+j}
     // on both operands, so the chunk's four MFMAs cover its 16 k exactly once.
     constexpr int UNR = 8;
@@ -87,6 +88,8 @@ __device__ __forceinline__ void skinny_gemm_body(const SkinnyArgs& g, const Blk 
                 }
             }
     };
+    if (idle) {
+    } else {
     load_batch(0, 0);
     if constexpr (NBUF == 1) {
         for (int c0 = 0; c0 < nchunk; c0 += UNR) {
@@ -100,6 +103,7 @@ __device__ __forceinline__ void skinny_gemm_body(const SkinnyArgs& g, const Blk 
             if (c0 + 2 * UNR < nchunk) load_batch(c0 + 2 * UNR, 0);
             if (c0 + UNR < nchunk) mfma_batch(c0 + UNR, NBUF - 1);
         }
+    }
     }
     // C layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
 #pragma unroll
@@ -139,6 +143,7 @@ __device__ __forceinline__ void skinny_gemm_body(const SkinnyArgs& g, const Blk 
     if (t >= MT * 64 || m >= g.M) return;
     const int col = n0 + 4 * c4;
     if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
+    if (col < g.k1_cols) v += *reinterpret_cast<const f32x4*>(g.A2 + (int64_t)m * g.lda2 + col);
     if (MODE == 1 && col >= g.relu_begin) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (MODE == 2) v = *reinterpret_cast<const f32x4*>(g.res + (int64_t)m * g.ldres + col) + g.alpha * v;
     if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) v = g.alpha * v;

@@ -63,7 +63,9 @@ __device__ __forceinline__ void skinny_gemm_wide_body(const SkinnyArgs& g, const
         for (int u = 0; u < UNR; ++u) av[mt][u] = *reinterpret_cast<const f32x4*>(ap + u * 16);
     }
     const int nb0 = blk.x * NT;                     // first 16-column block
+    const bool idle = seg2 && nb0 * 16 < g.k1_cols; // (all NT blocks of a workgroup lie on one side of k1_cols: a multiple of 64)
     auto load_w = [&](int nb, int buf) {
+        if (idle) return;
         const float* wp = g.W + (int64_t)(nb * 16 + r16) * g.ldw + kofs + 4 * kq;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) bw[buf][u] = *reinterpret_cast<const f32x4*>(wp + u * 16);
@@ -78,6 +80,7 @@ __device__ __forceinline__ void skinny_gemm_wide_body(const SkinnyArgs& g, const
         f32x4 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = {0.f, 0.f, 0.f, 0.f};
+        if (!idle)
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
 #pragma unroll
@@ -143,6 +146,7 @@ __device__ __forceinline__ void skinny_gemm_wide_body(const SkinnyArgs& g, const
             const int col = (nb0 + nt) * 16 + 4 * c4;
             f32x4 o = v[nt];
             if (g.bias) o += *reinterpret_cast<const f32x4*>(g.bias + col);
+            if (col < g.k1_cols) o += *reinterpret_cast<const f32x4*>(g.A2 + (int64_t)m * g.lda2 + col);
             if (MODE == 1 && col >= g.relu_begin) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             if (MODE == 2) o = *reinterpret_cast<const f32x4*>(g.res + (int64_t)m * g.ldres + col) + g.alpha * o;
             if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) o = g.alpha * o;
@@ -175,7 +179,7 @@ bool skinny_gemm_applicable(const SkinnyArgs& g) {
            (!g.Yt || g.vt_begin % 16 == 0) &&
            // two column segments of A: the boundary must fall between the K slices of every form (a wave's slice is K / (NW ksplit), NW <= 16)
            (!g.A2 || (al16(g.A2) && g.lda2 % 4 == 0 && g.K1 > 0 && g.K1 < g.K && g.K1 % 256 == 0 && (g.K - g.K1) % 256 == 0 && g.ksplit <= 1)) &&
-           g.relu_begin % 16 == 0;
+           g.relu_begin % 16 == 0 && g.k1_cols % 64 == 0 && (g.k1_cols == 0 || (g.A2 && g.k1_cols <= g.N));
 }
 
 template <int MODE, int NW>

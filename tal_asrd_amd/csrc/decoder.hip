@@ -441,9 +441,13 @@ static SkinnyArgs skinny(const float* A, int64_t lda, const float* W, const floa
     return g;
 }
 
-// does this layer run in the folded form (6 launches)?  All sessions of a merged step share the layer structs, hence the answer.
-static bool layer_folded(const tal_decoder_layer_w* w) {
-    return w->fold_sa_w && w->fold_sa_b && w->fold_ca_w && w->fold_ca_b && !opt(OPT_DECODE_NO_FOLD);
+// Does a problem of `rows` rows run this layer in the folded form (6 launches)?  A function of the problem's OWN row count, so that a
+// session takes the same form -- the same bits -- alone and inside a merged step.  The fold trades two launches for a K axis twice
+// as long in two dense layers: it wins while the step is latency-bound (measured: -8 % per step at <= 32 prefix tokens, even at
+// 64, +6 % at 128, +20 % at 256: profiles/r6_decode_folded_layer.txt).
+static bool layer_folded(const tal_decoder_layer_w* w, int E, int rows) {
+    return w->fold_sa_w && w->fold_sa_b && w->fold_ca_w && w->fold_ca_b && !opt(OPT_DECODE_NO_FOLD) && E % 256 == 0 &&
+           rows <= opt(OPT_DECODE_FOLD_ROWS);
 }
 
 static bool small_layer_applicable(int B, int U, int S, int E, int H, int FF, bool have_kv_cache) {
@@ -502,12 +506,12 @@ static int decoder_layer_small(const tal_decoder_layer_w* w, const float* tgt, i
     // Folded form (tal_decoder_layer_w.fold_*): the self-attention's out-projection + ReZero and the cross-attention's q projection are
     // ONE dense layer over [ctx | tgt] (x1 | q_c side by side in y3), and so are the cross-attention's out-projection + ReZero and
     // FFN-1 over [ctx2 | x1] (x2 | ff in y5): 6 dependent launches per layer instead of 8.
-    const bool fold = layer_folded(w);
+    const bool fold = layer_folded(w, E, M);
     const float* qc;
     int64_t ldq;
     if (fold) {
         SkinnyArgs g3 = skinny(ws.mha.ctx, E, w->fold_sa_w, w->fold_sa_b, nullptr, ws.y3, 2 * E, M, 2 * E, 2 * E, 0.f);
-        g3.A2 = tgt; g3.lda2 = E; g3.K1 = E;
+        g3.A2 = tgt; g3.lda2 = E; g3.K1 = E; g3.k1_cols = E;
         rc = launch_skinny_gemm(g3, 0, s);
         if (rc) return rc;
         qc = ws.y3 + E;
@@ -544,7 +548,7 @@ static int decoder_layer_small(const tal_decoder_layer_w* w, const float* tgt, i
     SkinnyArgs f2;
     if (fold) {
         SkinnyArgs g5 = skinny(ws.mha.ctx, E, w->fold_ca_w, w->fold_ca_b, nullptr, ws.y5, E + FF, M, E + FF, 2 * E, 0.f);
-        g5.A2 = ws.y3; g5.lda2 = 2 * E; g5.K1 = E;          // x1 = the first E columns of y3
+        g5.A2 = ws.y3; g5.lda2 = 2 * E; g5.K1 = E; g5.k1_cols = E;          // x1 = the first E columns of y3
         g5.relu_begin = E;                                   // x2 plain, ff through the relu
         rc = launch_skinny_gemm(g5, 1, s);
         if (rc) return rc;
@@ -585,7 +589,23 @@ struct SessionLayerIo {
     LayerWs ws;
     DecodeScratch sk;
 };
+static int decoder_layer_small_multi_form(const tal_decoder_layer_w* w, const SessionLayerIo* io, int G, int E, int H, int FF, bool fold, hipStream_t s);
+// (sessions on either side of the fold's row limit go through the layer as two groups of launches: each in the form its solo step takes)
 static int decoder_layer_small_multi(const tal_decoder_layer_w* w, const SessionLayerIo* io, int G, int E, int H, int FF, hipStream_t s) {
+    SessionLayerIo part[2][TAL_GROUP_MAX];
+    int n[2] = {0, 0};
+    for (int i = 0; i < G; ++i) {
+        const int f = layer_folded(w, E, io[i].U) ? 1 : 0;
+        part[f][n[f]++] = io[i];
+    }
+    for (int f = 1; f >= 0; --f)
+        if (n[f] > 0) {
+            const int rc = decoder_layer_small_multi_form(w, part[f], n[f], E, H, FF, f == 1, s);
+            if (rc) return rc;
+        }
+    return TAL_OK;
+}
+static int decoder_layer_small_multi_form(const tal_decoder_layer_w* w, const SessionLayerIo* io, int G, int E, int H, int FF, bool fold, hipStream_t s) {
     const int hd = E / H;
     const float qscale = 1.0f / sqrtf((float)hd);
     SkinnyArgs g[TAL_GROUP_MAX];
@@ -614,11 +634,11 @@ static int decoder_layer_small_multi(const tal_decoder_layer_w* w, const Session
     }
     rc = launch_attn_small_multi(a, G, hd, s);
     if (rc) return rc;
-    const bool fold = layer_folded(w);           // (the same arguments per session as decoder_layer_small builds: bit-identical)
+    // (fold: the same arguments per session as decoder_layer_small builds: bit-identical)
     if (fold) {
         for (int i = 0; i < G; ++i) {
             g[i] = skinny(io[i].ws.mha.ctx, E, w->fold_sa_w, w->fold_sa_b, nullptr, io[i].ws.y3, 2 * E, io[i].U, 2 * E, 2 * E, 0.f);
-            g[i].A2 = io[i].tgt; g[i].lda2 = E; g[i].K1 = E;
+            g[i].A2 = io[i].tgt; g[i].lda2 = E; g[i].K1 = E; g[i].k1_cols = E;
         }
         rc = launch_skinny_gemm_multi(g, G, 0, s);
         if (rc) return rc;
@@ -651,7 +671,7 @@ static int decoder_layer_small_multi(const tal_decoder_layer_w* w, const Session
     if (fold) {
         for (int i = 0; i < G; ++i) {
             g[i] = skinny(io[i].ws.mha.ctx, E, w->fold_ca_w, w->fold_ca_b, nullptr, io[i].ws.y5, E + FF, io[i].U, E + FF, 2 * E, 0.f);
-            g[i].A2 = io[i].ws.y3; g[i].lda2 = 2 * E; g[i].K1 = E;
+            g[i].A2 = io[i].ws.y3; g[i].lda2 = 2 * E; g[i].K1 = E; g[i].k1_cols = E;
             g[i].relu_begin = E;
         }
         rc = launch_skinny_gemm_multi(g, G, 1, s);
@@ -685,7 +705,7 @@ static bool greedy_persist_ok(const tal_greedy_ctx* c, int U, int S) {
     const int E = c->E, H = c->H, FF = c->FF, K0 = c->E0 > 0 ? c->E0 : c->E, hd = E / H;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     // (the one-launch form walks the UNFOLDED layer's phases: it is a measurement switch of round 5, valid beside option decode_no_fold)
-    return c->tickets && !c->pick_bias && !layer_folded(&c->layers[0]) && c->n_layers <= TAL_PS_MAX_LAYERS && (hd == 128 || hd == 64) && E <= 512 && FF / 4 <= 512 && E % 64 == 0 &&
+    return c->tickets && !c->pick_bias && !layer_folded(&c->layers[0], c->E, U) && c->n_layers <= TAL_PS_MAX_LAYERS && (hd == 128 || hd == 64) && E <= 512 && FF / 4 <= 512 && E % 64 == 0 &&
            small_layer_applicable(1, U, S, E, H, FF, true) && S > 64 && attn_split_tickets(1, U, H) <= 64 && FF >= 2048 && FF % 256 == 0 &&
            64 + (E / 16) * ((U + 31) / 32) <= PS_BAR && E % 16 == 0 && K0 % 8 == 0 && al16(c->emb) && (!c->proj_t || al16(c->proj_t));
 }

@@ -504,14 +504,28 @@ __device__ unsigned long long g_gc_timeline[8 * 4 * 4096];
         t0 = (int64_t)blockIdx.x * TT;                                                       \
     }
 
+// FROMC1 (round 6; 10 channels per group, split form out): the slab is not loaded but COMPUTED -- the workgroup runs the first resize
+// conv of the encoder (1 mel bin -> 10 channels per group, stride 2, no padding: tal/asr/models.py:363-364) for its groups and its
+// tile's rows (halo included) straight into the slab, with gconv_s2_c1_kernel's arithmetic (same fmaf chain, same mean fold, same
+// split), and the TDSBlock conv follows from there.  The stage's first activation (576 MB per hour of audio) is never written or
+// read, and the resize conv's launch is gone; results are bit-identical to the two launches.
+struct GcC1 {
+    const float* mel;     // [B][T_mel][C_mel] log-mel (before its mean subtraction when `mean` is given)
+    const float* w1;      // packed resize-conv weights [G][1][21][10]
+    const float* b1;      // [G * 10]
+    const float* mean;    // device scalar or NULL
+    int64_t T_mel;
+    int C_mel;
+};
+
 // SPLIT: 0 = fp32 output, 1 = fp32 output + its hi / lo split, 2 = the split form only.  XSPLIT: the input is in the split
 // form (per row and 32-channel block: 32 hi halves, 32 lo halves; same bytes as fp32) -- the slab is then filled without
 // any conversion arithmetic and the TDSBlock residual is rebuilt from the slab as hi + lo * 2^-11.
-template <int CIG, int COG, int STRIDE, bool RESID, int GB, int TT, int SPLIT, bool XSPLIT = false>
+template <int CIG, int COG, int STRIDE, bool RESID, int GB, int TT, int SPLIT, bool XSPLIT = false, bool FROMC1 = false>
 __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(const float* __restrict__ x, const _Float16* __restrict__ wfrag,
                                                            const float* __restrict__ bias, float alpha, float* __restrict__ y,
                                                            _Float16* __restrict__ ysplit, int64_t T_in, int64_t T_out, int C_in,
-                                                           int C_out, int* __restrict__ range_flag, int n_tt, int n_gb) {
+                                                           int C_out, int* __restrict__ range_flag, int n_tt, int n_gb, const GcC1 c1) {
     using LY = GcLayout<CIG, STRIDE>;
     constexpr int NKS = LY::NKS, NK0 = LY::nk(0), MT = (COG + 15) / 16;
     constexpr int P0 = LY::pitch(0), P1 = LY::pitch(1);
@@ -539,6 +553,71 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
     float* yb = y + (int64_t)b * T_out * C_out;
     GC_STAMP(0);
 
+    if constexpr (FROMC1) {
+        static_assert(CIG == 10 && COG == 10 && STRIDE == 1 && RESID && GB == 4 && XSPLIT && SPLIT == 2 && LY::NSEG == 1 && TIN % 4 == 0, "shape");
+        // ---- the slab from the log-mel: stage the tile's mel rows ([row][4 bins], 16-byte loads), then thread = (channel of the
+        // workgroup, row phase): a channel's 21 weights + bias in registers, four consecutive rows share their 27 samples ----
+        constexpr int NR = 2 * (TIN - 1) + KS;                       // mel rows behind TIN rows of the stage
+        float* xs = reinterpret_cast<float*>(slab + 2 * GB * GS);    // [NR][GB] floats behind the slabs
+        const float* mb = c1.mel + (int64_t)b * c1.T_mel * c1.C_mel + g0;
+        const int64_t m0 = 2 * (t0 - PADT);
+        for (int i = tid; i < NR; i += 256) {
+            int64_t t = m0 + i;
+            t = t < 0 ? 0 : (t < c1.T_mel ? t : c1.T_mel - 1);       // (clamped rows only feed rows outside [0, T_in): forced to zero below)
+            *reinterpret_cast<f32x4*>(xs + i * GB) = *reinterpret_cast<const f32x4*>(mb + t * c1.C_mel);
+        }
+        __syncthreads();
+        float amax = 0.f;
+        if (tid < GB * CIG * 6) {
+            const int chn = tid % (GB * CIG), ph = tid / (GB * CIG);
+            const int gl = chn / CIG, ci = chn - gl * CIG, g = g0 + gl;
+            float wk[KS];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) wk[k] = c1.w1[((int64_t)g * KS + k) * COG + ci];
+            float bv = c1.b1[g * COG + ci];
+            if (c1.mean) {
+                float wsum = wk[0];
+#pragma unroll
+                for (int k = 1; k < KS; ++k) wsum += wk[k];
+                bv = fmaf(-c1.mean[0], wsum, bv);
+            }
+            const float* xc = xs + gl;
+            _Float16* dh = s_hi + gl * GS + ci;
+            _Float16* dl = s_lo + gl * GS + ci;
+            for (int rq = ph; rq < TIN / 4; rq += 6) {
+                const int r = 4 * rq;
+                float xv[KS + 6];
+#pragma unroll
+                for (int i = 0; i < KS + 6; ++i) xv[i] = xc[(2 * r + i) * GB];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float acc = bv;
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) acc = fmaf(wk[k], xv[2 * q + k], acc);
+                    const int64_t tg = t0 - PADT + r + q;
+                    const bool inside = tg >= 0 && tg < T_in;         // outside: the TDSBlock conv's zero padding
+                    _Float16 hi, lo;
+                    split_f16x3(acc, hi, lo);
+                    if (inside) amax = fmaxf(amax, fabsf(acc));
+                    dh[(r + q) * P0] = inside ? hi : (_Float16)0.f;
+                    dl[(r + q) * P0] = inside ? lo : (_Float16)0.f;
+                    if (ci == CIG - 1) {                              // this row's pad columns (finite bytes under zero weights)
+#pragma unroll
+                        for (int j = 1; j <= P0 - CIG; ++j) {
+                            dh[(r + q) * P0 + j] = (_Float16)0.f;
+                            dl[(r + q) * P0 + j] = (_Float16)0.f;
+                        }
+                    }
+                }
+            }
+        }
+        note_range(amax, range_flag);
+        const f16x2 z2 = {(_Float16)0.f, (_Float16)0.f};
+        constexpr int tail2 = (SL0 - LY::rows(0, TT) * P0) / 2;
+        if (tail2 > 0)
+            for (int i = tid; i < 2 * GB * tail2; i += 256)
+                *reinterpret_cast<f16x2*>(slab + (i / tail2) * GS + LY::rows(0, TT) * P0 + 2 * (i % tail2)) = z2;
+    } else
     // ---- slab load: thread = (input row inside a pass, 16-byte column piece): 16-byte global loads (GB*CIG contiguous
     // floats per row), all passes in flight, split, 4-byte LDS stores ----
     {
@@ -1361,7 +1440,7 @@ static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias
                             bool x_split = false) {
     using LY = GcLayout<CIG, STRIDE>;
     constexpr size_t lds = (size_t)2 * GB * (LY::slab(0, TT) + LY::slab(1, TT)) * sizeof(_Float16);
-    typedef void (*kern_t)(const float*, const _Float16*, const float*, float, float*, _Float16*, int64_t, int64_t, int, int, int*, int, int);
+    typedef void (*kern_t)(const float*, const _Float16*, const float*, float, float*, _Float16*, int64_t, int64_t, int, int, int*, int, int, const GcC1);
     kern_t k;
     if (x_split) k = y ? (ysplit ? (kern_t)gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, 1, true> : (kern_t)gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, 0, true>)
                        : (kern_t)gconv_mfma_kernel<CIG, COG, STRIDE, RESID, GB, TT, 2, true>;
@@ -1383,7 +1462,7 @@ static int launch_mfma_spec(const float* x, const void* wfrag, const float* bias
     const dim3 grid = gconv_grid(cdiv(T_out, TT), groups / GB, B, n_tt, n_gb);
     ProfScope prof(RESID ? PROF_GCONV_RES : PROF_GCONV_S2, 2.0 * (double)B * (double)T_out * C_out * CIG * KS, s);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, reinterpret_cast<const _Float16*>(wfrag), bias, alpha, y,
-                       reinterpret_cast<_Float16*>(ysplit), T_in, T_out, C_in, C_out, range_flag, n_tt, n_gb);
+                       reinterpret_cast<_Float16*>(ysplit), T_in, T_out, C_in, C_out, range_flag, n_tt, n_gb, GcC1{});
     TAL_CHECK_LAUNCH("gconv (fp16x3)");
     return TAL_OK;
 }
@@ -1426,6 +1505,47 @@ int launch_pack_gconv_f16x3(const float* w_ref, void* w_frag, int C_in, int C_ou
         TAL_CHECK_LAUNCH("tal_pack_gconv_f16x3_weight (shifted tile)");
     }
     return TAL_OK;
+}
+
+// The first resize conv (1 mel bin -> 10 channels per group) and the first TDSBlock conv of the stage as ONE launch (FROMC1):
+// mel [B][T_mel][groups] -> y_split [B][T1][10 groups] in the split form, T1 = (T_mel - 21) / 2 + 1.
+bool gconv_c1_res_fusable(int C_in, int C_out, int groups, const float* mel) {
+    return groups > 0 && C_in == groups && C_out == 10 * groups && groups % 4 == 0 && C_out % 32 == 0 &&
+           (reinterpret_cast<uintptr_t>(mel) & 15) == 0 && gconv_f16x3_weight_bytes(C_out, C_out, groups, 1) > 0;
+}
+template <int TT>
+static int launch_c1_res_tt(const GcC1& c1, const void* wfrag, const float* bias, float alpha, int B, int64_t T1, int C, int groups,
+                            void* ysplit, hipStream_t s, int* range_flag) {
+    using LY = GcLayout<10, 1>;
+    constexpr int GB = 4, TIN = TT + KS - 1, NR = 2 * (TIN - 1) + KS;
+    constexpr size_t lds = (size_t)2 * GB * LY::slab(0, TT) * sizeof(_Float16) + (size_t)NR * GB * sizeof(float);
+    auto k = gconv_mfma_kernel<10, 10, 1, true, GB, TT, 2, true, true>;
+    static const void* attr_done = nullptr;
+    if (attr_done != reinterpret_cast<const void*>(k)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("gconv (resize conv + TDSBlock conv): cannot reserve %zu bytes of LDS", lds);
+            return TAL_EHIP;
+        }
+        attr_done = reinterpret_cast<const void*>(k);
+    }
+    int n_tt, n_gb;
+    const dim3 grid = gconv_grid(cdiv(T1, TT), groups / GB, B, n_tt, n_gb);
+    ProfScope prof(PROF_GCONV_RES, 2.0 * (double)B * (double)T1 * C * (10 + 1) * KS, s);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const float*)nullptr, reinterpret_cast<const _Float16*>(wfrag), bias, alpha, (float*)nullptr,
+                       reinterpret_cast<_Float16*>(ysplit), T1, T1, C, C, range_flag, n_tt, n_gb, c1);
+    TAL_CHECK_LAUNCH("gconv (resize conv + TDSBlock conv)");
+    return TAL_OK;
+}
+int launch_gconv_c1_res_f16x3(const float* mel, const float* w1, const float* b1, const float* in_mean, const void* w_frag, const float* bias,
+                              float alpha, int B, int64_t T_mel, int groups, void* y_split, hipStream_t s, int* range_flag) {
+    TAL_CHECK_ARG(mel && w1 && b1 && w_frag && bias && y_split, "gconv (resize conv + TDSBlock conv): null pointer");
+    TAL_CHECK_ARG(B > 0 && T_mel >= KS && gconv_c1_res_fusable(groups, 10 * groups, groups, mel), "gconv (resize conv + TDSBlock conv): shape not supported");
+    const int64_t T1 = (T_mel - KS) / 2 + 1;
+    const int C = 10 * groups;
+    TAL_CHECK_ARG(gconv_f16x3_fits(T1, C), "gconv (resize conv + TDSBlock conv): one batch item must stay below 2 GiB");
+    GcC1 c1 = {mel, w1, b1, in_mean, T_mel, groups};
+    if (gconv_short_tiles(T1, 256, groups / 4, B)) return launch_c1_res_tt<64>(c1, w_frag, bias, alpha, B, T1, C, groups, y_split, s, range_flag);
+    return launch_c1_res_tt<256>(c1, w_frag, bias, alpha, B, T1, C, groups, y_split, s, range_flag);
 }
 
 int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias, float alpha, int B, int64_t T, int C, int groups,

@@ -51,7 +51,7 @@ def _folded_weights(layer):
         return None
     sa, ca = layer.self_attn, layer.multihead_attn
     E = sa.embed_dim
-    if E % 32 != 0 or layer.linear1.out_features % 16 != 0:
+    if E % 256 != 0 or layer.linear1.out_features % 64 != 0:      # (the two-segment dense kernels: K slices of up to 256 per wave)
         return None
     d = torch.float64
     s = float(E // sa.num_heads) ** -0.5
@@ -60,7 +60,7 @@ def _folded_weights(layer):
     Wq, bq = ca.in_proj_weight.detach()[:E].to(d), ca.in_proj_bias.detach()[:E].to(d)
     Wo2, bo2 = ca.out_proj.weight.detach().to(d), ca.out_proj.bias.detach().to(d)
     W1, b1 = layer.linear1.weight.detach().to(d), layer.linear1.bias.detach().to(d)
-    eye = torch.eye(E, dtype=d, device=Wo.device)
+    eye = torch.zeros(E, E, dtype=d, device=Wo.device)      # (the skip path's half is never read: the kernel adds tgt / x1 itself)
     # (the layer scales q with a single fp32 multiply by s after the bias; here s rides in the weights)
     s32 = float(torch.tensor(s, dtype=torch.float32))
     f_sa_w = torch.cat([torch.cat([rw * Wo, eye], 1), torch.cat([s32 * rw * (Wq @ Wo), s32 * Wq], 1)], 0)

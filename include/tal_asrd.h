@@ -433,6 +433,12 @@ typedef struct tal_greedy_ctx {
      * two vocabularies and 0 beyond it, before every step.  Honoured by tal_greedy_step_fwd and tal_greedy_step_multi_fwd; the
      * one-launch form (option decode_persist) is not taken while it is set. */
     const float* pick_bias;
+    /* != 0: this session's steps never take the folded decoder layer (tal_decoder_layer_w.fold_*), whatever its prefix length.  The fold
+     * pays while a step is latency-bound (one session, or a few in shared launches: -8 % per step) and costs when many sessions share
+     * their launches (8: +12 %, 16: +19 %: the merged dense layers are throughput-bound); a session keeps ONE form for its lifetime so
+     * that its results do not depend on which other sessions happen to step beside it. */
+    uint32_t no_fold;
+    uint32_t _pad2;
 } tal_greedy_ctx;
 size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H, int FF, int V, int E0, int n_layers);
 /* sync: 0 = enqueue only; 1 = copy {token, attention row} to picked_host and wait for the stream; 2 = the last kernel writes

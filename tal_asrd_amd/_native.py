@@ -48,7 +48,8 @@ class GreedyCtx(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("picked_dev", C.c_void_p),
                 ("picked_host", C.c_void_p), ("tickets", C.c_void_p), ("picked_host_dev", C.c_void_p),
                 ("seq", C.c_uint32), ("needs_reset", C.c_uint32), ("k_pitch", C.c_int64), ("kv_all", C.c_void_p), ("kpm_all", C.c_void_p),
-                ("enc_frames", C.c_int64), ("kv_pitch", C.c_int64), ("pick_bias", C.c_void_p)]
+                ("enc_frames", C.c_int64), ("kv_pitch", C.c_int64), ("pick_bias", C.c_void_p),
+                ("no_fold", C.c_uint32), ("_pad2", C.c_uint32)]
 
 
 class UnalignedState(C.Structure):

@@ -481,7 +481,7 @@ static size_t decode_scratch_floats(int U, int S, int E, int H) {
 static int decoder_layer_small(const tal_decoder_layer_w* w, const float* tgt, int B, int U, int S, int E, int H, int FF,
                                const float* tgt_mask, const uint8_t* mem_kpm, const float* ck, const float* cvt, float* out,
                                float* xattn_avg, float* probs_last, const LayerWs& ws, hipStream_t s,
-                               const DecodeScratch* sk = nullptr, int64_t k_pitch = 0) {
+                               const DecodeScratch* sk = nullptr, int64_t k_pitch = 0, bool allow_fold = true) {
     const int M = B * U, hd = E / H;
     const int64_t U4 = pad4(U), S4 = pad4(S);
     const float qscale = 1.0f / sqrtf((float)hd);
@@ -506,7 +506,7 @@ static int decoder_layer_small(const tal_decoder_layer_w* w, const float* tgt, i
     // Folded form (tal_decoder_layer_w.fold_*): the self-attention's out-projection + ReZero and the cross-attention's q projection are
     // ONE dense layer over [ctx | tgt] (x1 | q_c side by side in y3), and so are the cross-attention's out-projection + ReZero and
     // FFN-1 over [ctx2 | x1] (x2 | ff in y5): 6 dependent launches per layer instead of 8.
-    const bool fold = layer_folded(w, E, M);
+    const bool fold = allow_fold && layer_folded(w, E, M);
     const float* qc;
     int64_t ldq;
     if (fold) {
@@ -588,6 +588,7 @@ struct SessionLayerIo {
     float* probs_last;       // [H][S]
     LayerWs ws;
     DecodeScratch sk;
+    bool no_fold;            // the session's tal_greedy_ctx.no_fold
 };
 static int decoder_layer_small_multi_form(const tal_decoder_layer_w* w, const SessionLayerIo* io, int G, int E, int H, int FF, bool fold, hipStream_t s);
 // (sessions on either side of the fold's row limit go through the layer as two groups of launches: each in the form its solo step takes)
@@ -595,7 +596,7 @@ static int decoder_layer_small_multi(const tal_decoder_layer_w* w, const Session
     SessionLayerIo part[2][TAL_GROUP_MAX];
     int n[2] = {0, 0};
     for (int i = 0; i < G; ++i) {
-        const int f = layer_folded(w, E, io[i].U) ? 1 : 0;
+        const int f = (!io[i].no_fold && layer_folded(w, E, io[i].U)) ? 1 : 0;
         part[f][n[f]++] = io[i];
     }
     for (int f = 1; f >= 0; --f)
@@ -705,7 +706,7 @@ static bool greedy_persist_ok(const tal_greedy_ctx* c, int U, int S) {
     const int E = c->E, H = c->H, FF = c->FF, K0 = c->E0 > 0 ? c->E0 : c->E, hd = E / H;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     // (the one-launch form walks the UNFOLDED layer's phases: it is a measurement switch of round 5, valid beside option decode_no_fold)
-    return c->tickets && !c->pick_bias && !layer_folded(&c->layers[0], c->E, U) && c->n_layers <= TAL_PS_MAX_LAYERS && (hd == 128 || hd == 64) && E <= 512 && FF / 4 <= 512 && E % 64 == 0 &&
+    return c->tickets && !c->pick_bias && (c->no_fold || !layer_folded(&c->layers[0], c->E, U)) && c->n_layers <= TAL_PS_MAX_LAYERS && (hd == 128 || hd == 64) && E <= 512 && FF / 4 <= 512 && E % 64 == 0 &&
            small_layer_applicable(1, U, S, E, H, FF, true) && S > 64 && attn_split_tickets(1, U, H) <= 64 && FF >= 2048 && FF % 256 == 0 &&
            64 + (E / 16) * ((U + 31) / 32) <= PS_BAR && E % 16 == 0 && K0 % 8 == 0 && al16(c->emb) && (!c->proj_t || al16(c->proj_t));
 }
@@ -1058,7 +1059,7 @@ extern "C" int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int
         TAL_CHECK_ARG(c->k_cache[l] && c->vt_cache[l], "tal_greedy_step_fwd: layer %d has no cached K / V^T", l);
         if (small)
             rc = decoder_layer_small(&c->layers[l], cur, 1, U, S, E, H, FF, nullptr, c->mem_kpm, c->k_cache[l], c->vt_cache[l], h1,
-                                     nullptr, probs + (size_t)l * H * S, ws, s, c->tickets ? &sk : nullptr, c->k_pitch);
+                                     nullptr, probs + (size_t)l * H * S, ws, s, c->tickets ? &sk : nullptr, c->k_pitch, !c->no_fold);
         else
             rc = decoder_layer_pitched(&c->layers[l], cur, 1, U, nullptr, S, E, H, FF, nullptr, c->mem_kpm, c->k_cache[l],
                                        c->vt_cache[l], h1, avg + (size_t)l * U * S, base, ws.total_floats * sizeof(float), stream, c->k_pitch);
@@ -1190,7 +1191,7 @@ extern "C" int tal_greedy_step_multi_fwd(tal_greedy_ctx* const* ctxs, const int6
         DecodeScratch sk = {p, c->tickets};
         p += up64(decode_scratch_floats(U, S, E, H));
         pick_part[i] = p;
-        io[i].U = U; io[i].S = S; io[i].mem_kpm = c->mem_kpm; io[i].ws = ws; io[i].sk = sk;
+        io[i].U = U; io[i].S = S; io[i].mem_kpm = c->mem_kpm; io[i].ws = ws; io[i].sk = sk; io[i].no_fold = c->no_fold != 0;
         em.tokens[i] = c->tokens + history_start[i];
         em.out[i] = h0[i];
         em.U[i] = U;

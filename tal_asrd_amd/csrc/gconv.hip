@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
     GC_STAMP(0);
 
     if constexpr (FROMC1) {
-        static_assert(CIG == 10 && COG == 10 && STRIDE == 1 && RESID && GB == 4 && XSPLIT && SPLIT == 2 && LY::NSEG == 1 && TIN % 4 == 0, "shape");
+        static_assert(CIG == 10 && COG == 10 && STRIDE == 1 && RESID && GB == 4 && XSPLIT && SPLIT == 2 && LY::NSEG == 1 && TIN % 4 == 0 && P0 % 2 == 0, "shape");
         // ---- the slab from the log-mel: stage the tile's mel rows ([row][4 bins], 16-byte loads), then thread = (channel of the
         // workgroup, row phase): a channel's 21 weights + bias in registers, four consecutive rows share their 27 samples ----
         constexpr int NR = 2 * (TIN - 1) + KS;                       // mel rows behind TIN rows of the stage
@@ -568,44 +568,57 @@ __global__ __launch_bounds__(256, GC_LB(CIG, STRIDE)) void gconv_mfma_kernel(con
         }
         __syncthreads();
         float amax = 0.f;
-        if (tid < GB * CIG * 6) {
-            const int chn = tid % (GB * CIG), ph = tid / (GB * CIG);
-            const int gl = chn / CIG, ci = chn - gl * CIG, g = g0 + gl;
-            float wk[KS];
+        // A thread owns a channel PAIR (packed fp32 multiply-adds: on this chip a SIMD's vector ALU time is what the conv phase
+        // behind competes for -- the first version, one channel per thread, made the launch 0.27 ms slower than the two it replaces)
+        // and one of 12 row phases; per element the fmaf chain of gconv_s2_c1_kernel, so the halves are bit-identical to its output.
+        constexpr int NPAIR = GB * CIG / 2, NPH = 256 / NPAIR;          // 20 pairs x 12 phases = 240 threads
+        if (tid < NPAIR * NPH) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const int pr = tid % NPAIR, ph = tid / NPAIR;
+            const int gl = pr / (CIG / 2), ci = 2 * (pr - gl * (CIG / 2)), g = g0 + gl;
+            f32x2 wk[KS];
 #pragma unroll
-            for (int k = 0; k < KS; ++k) wk[k] = c1.w1[((int64_t)g * KS + k) * COG + ci];
-            float bv = c1.b1[g * COG + ci];
+            for (int k = 0; k < KS; ++k) wk[k] = *reinterpret_cast<const f32x2*>(c1.w1 + ((int64_t)g * KS + k) * COG + ci);
+            f32x2 bv = *reinterpret_cast<const f32x2*>(c1.b1 + g * COG + ci);
             if (c1.mean) {
-                float wsum = wk[0];
+                f32x2 wsum = wk[0];
 #pragma unroll
                 for (int k = 1; k < KS; ++k) wsum += wk[k];
-                bv = fmaf(-c1.mean[0], wsum, bv);
+                const float m = -c1.mean[0];
+                bv[0] = fmaf(m, wsum[0], bv[0]);
+                bv[1] = fmaf(m, wsum[1], bv[1]);
             }
             const float* xc = xs + gl;
             _Float16* dh = s_hi + gl * GS + ci;
             _Float16* dl = s_lo + gl * GS + ci;
-            for (int rq = ph; rq < TIN / 4; rq += 6) {
+            for (int rq = ph; rq < TIN / 4; rq += NPH) {
                 const int r = 4 * rq;
                 float xv[KS + 6];
 #pragma unroll
                 for (int i = 0; i < KS + 6; ++i) xv[i] = xc[(2 * r + i) * GB];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float acc = bv;
+                    f32x2 acc = bv;
 #pragma unroll
-                    for (int k = 0; k < KS; ++k) acc = fmaf(wk[k], xv[2 * q + k], acc);
+                    for (int k = 0; k < KS; ++k) {
+                        const f32x2 xx = {xv[2 * q + k], xv[2 * q + k]};
+                        acc = __builtin_elementwise_fma(wk[k], xx, acc);
+                    }
                     const int64_t tg = t0 - PADT + r + q;
                     const bool inside = tg >= 0 && tg < T_in;         // outside: the TDSBlock conv's zero padding
-                    _Float16 hi, lo;
-                    split_f16x3(acc, hi, lo);
-                    if (inside) amax = fmaxf(amax, fabsf(acc));
-                    dh[(r + q) * P0] = inside ? hi : (_Float16)0.f;
-                    dl[(r + q) * P0] = inside ? lo : (_Float16)0.f;
-                    if (ci == CIG - 1) {                              // this row's pad columns (finite bytes under zero weights)
+                    _Float16 h0, l0, h1, l1;
+                    split_f16x3(acc[0], h0, l0);
+                    split_f16x3(acc[1], h1, l1);
+                    if (inside) amax = fmaxf(amax, fmaxf(fabsf(acc[0]), fabsf(acc[1])));
+                    const f16x2 zz = {(_Float16)0.f, (_Float16)0.f};
+                    const f16x2 hh = {h0, h1}, ll = {l0, l1};
+                    *reinterpret_cast<f16x2*>(dh + (r + q) * P0) = inside ? hh : zz;
+                    *reinterpret_cast<f16x2*>(dl + (r + q) * P0) = inside ? ll : zz;
+                    if (ci == CIG - 2) {                              // this row's pad columns (finite bytes under zero weights)
 #pragma unroll
-                        for (int j = 1; j <= P0 - CIG; ++j) {
-                            dh[(r + q) * P0 + j] = (_Float16)0.f;
-                            dl[(r + q) * P0 + j] = (_Float16)0.f;
+                        for (int j = 2; j + 1 < P0 - CIG + 2; j += 2) {
+                            *reinterpret_cast<f16x2*>(dh + (r + q) * P0 + j) = zz;
+                            *reinterpret_cast<f16x2*>(dl + (r + q) * P0 + j) = zz;
                         }
                     }
                 }

@@ -51,7 +51,7 @@ class _GreedySession:
     embedding / LM-head tensors, one workspace sized for the longest prefix, the {token, attention row} result buffer
     and its pinned host mirror.  `set_window` points it at the cached cross-attention K / V^T of an encoder window."""
 
-    def __init__(self, model, gen_dev, max_positions, sync_mode=2):
+    def __init__(self, model, gen_dev, max_positions, sync_mode=2, fold=True):
         from . import decoder as D
         lib = N.lib()
         self.lib = lib
@@ -74,6 +74,7 @@ class _GreedySession:
             self._proj_t = D._proj_t(model)
             c.proj, c.proj_t = model.embedding_proj.weight.data_ptr(), self._proj_t.data_ptr()
         c.pe = model.pos_dec_encoder.pe.data_ptr()
+        c.no_fold = 0 if fold else 1      # (one form of the decoder layer for the session's lifetime: include/tal_asrd.h, tal_greedy_ctx.no_fold)
         self.dev = emb.device
         self._stream = N.stream_handle()          # the stream current at construction carries every step
         self._tickets = torch.zeros(256, dtype=torch.int32, device=emb.device)   # arrival tickets, self-resetting
@@ -178,8 +179,9 @@ class _UnalignedRun:
     uploaded, more room, or is finished.  Token stream and alignment records live in flat numpy buffers the struct points to."""
 
     def __init__(self, system, audio_x, generated, audio_lens, chunk_size=357, max_iters=1000000, max_positions=None,
-                 thresh_prct=0.5, shift_prct=0.25, stall_patience=25, rep_n=5, skip_prct=0.1):
+                 thresh_prct=0.5, shift_prct=0.25, stall_patience=25, rep_n=5, skip_prct=0.1, fold_layers=True):
         model = system.model
+        self.fold_layers = fold_layers
         if generated.size(0) != 1:
             raise ValueError("generate_unaligned handles one episode at a time (system.py:331,411 call .item())")
         self.system, self.model = system, model
@@ -312,7 +314,7 @@ class _UnalignedRun:
             # embed -> decoder stack on the window's cached K / V^T -> LM head of the last position -> pick + append on the
             # device -> {token, attention row} in pinned host memory
             if self.session is None:
-                self.session = _GreedySession(self.model, self.gen_dev, self.max_positions)
+                self.session = _GreedySession(self.model, self.gen_dev, self.max_positions, fold=self.fold_layers)
             if self.session.gen_dev is not self.gen_dev:
                 self.session.set_tokens(self.gen_dev)
             if view:
@@ -421,6 +423,8 @@ class System:
         # sections that go through it are serialised; the per-token C call of a decode session needs no lock
         self._lock = threading.RLock()
 
+    FOLD_GROUP_MAX = 8      # transcribe_unaligned_many: sessions of groups this large decode on the unfolded decoder layer
+
     # ------------------------------------------------------------------ several episodes in flight
     @torch.no_grad()
     def transcribe_unaligned_many(self, episodes, streams=None, group=None, stats=None, **kw):
@@ -457,7 +461,10 @@ class System:
         by window otherwise: slower window moves, same results.
 
         episodes: list of (audio [1, L] float tensor -- host (pinned or not) or device --, audio_lens LongTensor [1]).
-        Returns [(utterance dicts, generated, alignments)] in episode order, identical to the solo runs in either mode."""
+        Returns [(utterance dicts, generated, alignments)] in episode order: token streams, window starts and utterances identical to
+        the solo runs in either mode; attention rows bit-identical to them too, except in groups of FOLD_GROUP_MAX sessions or more,
+        whose sessions decode on the unfolded decoder layer (rows then equal a solo run with fold_layers=False bit for bit and the
+        default solo run to ~1e-6: the folded layer re-associates two weight products)."""
         if not episodes:
             return []
         if self.lm is not None and self.args.lm_weight > 0:
@@ -534,7 +541,9 @@ class System:
                             break
                         x = audio.to(dev, non_blocking=True)
                         prime = torch.full((1, 1), self.tokenizer.eos_token_id, dtype=torch.int64, device=dev)
-                        run = _UnalignedRun(self, x, prime, lens, 357, **kw)
+                        # (groups of FOLD_GROUP_MAX sessions or more: the merged dense layers are throughput-bound and the folded
+                        #  decoder layer costs there -- these sessions keep the eight-launch layer for all their steps)
+                        run = _UnalignedRun(self, x, prime, lens, 357, **dict(kw, fold_layers=kw.get("fold_layers", True) and group < self.FOLD_GROUP_MAX))
                         if not run.done:
                             run.prepare()
                             run.consume(*run.step_alone())
@@ -759,12 +768,12 @@ class System:
     @torch.no_grad()
     def generate_unaligned(self, audio_x, generated, audio_lens, chunk_size=357, max_iters=1000000,
                            max_positions=None, thresh_prct=0.5, shift_prct=0.25, stall_patience=25, rep_n=5,
-                           skip_prct=0.1):
+                           skip_prct=0.1, fold_layers=True):
         """system.py:254-524 (designed for batch 1: it calls .item() on per-batch tensors).
         Returns (generated [1, N] LongTensor on the input device, alignments: list of
         (chunk_start LongTensor[1], attention [1, S] CPU tensor) per generated token)."""
         run = _UnalignedRun(self, audio_x, generated, audio_lens, chunk_size, max_iters, max_positions, thresh_prct, shift_prct,
-                            stall_patience, rep_n, skip_prct)
+                            stall_patience, rep_n, skip_prct, fold_layers)
         while not run.done:
             run.prepare()
             run.consume(*run.step_alone())

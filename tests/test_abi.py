@@ -48,7 +48,7 @@ def test_struct_layout_matches_header():
     expect += 8                              # flags + pad
     assert C.sizeof(_native.TdsDesc) == expect
     assert _native.TdsDesc.flags.offset == expect - 8
-    assert C.sizeof(_native.GreedyCtx) == 8 + 8 * 4 + 8 * 8 + 8 + 8 + 3 * 8 + 8 + 8 + 5 * 8 + 8    # pointer, 8 ints, 8 pointers, workspace + size, 3 pointers, device alias, seq + pad, pitch + episode table, pick_bias
+    assert C.sizeof(_native.GreedyCtx) == 8 + 8 * 4 + 8 * 8 + 8 + 8 + 3 * 8 + 8 + 8 + 5 * 8 + 8 + 8    # pointer, 8 ints, 8 pointers, workspace + size, 3 pointers, device alias, seq + pad, pitch + episode table, pick_bias, no_fold + pad
 
 
 def test_struct_layouts_against_the_c_compiler(tmp_path):

@@ -126,13 +126,19 @@ def test_sessions_in_flight_reproduce_their_solo_runs(asr_weights):
         a = synth.synth_audio_batch(1, L, 2469 + k).astype(np.float16).astype(np.float32)
         eps.append((torch.from_numpy(a).pin_memory(), torch.tensor([L])))
     solo = [system.transcribe_unaligned(a.to(dev), lens) for a, lens in eps]
+    # groups of System.FOLD_GROUP_MAX sessions or more decode on the unfolded decoder layer (the fold costs where merged dense layers are
+    # throughput-bound): their rows equal the solo run with fold_layers=False bit for bit, the default solo run to rounding
+    solo_nf = [system.transcribe_unaligned(a.to(dev), lens, fold_layers=False) for a, lens in eps]
+    for (u1, g1, al1), (u2, g2, al2) in zip(solo, solo_nf):
+        assert torch.equal(g1.cpu(), g2.cpu()) and [int(c[0]) for c, _ in al1] == [int(c[0]) for c, _ in al2]
+        assert max(float((a1 - a2).abs().max()) for (_, a1), (_, a2) in zip(al1, al2)) < 1e-5
     # (streams, group): one chain of launches per session on its own stream | sessions advanced in step through SHARED launches
     # (tal_greedy_step_multi_fwd): five in one group; groups of two and three on two threads, slots refilled as episodes end
     # (None, None): the default split -- four threads x groups of ceil(episodes / 4)
     for streams, group in ((2, 1), (5, 1), (1, 8), (2, 2), (2, 3), (None, None)):
         many = system.transcribe_unaligned_many(eps, streams=streams, group=group)
         assert len(many) == len(solo)
-        for (u1, g1, al1), (u2, g2, al2) in zip(solo, many):
+        for (u1, g1, al1), (u2, g2, al2) in zip(solo_nf if (group or 0) >= System.FOLD_GROUP_MAX else solo, many):
             assert torch.equal(g1.cpu(), g2.cpu())
             assert [int(c[0]) for c, _ in al1] == [int(c[0]) for c, _ in al2]
             for (_, a1), (_, a2) in zip(al1, al2):
@@ -146,7 +152,7 @@ def test_sessions_in_flight_reproduce_their_solo_runs(asr_weights):
     try:
         for streams, group in ((1, 1), (1, 8), (3, 2)):
             many = system.transcribe_unaligned_many(eps, streams=streams, group=group)
-            for (u1, g1, al1), (u2, g2, al2) in zip(solo, many):
+            for (u1, g1, al1), (u2, g2, al2) in zip(solo_nf if group >= System.FOLD_GROUP_MAX else solo, many):
                 assert torch.equal(g1.cpu(), g2.cpu()) and all(torch.equal(a1, a2) and int(c1[0]) == int(c2[0]) for (c1, a1), (c2, a2) in zip(al1, al2))
     finally:
         S_._UnalignedRun.HOST_TOKENS0, S_._UnalignedRun.DEV_TOKENS0 = keep

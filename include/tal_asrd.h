@@ -505,7 +505,8 @@ typedef struct tal_unaligned_state {
 #define TAL_UNALIGNED_ALONE 16            /* (group_run) the next step does not take the merged kernels' forms: step it alone */
 /* One step's result {token, attention row [S]} -> state.  Returns the flags (>= 0) or a negative TAL_E* code. */
 int tal_unaligned_consume(tal_unaligned_state* st, int64_t token, const float* attn, int S);
-/* Advance G sessions (state i <-> context i) by merged steps (tal_greedy_step_multi_fwd + poll +
+/* G == 1: the same loop on the session's own launches (tal_greedy_step_fwd with sync 3; any prefix length).
+ * Advance G sessions (state i <-> context i) by merged steps (tal_greedy_step_multi_fwd + poll +
  * tal_unaligned_consume per session) until a session raises a flag the library cannot serve itself -- it moves a window that is
  * a view of the context's episode-wide K | V table (tal_greedy_set_window) and uploads a rewritten prefix from a pinned token
  * stream; DONE, GROW, ALONE and windows outside the table go back to the caller -- or max_steps steps are done.  Returns the number of steps

@@ -45,8 +45,11 @@ for k, gsz in modes:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     many = system.transcribe_unaligned_many(eps, streams=k, group=gsz)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    # tokens and window starts identical to the solo runs always; attention rows bit-identical unless the group is large enough for its
+    # sessions to decode on the unfolded decoder layer (System.FOLD_GROUP_MAX): then equal to rounding (the fold re-associates weights)
+    unfolded = gsz is not None and gsz >= System.FOLD_GROUP_MAX
     same = all(torch.equal(a[1].cpu(), b[1].cpu()) and [int(c[0]) for c, _ in a[2]] == [int(c[0]) for c, _ in b[2]] and
-               all(torch.equal(x[1], y[1]) for x, y in zip(a[2], b[2])) for a, b in zip(solo, many))
+               all((float((x[1] - y[1]).abs().max()) < 1e-5) if unfolded else torch.equal(x[1], y[1]) for x, y in zip(a[2], b[2])) for a, b in zip(solo, many))
     what = "default split (streams=None, group=None)" if k is None else "%2d sessions in flight, own launches" % k if gsz == 1 else "%d thread(s) x groups of %d sessions, shared launches" % (k, gsz)
-    print("%s: %.3f s = %.0f frames/s (%.2fx one at a time), %.3f ms per step overall, trajectories identical: %s"
-          % (what, dt, n_ep * frames / dt, t_solo / dt, 1e3 * dt / steps, same), flush=True)
+    print("%s: %.3f s = %.0f frames/s (%.2fx one at a time), %.3f ms per step overall, trajectories identical%s: %s"
+          % (what, dt, n_ep * frames / dt, t_solo / dt, 1e3 * dt / steps, " (rows to 1e-5: unfolded layer)" if unfolded else "", same), flush=True)

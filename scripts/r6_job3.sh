@@ -9,7 +9,7 @@ echo "pytest rc=$?" >> $O/pytest_parity.txt
 (timeout 900 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_flow.py tests/test_gpu_episode.py -m gpu -x -q) > $O/pytest_decode.txt 2>&1
 echo "pytest rc=$?" >> $O/pytest_decode.txt
 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-exact-pass --no-per-rank-share > $O/bench_1h_fused.json 2> $O/bench_1h.err
-TAL_OPTIONS=gconv_no_c1_fuse python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode > $O/bench_1h_unfused.json 2> /dev/null
+TAL_OPTIONS=gconv_c1_fuse=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode > $O/bench_1h_unfused.json 2> /dev/null
 python scripts/bench_greedy_step.py 1 16 32 48 64 96 128 256 > $O/decode_step_folded.txt 2>&1
 TAL_OPTIONS=decode_fold_rows=512 python scripts/bench_greedy_step.py 1 16 32 48 64 96 128 256 > $O/decode_step_folded_always.txt 2>&1
 TAL_OPTIONS=decode_no_fold python scripts/bench_greedy_step.py 1 16 32 48 64 96 128 256 > $O/decode_step_unfolded.txt 2>&1

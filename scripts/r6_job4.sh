@@ -9,7 +9,7 @@ echo "pytest rc=$?" >> $O/pytest_parity.txt
 (timeout 1200 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_flow.py tests/test_gpu_episode.py -m gpu -x -q) > $O/pytest_decode.txt 2>&1
 echo "pytest rc=$?" >> $O/pytest_decode.txt
 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency > $O/bench_1h_fused.json 2> $O/bench_1h.err
-TAL_OPTIONS=gconv_no_c1_fuse python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency > $O/bench_1h_unfused.json 2> /dev/null
+TAL_OPTIONS=gconv_c1_fuse=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency > $O/bench_1h_unfused.json 2> /dev/null
 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency > $O/bench_1h_fused_b.json 2> /dev/null
 python scripts/bench_episode_streams.py 3600 8 2>&1 | grep -v amdgpu.ids > $O/episode_streams_8x1h.txt
 grep -h "passed\|failed\|rc=" $O/pytest_parity.txt $O/pytest_decode.txt

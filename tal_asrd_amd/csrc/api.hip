@@ -20,7 +20,7 @@ void set_error(const char* fmt, ...) {
 // ---- behaviour switches (tal_set_option) ---------------------------------------------------
 static const char* const g_opt_names[OPT_COUNT] = {
     "tds_exact_f32", "tds_fp32_activations", "gconv_fuse_split", "gconv_c1_generic", "head_no_astationary", "gemm_global_loads",
-    "gemm_no_splitk4", "gemm_no_glds", "gemm_no_splitk_tail", "gemm_no_w64", "logmel_no_fold", "decode_no_small", "decode_small_rows", "gemm_no_row_split", "gemm_no_n96", "gemm_s64_below", "gconv_short_below", "gconv_no_shift18", "gconv_grid_xyz", "gemm_w64_stagger", "gemm_s64_order", "decode_wide_gemm", "gemm_s64_rows", "decode_persist", "decode_persist_wgs", "logmel_mfma", "gru_unfused", "decode_no_fold", "gconv_no_c1_fuse", "decode_fold_rows"};
+    "gemm_no_splitk4", "gemm_no_glds", "gemm_no_splitk_tail", "gemm_no_w64", "logmel_no_fold", "decode_no_small", "decode_small_rows", "gemm_no_row_split", "gemm_no_n96", "gemm_s64_below", "gconv_short_below", "gconv_no_shift18", "gconv_grid_xyz", "gemm_w64_stagger", "gemm_s64_order", "decode_wide_gemm", "gemm_s64_rows", "decode_persist", "decode_persist_wgs", "logmel_mfma", "gru_unfused", "decode_no_fold", "gconv_c1_fuse", "decode_fold_rows"};
 static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {256}, {0}, {0}, {2}, {4}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {32}, {0}, {0}, {0}, {0}, {64}};
 int opt(Option o) { return g_opt[o].load(std::memory_order_relaxed); }
 
@@ -511,9 +511,11 @@ static int tds_fwd_impl(const tal_tds_desc* d, const float* x, const float* x_me
         // resize conv: cur -> a (a buffer other than cur's)
         const int io = (ia + 1) % 4;
         float* a = (last_stage && d->depths[i] == 0) ? y : buf[io];
-        // the first stage's resize conv (1 mel bin -> 10 channels per group) runs INSIDE the first TDSBlock conv's launch (round 6):
-        // its output is computed straight into that kernel's LDS slab and never touches memory
-        const bool c1_fused = allsplit && i == 0 && !cur_split && !s2_mfma_ok(i, Tc) && d->depths[i] > 0 && !opt(OPT_GCONV_NO_C1_FUSE) &&
+        // option gconv_c1_fuse (round 6, off by default): the first stage's resize conv (1 mel bin -> 10 channels per group) runs INSIDE the
+        // first TDSBlock conv's launch -- its output is computed straight into that kernel's LDS slab and never touches memory.  Bit-identical
+        // and one launch + 1.15 GB of traffic per hour of audio less, but the conv's 3 G multiply-adds cost the same ~0.25 ms inside the
+        // matrix-core kernel as in a launch of their own (profiles/r6_gconv_c1_fusion.txt): measured, kept for the record, not the default
+        const bool c1_fused = allsplit && i == 0 && !cur_split && !s2_mfma_ok(i, Tc) && d->depths[i] > 0 && opt(OPT_GCONV_C1_FUSE) &&
                               !opt(OPT_GCONV_C1_GENERIC) && gconv_c1_res_fusable(cin, c, d->groups, cur);
         if (c1_fused) {
             rc = TAL_OK;

@@ -124,7 +124,7 @@ enum Option {
     OPT_LOGMEL_MFMA,              // log-mel as the float64 matrix-core DFT of rounds 1-4 instead of the fast transform on the vector ALU
     OPT_GRU_UNFUSED,              // GRU cell as two dense launches + a gate kernel (rounds 1-5) instead of the one-launch step
     OPT_DECODE_NO_FOLD,           // latency-oriented decoder layer on its eight launches even when the folded weights are there (six)
-    OPT_GCONV_NO_C1_FUSE,         // first resize conv and first TDSBlock conv as two launches (rounds 1-5) instead of one
+    OPT_GCONV_C1_FUSE,            // first resize conv computed inside the first TDSBlock conv's launch (round 6: bit-identical, no faster -- off)
     OPT_DECODE_FOLD_ROWS,         // the folded decoder layer is taken up to this many rows (prefix tokens) per problem (default 64)
     OPT_COUNT
 };

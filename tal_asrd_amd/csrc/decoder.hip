@@ -1426,7 +1426,7 @@ extern "C" int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greed
             if (st[i]->n + 1 >= st[i]->gen_cap || st[i]->n_rec + 1 >= st[i]->rec_cap || st[i]->n + 1 > dev_cap[i]) {
                 st[i]->flags |= TAL_UNALIGNED_GROW;
                 go = false;
-            } else if (!tal_greedy_group_ok(ctxs[i], st[i]->history_start, st[i]->n)) {
+            } else if (G > 1 && !tal_greedy_group_ok(ctxs[i], st[i]->history_start, st[i]->n)) {
                 st[i]->flags |= TAL_UNALIGNED_ALONE;
                 go = false;
             }
@@ -1435,7 +1435,10 @@ extern "C" int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greed
         }
         if (!go) return step;
         int rc;
-        GT(t_launch, rc = tal_greedy_step_multi_fwd(ctxs, hs, ng, G, stream));
+        // (one session: its OWN launches -- tal_greedy_step_fwd, every form of it -- so that System.generate_unaligned's solo loop can
+        //  stay inside the library between the decisions that need Python, exactly as a group's does)
+        if (G == 1) GT(t_launch, rc = tal_greedy_step_fwd(ctxs[0], hs[0], ng[0], 3, stream));
+        else GT(t_launch, rc = tal_greedy_step_multi_fwd(ctxs, hs, ng, G, stream));
         if (rc) return rc;
 #ifdef TAL_GROUP_TIMING
         n_steps += 1; n_sess += G;

@@ -83,6 +83,9 @@ class _GreedySession:
         self.ws = None
         self._ctx_ref = C.byref(self.ctx)
         self._sync_mode = sync_mode      # 2: result written straight to pinned memory and polled; 1: copy command + stream wait
+        # may the library loop over this session's steps itself (sync 3: the merged LM-head + pick kernel writes the result word)?
+        K0 = c.E0 if c.E0 > 0 else c.E
+        self.host_direct_ok = c.E % 16 == 0 and K0 % 8 == 0 and c.emb % 16 == 0 and (not c.proj_t or c.proj_t % 16 == 0)
         self.set_tokens(gen_dev)
 
     def set_tokens(self, gen_dev):
@@ -774,7 +777,20 @@ class System:
         (chunk_start LongTensor[1], attention [1, S] CPU tensor) per generated token)."""
         run = _UnalignedRun(self, audio_x, generated, audio_lens, chunk_size, max_iters, max_positions, thresh_prct, shift_prct,
                             stall_patience, rep_n, skip_prct, fold_layers)
+        lib = N.lib()
+        st_arr, ctx_arr, cap_arr = (C.POINTER(N.UnalignedState) * 1)(), (C.POINTER(N.GreedyCtx) * 1)(), (C.c_int64 * 1)()
+        handle = N.stream_handle()
         while not run.done:
             run.prepare()
-            run.consume(*run.step_alone())
+            if run.st.it == 0 or run.lm_active or not run.session.host_direct_ok:
+                # the first step goes through the module API; an LM's forward pass runs between the steps on this side of the C ABI
+                run.consume(*run.step_alone())
+                continue
+            # every other step: step -> poll -> consume inside the library (tal_unaligned_group_run with one session = its own launches),
+            # back here only when the control flow asks for something Python owns (a window outside the K | V table, more room, the end):
+            # ~10 us of interpreter time per generated token less than the loop above, same calls in the same order
+            st_arr[0], ctx_arr[0], cap_arr[0] = C.pointer(run.st), C.pointer(run.session.ctx), run.gen_dev.numel()
+            rc = lib.tal_unaligned_group_run(st_arr, ctx_arr, cap_arr, 1, 4096, handle)
+            if rc < 0:
+                N.check(rc, "tal_unaligned_group_run")
         return run.result()

@@ -729,10 +729,10 @@ def test_sd_b4_split_over_two_ranks_with_the_combined_mean(sd_model):
 
 @pytest.mark.parametrize("B,seconds", [(1, 30), (1, 300), (2, 47), (1, 1200), (8, 300)])
 def test_first_resize_conv_inside_the_first_block_conv_launch(sd_model, B, seconds):
-    """Round 6: the encoder's first resize conv (1 mel bin -> 10 channels per group, tal/asr/models.py:363-364) is computed straight
-    into the LDS slab of the first TDSBlock conv's launch (gconv_mfma_kernel<.., FROMC1>: same fmaf chain, mean fold and hi / lo
-    split as gconv_s2_c1_kernel) -- the stage's first activation never exists in memory.  Against the two launches of rounds 1-5
-    (option gconv_no_c1_fuse): features and speaker ids BIT-identical, with and without the folded mean, short (64-step) and long
+    """Round 6, option gconv_c1_fuse (measured no faster, off by default): the encoder's first resize conv (1 mel bin -> 10 channels per
+    group, tal/asr/models.py:363-364) computed straight into the LDS slab of the first TDSBlock conv's launch (gconv_mfma_kernel<..,
+    FROMC1>: same fmaf chain, mean fold and hi / lo split as gconv_s2_c1_kernel) -- the stage's first activation never exists in
+    memory.  Against the two launches of the default path: features and speaker ids BIT-identical, with and without the folded mean, short (64-step) and long
     (256-step) tiles, a batch, a length whose last tile is partial."""
     from tal_asrd_amd import _native as N, ops, synth
     L = seconds * 16000 + 1234
@@ -741,14 +741,14 @@ def test_first_resize_conv_inside_the_first_block_conv_launch(sd_model, B, secon
     out = {}
     try:
         for nofuse in (0, 1):
-            N.set_option("gconv_no_c1_fuse", nofuse)
+            N.set_option("gconv_c1_fuse", 1 - nofuse)
             with torch.no_grad():
                 f, i = sd_model.speaker_ids(audio)                   # the mean rides in the first conv's bias
                 mel = sd_model.extract_features(audio)               # the mean already subtracted
                 y = ops.tds_forward(enc._descriptor(0, len(enc.sizes) - 1), mel, enc.sizes[-1])
             out[nofuse] = (f.clone(), i.clone(), y.clone())
     finally:
-        N.set_option("gconv_no_c1_fuse", 0)
+        N.set_option("gconv_c1_fuse", 0)
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     assert torch.equal(out[0][2], out[1][2])
 

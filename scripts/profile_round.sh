@@ -1,14 +1,14 @@
 #!/bin/bash
 # One GPU job that regenerates the round's measurement artefacts (run through gpurun; copy the results from
-# gpurun_out/r5final/ into profiles/ with the r5_ prefix): bench lines of every workload, rocprofv3 kernel stats,
+# gpurun_out/r6final/ into profiles/ with the r6_ prefix): bench lines of every workload, rocprofv3 kernel stats,
 # FETCH / WRITE traffic passes, SQ counter passes, decode-step and short-clip traces.  PMC passes are separate runs with
 # --kernel-trace only, as the pool requires; every profiled program is `python3 <script>` directly after `--`.
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r5final
+O=$R/gpurun_out/r6final
 mkdir -p $O
 cd $R
-python bench.py > $O/bench_1h.json 2> $O/bench_1h.err
+python bench.py --steps 20 --warmup 3 > $O/bench_1h.json 2> $O/bench_1h.err
 TAL_OPTIONS=gemm_no_w64 python bench.py --no-cpu-baseline --no-exact-pass > $O/bench_1h_128row_tiles.json 2> /dev/null
 TAL_OPTIONS=tds_exact_f32 python bench.py --no-cpu-baseline > $O/bench_1h_fp32.json 2> $O/bench_1h_fp32.err
 TAL_OPTIONS=tds_fp32_activations python bench.py --no-cpu-baseline > $O/bench_1h_fp32_activations.json 2> /dev/null
@@ -18,15 +18,18 @@ python bench.py --workload decode --steps 2 --warmup 1 > $O/bench_decode_1h_epis
 python scripts/bench_gconv_grid.py > $O/gconv_grid.txt 2>&1
 python scripts/bench_greedy_step_multi.py 32 2>&1 | grep -v amdgpu.ids > $O/decode_step_merged.txt
 python scripts/bench_short.py 10 30 60 120 300 600 > $O/short_clips_product.txt 2>&1
-python scripts/bench_greedy_step.py 1 16 32 64 128 256 > $O/decode_step.txt 2>&1
+python scripts/bench_greedy_step.py 1 16 32 48 64 96 128 256 > $O/decode_step.txt 2>&1
+TAL_OPTIONS=decode_no_fold python scripts/bench_greedy_step.py 1 16 32 48 64 96 128 256 > $O/decode_step_unfolded_layer.txt 2>&1
+TAL_OPTIONS=decode_no_fold python scripts/bench_greedy_step_multi.py 32 2>&1 | grep -v amdgpu.ids > $O/decode_step_merged_unfolded_layer.txt
+python scripts/r6_uisrnn_predict.py 2>&1 | grep -v amdgpu.ids > $O/uisrnn_predict.txt
 python scripts/bench_episode_streams.py 3600 8 2>&1 | grep -v amdgpu.ids > $O/episode_streams.txt
 cd /tmp && export TMPDIR=/tmp
 # (only the 1-hour steps may be in the stats table: its averages are what roofline.avg_launch_ms is checked against)
-rocprofv3 --kernel-trace --stats -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency > $O/bench_1h_under_rocprof.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $O/pmc_sq -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency --steps 2 --warmup 1 > $O/pmc_sq.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE -d $O/pmc_inst -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency --steps 2 --warmup 1 > $O/pmc_inst.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency --no-clock-sampler > $O/bench_1h_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency --steps 2 --warmup 1 --passes 1 --no-clock-sampler > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency --steps 2 --warmup 1 --passes 1 --no-clock-sampler > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $O/pmc_sq -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency --steps 2 --warmup 1 --passes 1 --no-clock-sampler > $O/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE -d $O/pmc_inst -- python3 $R/bench.py --no-cpu-baseline --no-exact-pass --no-per-rank-share --no-decode-episode --no-clip-latency --steps 2 --warmup 1 --passes 1 --no-clock-sampler > $O/pmc_inst.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/dstats -- python3 $R/scripts/bench_episode.py 300 > $O/decode_5min_under_rocprof.log 2>&1
 REPS=3 rocprofv3 --kernel-trace -d $O/gstep -- python3 $R/scripts/bench_greedy_step.py 32 > $O/gstep.log 2>&1
 REPS=3 rocprofv3 --kernel-trace -d $O/short -- python3 $R/scripts/bench_short.py 30 > $O/short.log 2>&1

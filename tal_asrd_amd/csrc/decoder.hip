@@ -1402,9 +1402,118 @@ static int unaligned_serve(tal_unaligned_state* st, tal_greedy_ctx* c, int64_t d
     return TAL_OK;
 }
 
+extern "C" size_t tal_greedy_result_stride(int S) { return S > 0 ? (size_t)((2 + S + 15) / 16) * 16 : 0; }
+
+// ONE session on its own launches, with the NEXT step enqueued while the current one runs (tal_greedy_ctx.picked_pair).
+// A generated token costs ~26 dependent launches and then a trip through the host -- the result word lands in pinned memory, the
+// control flow (tal_unaligned_consume) looks at it, the next call's first launch starts from an idle GPU: ~13 us of every ~260.
+// But the device already has everything the next step reads (the pick appended its token to the device-resident prefix), and in
+// ~98 % of the steps the control flow only says "go on": so step k + 1 is enqueued for the prefix one token longer BEFORE step k's
+// result is back, into the other result buffer.  If consume(k) leaves the state exactly there (same window, same history start,
+// n + 1, no flags), that launch chain IS step k + 1 -- same launches on the same operands as without speculation, bit-identical -- and
+// the GPU went from one step into the next without waiting.  Otherwise (window move, roll-back, forced EOS, end of the episode) the
+// speculated step is waited for and dropped: whatever the control flow then asks for is enqueued BEHIND it in the stream, and its
+// token lands one slot behind the valid prefix, where the next real step writes its own.
+static int unaligned_run_solo(tal_unaligned_state* st, tal_greedy_ctx* c, int64_t dev_cap, int max_steps, void* stream) {
+    TAL_CHECK_ARG(c->picked_host && c->tickets && c->S > 0, "tal_unaligned_group_run: the session has no pinned result buffer / tickets");
+    const int S = c->S;
+    const size_t stride = tal_greedy_result_stride(S);
+    float* const base_host = c->picked_host;
+    if (!c->picked_host_dev) {
+        void* alias = nullptr;
+        if (hipHostGetDevicePointer(&alias, base_host, 0) != hipSuccess || !alias) {
+            set_error("tal_unaligned_group_run: picked_host is not mapped pinned host memory (%s)", hipGetErrorString(hipGetLastError()));
+            return TAL_EINVAL;
+        }
+        c->picked_host_dev = reinterpret_cast<float*>(alias);
+        reinterpret_cast<volatile unsigned*>(base_host)[1 + S] = 0u;
+        if (c->picked_pair) reinterpret_cast<volatile unsigned*>(base_host + stride)[1 + S] = 0u;
+    }
+    float* const base_dev = c->picked_host_dev;
+    float* const hostbuf[2] = {base_host, base_host + stride};
+    float* const devbuf[2] = {base_dev, base_dev + stride};
+    const bool pair = c->picked_pair != 0;
+    auto launch = [&](int buf, int64_t hs, int64_t n, unsigned* seq) {
+        c->picked_host = hostbuf[buf];
+        c->picked_host_dev = devbuf[buf];
+        const int rc = tal_greedy_step_fwd(c, hs, n, 3, stream);
+        *seq = c->seq;
+        c->picked_host = base_host;
+        c->picked_host_dev = base_dev;
+        return rc;
+    };
+    auto wait = [&](int buf, unsigned seq) {       // -> 0: delivered; TAL_EHIP: no result after 20 s / the failure marker
+        volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(hostbuf[buf] + 1 + S);
+        if (*flag != seq) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0; *flag != seq; ++spins)
+                if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
+        }
+        if (*flag != seq) {
+            const hipError_t e = hipStreamSynchronize((hipStream_t)stream);      // nothing may stay in flight behind an error
+            set_error("tal_unaligned_group_run: no result after 20 s (stream after the wait: %s)", hipGetErrorString(e));
+            return (int)TAL_EHIP;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (reinterpret_cast<const volatile int*>(hostbuf[buf])[0] == -1) {
+            c->needs_reset = 1;
+            set_error("tal_unaligned_group_run: the decode step delivered the failure marker");
+            return (int)TAL_EHIP;
+        }
+        return (int)TAL_OK;
+    };
+    int cur = 0, step = 0;
+    bool inflight = false;
+    unsigned seq_cur = 0;
+    for (;;) {
+        if (!inflight) {
+            if (step >= max_steps) return step;
+            int rc = unaligned_serve(st, c, dev_cap, stream);
+            if (rc) return rc;
+            if (st->flags) return step;
+            if (st->n + 1 >= st->gen_cap || st->n_rec + 1 >= st->rec_cap || st->n + 1 > dev_cap) {
+                st->flags |= TAL_UNALIGNED_GROW;
+                return step;
+            }
+            rc = launch(cur, st->history_start, st->n, &seq_cur);
+            if (rc) return rc;
+            inflight = true;
+        }
+        const int64_t hs = st->history_start, n = st->n, cs = st->chunk_start;
+        bool spec = false;
+        unsigned seq_spec = 0;
+        if (pair && step + 1 < max_steps && n + 1 - hs <= c->max_len && n + 2 < st->gen_cap && st->n_rec + 2 < st->rec_cap && n + 2 <= dev_cap &&
+            st->it + 2 <= st->max_iters) {
+            const int rc = launch(cur ^ 1, hs, n + 1, &seq_spec);
+            if (rc) { wait(cur, seq_cur); return rc; }
+            spec = true;
+        }
+        int rc = wait(cur, seq_cur);
+        if (rc) return rc;
+        inflight = false;
+        rc = tal_unaligned_consume(st, (int64_t)__builtin_bit_cast(int32_t, hostbuf[cur][0]), hostbuf[cur] + 1, S);
+        ++step;
+        if (spec) {
+            if (rc >= 0 && st->flags == 0 && st->history_start == hs && st->n == n + 1 && st->chunk_start == cs) {
+                inflight = true;                 // the speculated launches are the next step
+                cur ^= 1;
+                seq_cur = seq_spec;
+            } else {
+                const int rw = wait(cur ^ 1, seq_spec);      // dropped; what comes next is enqueued behind it
+                if (rw) return rw;
+            }
+        }
+        if (rc < 0) return rc;
+    }
+}
+
 extern "C" int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greedy_ctx* const* ctxs, const int64_t* dev_cap, int G,
                                        int max_steps, void* stream) {
     TAL_CHECK_ARG(st && ctxs && dev_cap && G >= 1 && G <= TAL_GROUP_MAX && max_steps >= 1, "tal_unaligned_group_run: bad argument");
+    if (G == 1) {
+        TAL_CHECK_ARG(st[0] && ctxs[0], "tal_unaligned_group_run: null session");
+        return unaligned_run_solo(st[0], ctxs[0], dev_cap[0], max_steps, stream);
+    }
     int64_t hs[TAL_GROUP_MAX], ng[TAL_GROUP_MAX];
 #ifdef TAL_GROUP_TIMING      // (ablation build: where a merged step's wall time goes, printed every 2000 steps)
     static thread_local double t_launch = 0, t_poll = 0, t_consume = 0, u_max_sum = 0, u_sum = 0;
@@ -1435,10 +1544,7 @@ extern "C" int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greed
         }
         if (!go) return step;
         int rc;
-        // (one session: its OWN launches -- tal_greedy_step_fwd, every form of it -- so that System.generate_unaligned's solo loop can
-        //  stay inside the library between the decisions that need Python, exactly as a group's does)
-        if (G == 1) GT(t_launch, rc = tal_greedy_step_fwd(ctxs[0], hs[0], ng[0], 3, stream));
-        else GT(t_launch, rc = tal_greedy_step_multi_fwd(ctxs, hs, ng, G, stream));
+        GT(t_launch, rc = tal_greedy_step_multi_fwd(ctxs, hs, ng, G, stream));
         if (rc) return rc;
 #ifdef TAL_GROUP_TIMING
         n_steps += 1; n_sess += G;

@@ -438,15 +438,8 @@ typedef struct tal_greedy_ctx {
      * their launches (8: +12 %, 16: +19 %: the merged dense layers are throughput-bound); a session keeps ONE form for its lifetime so
      * that its results do not depend on which other sessions happen to step beside it. */
     uint32_t no_fold;
-    /* != 0: picked_host holds TWO result buffers, the second tal_greedy_result_stride(S) floats behind the first.  tal_unaligned_group_run
-     * with one session then keeps TWO steps in flight: while step k runs it enqueues step k + 1 for the prefix one token longer (the
-     * pick of step k appends that token on the device, so the launches need nothing from the host); when the control flow, fed step k's
-     * result, confirms that this IS the next step (no window move, roll-back, forced EOS or end) the GPU never waited for the host;
-     * otherwise the speculated step is drained and discarded (~1 step in 50). */
-    uint32_t picked_pair;
+    uint32_t _pad2;
 } tal_greedy_ctx;
-/* floats between the two result buffers of a context with picked_pair != 0 */
-size_t tal_greedy_result_stride(int S);
 size_t tal_greedy_step_workspace_bytes(int U_max, int S, int E, int H, int FF, int V, int E0, int n_layers);
 /* sync: 0 = enqueue only; 1 = copy {token, attention row} to picked_host and wait for the stream; 2 = the last kernel writes
  * {token, row, sequence word} into picked_host itself and the call polls the word (no copy command, no driver wake-up;

@@ -49,7 +49,7 @@ class GreedyCtx(C.Structure):
                 ("picked_host", C.c_void_p), ("tickets", C.c_void_p), ("picked_host_dev", C.c_void_p),
                 ("seq", C.c_uint32), ("needs_reset", C.c_uint32), ("k_pitch", C.c_int64), ("kv_all", C.c_void_p), ("kpm_all", C.c_void_p),
                 ("enc_frames", C.c_int64), ("kv_pitch", C.c_int64), ("pick_bias", C.c_void_p),
-                ("no_fold", C.c_uint32), ("picked_pair", C.c_uint32)]
+                ("no_fold", C.c_uint32), ("_pad2", C.c_uint32)]
 
 
 class UnalignedState(C.Structure):
@@ -69,7 +69,6 @@ UNALIGNED_WINDOW_MOVED, UNALIGNED_PREFIX_REWRITTEN, UNALIGNED_DONE, UNALIGNED_GR
 _i, _i64, _sz, _f, _p = C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_void_p
 SIGNATURES = {
     "tal_version": (_i, []),
-    "tal_greedy_result_stride": (_sz, [_i]),
     "tal_last_error": (C.c_char_p, []),
     "tal_set_option": (_i, [C.c_char_p, _i]),
     "tal_get_option": (_i, [C.c_char_p, C.POINTER(C.c_int)]),

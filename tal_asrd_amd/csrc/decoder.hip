@@ -1402,109 +1402,37 @@ static int unaligned_serve(tal_unaligned_state* st, tal_greedy_ctx* c, int64_t d
     return TAL_OK;
 }
 
-extern "C" size_t tal_greedy_result_stride(int S) { return S > 0 ? (size_t)((2 + S + 15) / 16) * 16 : 0; }
-
-// ONE session on its own launches, with the NEXT step enqueued while the current one runs (tal_greedy_ctx.picked_pair).
-// A generated token costs ~26 dependent launches and then a trip through the host -- the result word lands in pinned memory, the
-// control flow (tal_unaligned_consume) looks at it, the next call's first launch starts from an idle GPU: ~13 us of every ~260.
-// But the device already has everything the next step reads (the pick appended its token to the device-resident prefix), and in
-// ~98 % of the steps the control flow only says "go on": so step k + 1 is enqueued for the prefix one token longer BEFORE step k's
-// result is back, into the other result buffer.  If consume(k) leaves the state exactly there (same window, same history start,
-// n + 1, no flags), that launch chain IS step k + 1 -- same launches on the same operands as without speculation, bit-identical -- and
-// the GPU went from one step into the next without waiting.  Otherwise (window move, roll-back, forced EOS, end of the episode) the
-// speculated step is waited for and dropped: whatever the control flow then asks for is enqueued BEHIND it in the stream, and its
-// token lands one slot behind the valid prefix, where the next real step writes its own.
+// ONE session on its own launches: step -> poll -> consume without leaving the library (System.generate_unaligned's solo loop between
+// the decisions that need Python).  Keeping the NEXT step in flight as well -- enqueued for the prefix one token longer before this
+// step's result is back, dropped when the control flow says otherwise -- was built and measured in round 6 and LOSES: the window
+// moves in 9.4 % of the steps of an episode (538 of 5,721), every such step wastes a whole speculated step (~230 us), and a correct
+// guess saves only the ~13 us between a pick and the next embed: 0.261 -> 0.274 ms per token on the 1-hour episode
+// (profiles/r6_decode_two_steps_in_flight.txt).  Removed again.
 static int unaligned_run_solo(tal_unaligned_state* st, tal_greedy_ctx* c, int64_t dev_cap, int max_steps, void* stream) {
     TAL_CHECK_ARG(c->picked_host && c->tickets && c->S > 0, "tal_unaligned_group_run: the session has no pinned result buffer / tickets");
-    const int S = c->S;
-    const size_t stride = tal_greedy_result_stride(S);
-    float* const base_host = c->picked_host;
-    if (!c->picked_host_dev) {
-        void* alias = nullptr;
-        if (hipHostGetDevicePointer(&alias, base_host, 0) != hipSuccess || !alias) {
-            set_error("tal_unaligned_group_run: picked_host is not mapped pinned host memory (%s)", hipGetErrorString(hipGetLastError()));
-            return TAL_EINVAL;
-        }
-        c->picked_host_dev = reinterpret_cast<float*>(alias);
-        reinterpret_cast<volatile unsigned*>(base_host)[1 + S] = 0u;
-        if (c->picked_pair) reinterpret_cast<volatile unsigned*>(base_host + stride)[1 + S] = 0u;
-    }
-    float* const base_dev = c->picked_host_dev;
-    float* const hostbuf[2] = {base_host, base_host + stride};
-    float* const devbuf[2] = {base_dev, base_dev + stride};
-    const bool pair = c->picked_pair != 0;
-    auto launch = [&](int buf, int64_t hs, int64_t n, unsigned* seq) {
-        c->picked_host = hostbuf[buf];
-        c->picked_host_dev = devbuf[buf];
-        const int rc = tal_greedy_step_fwd(c, hs, n, 3, stream);
-        *seq = c->seq;
-        c->picked_host = base_host;
-        c->picked_host_dev = base_dev;
-        return rc;
-    };
-    auto wait = [&](int buf, unsigned seq) {       // -> 0: delivered; TAL_EHIP: no result after 20 s / the failure marker
-        volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(hostbuf[buf] + 1 + S);
-        if (*flag != seq) {
-            const auto t0 = std::chrono::steady_clock::now();
-            for (unsigned spins = 0; *flag != seq; ++spins)
-                if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
-        }
-        if (*flag != seq) {
-            const hipError_t e = hipStreamSynchronize((hipStream_t)stream);      // nothing may stay in flight behind an error
-            set_error("tal_unaligned_group_run: no result after 20 s (stream after the wait: %s)", hipGetErrorString(e));
-            return (int)TAL_EHIP;
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        if (reinterpret_cast<const volatile int*>(hostbuf[buf])[0] == -1) {
-            c->needs_reset = 1;
-            set_error("tal_unaligned_group_run: the decode step delivered the failure marker");
-            return (int)TAL_EHIP;
-        }
-        return (int)TAL_OK;
-    };
-    int cur = 0, step = 0;
-    bool inflight = false;
-    unsigned seq_cur = 0;
-    for (;;) {
-        if (!inflight) {
-            if (step >= max_steps) return step;
-            int rc = unaligned_serve(st, c, dev_cap, stream);
-            if (rc) return rc;
-            if (st->flags) return step;
-            if (st->n + 1 >= st->gen_cap || st->n_rec + 1 >= st->rec_cap || st->n + 1 > dev_cap) {
-                st->flags |= TAL_UNALIGNED_GROW;
-                return step;
-            }
-            rc = launch(cur, st->history_start, st->n, &seq_cur);
-            if (rc) return rc;
-            inflight = true;
-        }
-        const int64_t hs = st->history_start, n = st->n, cs = st->chunk_start;
-        bool spec = false;
-        unsigned seq_spec = 0;
-        if (pair && step + 1 < max_steps && n + 1 - hs <= c->max_len && n + 2 < st->gen_cap && st->n_rec + 2 < st->rec_cap && n + 2 <= dev_cap &&
-            st->it + 2 <= st->max_iters) {
-            const int rc = launch(cur ^ 1, hs, n + 1, &seq_spec);
-            if (rc) { wait(cur, seq_cur); return rc; }
-            spec = true;
-        }
-        int rc = wait(cur, seq_cur);
+    for (int step = 0; step < max_steps; ++step) {
+        int rc = unaligned_serve(st, c, dev_cap, stream);
         if (rc) return rc;
-        inflight = false;
-        rc = tal_unaligned_consume(st, (int64_t)__builtin_bit_cast(int32_t, hostbuf[cur][0]), hostbuf[cur] + 1, S);
-        ++step;
-        if (spec) {
-            if (rc >= 0 && st->flags == 0 && st->history_start == hs && st->n == n + 1 && st->chunk_start == cs) {
-                inflight = true;                 // the speculated launches are the next step
-                cur ^= 1;
-                seq_cur = seq_spec;
-            } else {
-                const int rw = wait(cur ^ 1, seq_spec);      // dropped; what comes next is enqueued behind it
-                if (rw) return rw;
-            }
+        if (st->flags) return step;
+        if (st->n + 1 >= st->gen_cap || st->n_rec + 1 >= st->rec_cap || st->n + 1 > dev_cap) {
+            st->flags |= TAL_UNALIGNED_GROW;
+            return step;
         }
+        rc = tal_greedy_step_fwd(c, st->history_start, st->n, 3, stream);
+        if (rc) return rc;
+        const int got = tal_greedy_step_poll(c, 20000);
+        if (got != 1) {
+            if (got == 0) {
+                const hipError_t e = hipStreamSynchronize((hipStream_t)stream);      // nothing may stay in flight behind an error
+                set_error("tal_unaligned_group_run: no result after 20 s (stream after the wait: %s)", hipGetErrorString(e));
+            }
+            return TAL_EHIP;
+        }
+        const float* ph = c->picked_host;
+        rc = tal_unaligned_consume(st, (int64_t)__builtin_bit_cast(int32_t, ph[0]), ph + 1, c->S);
         if (rc < 0) return rc;
     }
+    return max_steps;
 }
 
 extern "C" int tal_unaligned_group_run(tal_unaligned_state* const* st, tal_greedy_ctx* const* ctxs, const int64_t* dev_cap, int G,

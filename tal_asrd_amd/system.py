@@ -135,10 +135,7 @@ class _GreedySession:
             self.ws = ops._ws(nws, self.dev)
             c.workspace, c.workspace_bytes = self.ws.data_ptr(), nws
             self.picked_dev = torch.empty(1 + S, dtype=torch.float32, device=self.dev)
-            # two result buffers {token, row [S], sequence word}, the second tal_greedy_result_stride(S) floats behind the first: the solo
-            # loop keeps the next step in flight while it looks at the current one's result (tal_greedy_ctx.picked_pair)
-            self.picked_host = torch.zeros(2 * self.lib.tal_greedy_result_stride(S), dtype=torch.float32).pin_memory()
-            c.picked_pair = 1
+            self.picked_host = torch.zeros(2 + S, dtype=torch.float32).pin_memory()    # {token, row [S], sequence word}
             self.picked_np = self.picked_host.numpy()[:1 + S]
             c.picked_dev, c.picked_host = self.picked_dev.data_ptr(), self.picked_host.data_ptr()
             c.picked_host_dev = None         # (the library resolves the new buffer's device alias on the next step)

@@ -44,7 +44,7 @@ extern "C" {
 #define TAL_MAX_STAGES 4
 #define TAL_MAX_DEPTH 8
 
-int tal_version(void);          /* 430 = 0.4.3 */
+int tal_version(void);          /* 500 = 0.5.0 */
 const char* tal_last_error(void);
 
 /* Process-wide behaviour switches.  The library never reads the environment: which kernels a caller gets depends on its

@@ -187,7 +187,7 @@ static int64_t conv_out_len(int64_t t) { return t < 21 ? 0 : (t - 21) / 2 + 1; }
 
 using namespace tal;
 
-extern "C" int tal_version(void) { return 430; /* 0.4.3: log-mel as a fast transform (option logmel_mfma: the matrix form), the plan grew; 0.4.2: TAL_TDS_OUT_SPLIT, tal_tds_out_split, tal_sd_head_split_fwd; 0.4.1: tal_tds_premean_fwd / tal_tds_premean_ok; 0.4.0: tal_greedy_ctx grew (k_pitch, episode-wide K | V table), merged decode steps, tal_unaligned_*, tal_logmel_f16_fwd; 0.3.0: tal_set_option */ }
+extern "C" int tal_version(void) { return 500; /* 0.5.0: tal_greedy_ctx grew (needs_reset, pick_bias, no_fold), tal_decoder_layer_w grew (fold_*), tal_greedy_step_poll takes a non-const context, word 1 of the TDS status block = output form, options gru_unfused / decode_no_fold / decode_fold_rows / gconv_c1_fuse; 0.4.3: log-mel as a fast transform (option logmel_mfma: the matrix form), the plan grew; 0.4.2: TAL_TDS_OUT_SPLIT, tal_tds_out_split, tal_sd_head_split_fwd; 0.4.1: tal_tds_premean_fwd / tal_tds_premean_ok; 0.4.0: tal_greedy_ctx grew (k_pitch, episode-wide K | V table), merged decode steps, tal_unaligned_*, tal_logmel_f16_fwd; 0.3.0: tal_set_option */ }
 
 // Host-side helper of the decode loop (no device work): ngram_repeat_mask(row, n).sum() of tal/asr/util.py:5-17 -- the number
 // of positions covered by an n-gram that already occurred earlier in the row; like the reference, n-gram starts run to

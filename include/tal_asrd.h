@@ -434,9 +434,9 @@ typedef struct tal_greedy_ctx {
      * one-launch form (option decode_persist) is not taken while it is set. */
     const float* pick_bias;
     /* != 0: this session's steps never take the folded decoder layer (tal_decoder_layer_w.fold_*), whatever its prefix length.  The fold
-     * pays while a step is latency-bound (one session, or a few in shared launches: -8 % per step) and costs when many sessions share
-     * their launches (8: +12 %, 16: +19 %: the merged dense layers are throughput-bound); a session keeps ONE form for its lifetime so
-     * that its results do not depend on which other sessions happen to step beside it. */
+     * pays while a step is latency-bound (a session on its own launches: -8 % per step) and costs where sessions share their launches and
+     * several such chains run side by side (4 host threads x groups of 2: +5 %; a merged step of 16: +19 %: throughput-bound); a session
+     * keeps ONE form for its lifetime so that its results do not depend on which other sessions happen to step beside it. */
     uint32_t no_fold;
     uint32_t _pad2;
 } tal_greedy_ctx;

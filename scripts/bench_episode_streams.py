@@ -38,16 +38,22 @@ steps = sum(int(g_.shape[1]) - 1 for _, g_, _ in solo)
 print("one at a time: %d episodes x %.0f s, %d decode steps, %.3f s = %.0f frames/s, %.3f ms per step"
       % (n_ep, seconds, steps, t_solo, n_ep * frames / t_solo, 1e3 * t_solo / steps), flush=True)
 modes = [(k, 1) for k in (1, 2, 4, 8, 16) if k <= n_ep]
+ONLY = os.environ.get("MODES")          # e.g. MODES="4x2,2x16,default": only these (threads x group) modes
 # sessions advanced in step through SHARED launches (tal_greedy_step_multi_fwd): (host threads, sessions per group)
 modes += [(t, gsz) for t, gsz in ((1, 8), (2, 4), (4, 2), (1, 16), (2, 8), (4, 4), (2, 16)) if gsz <= n_ep]
 modes.append((None, None))       # the default split of transcribe_unaligned_many
+if ONLY:
+    want = set(ONLY.split(","))
+    modes = [(k, g_) for k, g_ in modes if ("default" if k is None else "%dx%d" % (k, g_)) in want]
 for k, gsz in modes:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     many = system.transcribe_unaligned_many(eps, streams=k, group=gsz)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    # tokens and window starts identical to the solo runs always; attention rows bit-identical unless the group is large enough for its
-    # sessions to decode on the unfolded decoder layer (System.FOLD_GROUP_MAX): then equal to rounding (the fold re-associates weights)
-    unfolded = gsz is not None and gsz >= System.FOLD_GROUP_MAX
+    # tokens and window starts identical to the solo runs always; attention rows bit-identical with group == 1; sessions that advance in
+    # groups decode on the unfolded decoder layer (System.FOLD_GROUP_MAX): rows then equal to rounding (the fold re-associates weights)
+    # (the default split from 32 episodes on is two threads x groups of 16)
+    gsz_eff = gsz if gsz is not None else (16 if n_ep >= 32 else max(1, min(4, -(-n_ep // 4))))
+    unfolded = gsz_eff >= System.FOLD_GROUP_MAX
     same = all(torch.equal(a[1].cpu(), b[1].cpu()) and [int(c[0]) for c, _ in a[2]] == [int(c[0]) for c, _ in b[2]] and
                all((float((x[1] - y[1]).abs().max()) < 1e-5) if unfolded else torch.equal(x[1], y[1]) for x, y in zip(a[2], b[2])) for a, b in zip(solo, many))
     what = "default split (streams=None, group=None)" if k is None else "%2d sessions in flight, own launches" % k if gsz == 1 else "%d thread(s) x groups of %d sessions, shared launches" % (k, gsz)

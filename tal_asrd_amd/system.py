@@ -426,7 +426,11 @@ class System:
         # sections that go through it are serialised; the per-token C call of a decode session needs no lock
         self._lock = threading.RLock()
 
-    FOLD_GROUP_MAX = 8      # transcribe_unaligned_many: sessions of groups this large decode on the unfolded decoder layer
+    # transcribe_unaligned_many: sessions that advance in GROUPS (shared launches, group >= 2) decode on the unfolded decoder layer.
+    # Same-box A / B on 8 x 1 h (profiles/r6_episode_streams_fold_ab.txt): one session at a time 13.6 -> 12.5 s with the folded layer, four
+    # solo sessions in flight 4.56 -> 4.22 s, but 4 threads x groups of 2: 3.27 -> 3.44 s, 2 x 4: 3.52 -> 3.67 s, 32 x 10 min in 4 x 4: 1.77
+    # -> 1.94 s -- several merged chains side by side are throughput-bound, and the fold's longer K axis costs there.
+    FOLD_GROUP_MAX = 2
 
     # ------------------------------------------------------------------ several episodes in flight
     @torch.no_grad()
@@ -465,9 +469,9 @@ class System:
 
         episodes: list of (audio [1, L] float tensor -- host (pinned or not) or device --, audio_lens LongTensor [1]).
         Returns [(utterance dicts, generated, alignments)] in episode order: token streams, window starts and utterances identical to
-        the solo runs in either mode; attention rows bit-identical to them too, except in groups of FOLD_GROUP_MAX sessions or more,
-        whose sessions decode on the unfolded decoder layer (rows then equal a solo run with fold_layers=False bit for bit and the
-        default solo run to ~1e-6: the folded layer re-associates two weight products)."""
+        the solo runs in either mode; attention rows bit-identical to them with group == 1; sessions that advance in groups (group >= 2)
+        decode on the unfolded decoder layer: their rows equal a solo run with fold_layers=False bit for bit and the default solo run
+        to ~1e-6 (the folded layer re-associates two weight products)."""
         if not episodes:
             return []
         if self.lm is not None and self.args.lm_weight > 0:
@@ -544,8 +548,7 @@ class System:
                             break
                         x = audio.to(dev, non_blocking=True)
                         prime = torch.full((1, 1), self.tokenizer.eos_token_id, dtype=torch.int64, device=dev)
-                        # (groups of FOLD_GROUP_MAX sessions or more: the merged dense layers are throughput-bound and the folded
-                        #  decoder layer costs there -- these sessions keep the eight-launch layer for all their steps)
+                        # (sessions that advance in groups keep the eight-launch decoder layer for all their steps: FOLD_GROUP_MAX)
                         run = _UnalignedRun(self, x, prime, lens, 357, **dict(kw, fold_layers=kw.get("fold_layers", True) and group < self.FOLD_GROUP_MAX))
                         if not run.done:
                             run.prepare()

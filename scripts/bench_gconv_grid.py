@@ -22,7 +22,7 @@ def ab(label, fn, variants):
         for k, opts in variants.items():
             for o, v in opts.items(): N.set_option(o, v)
             res[k].append(timeit(fn))
-            for o in opts: N.set_option(o, 0)
+            for o in opts: N.set_option(o, 4 if o == "gconv_short_below" else 0)
     print(label + ": " + " | ".join("%s %.4f ms" % (k, min(v)) for k, v in res.items()), flush=True)
 for B, scale in ((1, 1.0), (8, 1.0 / 12.05)):
     for T, cg in ((179991, 10), (89986, 14), (44983, 18)):
@@ -33,10 +33,10 @@ for B, scale in ((1, 1.0), (8, 1.0 / 12.05)):
         b = torch.randn(C, device=dev)
         wf = ops.pack_gconv_f16x3_weight(w, G)
         xs = ops.split_f16x3(x.view(B * T, C))
-        variants = {"xcd order": {}, "plain grid": {"gconv_grid_xyz": 1}}
+        variants = {"xcd order": {}, "plain grid": {"gconv_grid_xyz": 1}, "256-step tiles": {"gconv_long_tt": 256}, "128-step tiles": {"gconv_long_tt": 128}, "64-step tiles": {"gconv_short_below": 1000000}}
         if cg == 18:
             variants = {"shift + xcd": {}, "shift, plain grid": {"gconv_grid_xyz": 1}, "two tiles + xcd": {"gconv_no_shift18": 1},
-                        "two tiles, plain grid (round 3)": {"gconv_no_shift18": 1, "gconv_grid_xyz": 1}}
+                        "two tiles, plain grid (round 3)": {"gconv_no_shift18": 1, "gconv_grid_xyz": 1}, "shift, 64-step tiles": {"gconv_short_below": 1000000}}
         ab("res  cg=%2d B=%d T=%6d" % (cg, B, T), lambda: ops.gconv_res_split(xs, (B, T, C), wf, b, 0.25, G), variants)
     for T, cin, cout in ((179991, 10, 14), (89986, 14, 18)):
         T = int(T * scale)
@@ -46,4 +46,4 @@ for B, scale in ((1, 1.0), (8, 1.0 / 12.05)):
         wf = ops.pack_gconv_f16x3_weight(w, G, stride=2)
         xs = ops.split_f16x3(x.view(B * T, G * cin))
         ab("s2 %d->%d B=%d T=%6d" % (cin, cout, B, T), lambda: ops.gconv_s2_split(xs, (B, T, G * cin), True, wf, b, G * cout, G),
-           {"xcd order": {}, "plain grid": {"gconv_grid_xyz": 1}})
+           {"xcd order": {}, "plain grid": {"gconv_grid_xyz": 1}, "64-step tiles": {"gconv_short_below": 1000000}})

@@ -1605,6 +1605,14 @@ int launch_gconv_res_f16x3(const float* x, const void* w_frag, const float* bias
         if (cg == 14) return launch_mfma_spec<14, 14, 1, true, 4, 64>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
         return launch_mfma_spec<18, 18, 1, true, 2, 64>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
     }
+    // Long inputs, 14 channels per group: 128-step tiles (38 KB of LDS: four workgroups per CU instead of two at 71 KB) -- the halo grows
+    // from 8 to 16 % of the rows filled, but twice the workgroups overlap their dependent phases: 0.317 -> 0.298 ms on the 1-hour shape,
+    // 0.220 -> 0.200 on eight 5-minute segments (profiles/r6_gconv_tile_lengths.txt).  10 channels per group (53 KB: three per CU
+    // already) lose 9 % with 128 steps and stay at 256; 64-step tiles lose everywhere on long inputs.  Same chain of MFMAs per output:
+    // results do not depend on the tile length.  Option gconv_long_tt: 256 / 128 force one length for both widths.
+    const int long_tt = opt(OPT_GCONV_LONG_TT);
+    if (long_tt == 128 && cg == 10) return launch_mfma_spec<10, 10, 1, true, 4, 128>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
+    if (long_tt != 256 && cg == 14) return launch_mfma_spec<14, 14, 1, true, 4, 128>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
     if (cg == 10) return launch_mfma_spec<10, 10, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
     if (cg == 14) return launch_mfma_spec<14, 14, 1, true, 4, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);
     return launch_mfma_spec<18, 18, 1, true, 2, 256>(x, w_frag, bias, alpha, y, y_split, B, T, T, C, C, groups, s, range_flag, x_split);

@@ -469,8 +469,11 @@ def test_gconv_short_tiles_equal_long_tiles(cg, T, B):
     xs = ops.split_f16x3(x.reshape(B * T, G * cg)) if (G * cg) % 32 == 0 else None
     out = {}
     try:
-        for below in (0, 1 << 20):
+        # (0: long tiles at their default lengths -- 256 steps, 128 for 14 channels per group since round 6 --; 1 << 20: 64-step tiles;
+        #  then the long tiles forced to 256 and to 128 steps, option gconv_long_tt)
+        for below, long_tt in ((0, 0), (1 << 20, 0), (0, 256), (0, 128)):
             N_.set_option("gconv_short_below", below)
+            N_.set_option("gconv_long_tt", long_tt)
             r = [ops.gconv_res_f16x3(x, wf, b, 0.25, G)]
             if xs is not None:
                 r.append(ops.gconv_res_split(xs, (B, T, G * cg), wf, b, 0.25, G))
@@ -479,12 +482,16 @@ def test_gconv_short_tiles_equal_long_tiles(cg, T, B):
                 if xs is not None and (G * cog) % 32 == 0:
                     r.append(ops.gconv_s2_split(xs, (B, T, G * cg), True, wf2, b2, G * cog, G))
             torch.cuda.synchronize()
-            out[below] = r
+            out[(below, long_tt)] = r
     finally:
         N_.set_option("gconv_short_below", 4)
-    assert len(out[0]) == len(out[1 << 20]) >= 2
-    for a, c in zip(out[0], out[1 << 20]):
-        assert torch.equal(a, c)
+        N_.set_option("gconv_long_tt", 0)
+    ref = out[(0, 0)]
+    assert len(ref) >= 2
+    for key, res in out.items():
+        assert len(res) == len(ref), key
+        for a, c in zip(ref, res):
+            assert torch.equal(a, c), key
 
 
 @pytest.mark.parametrize("M", [1900, 3751])

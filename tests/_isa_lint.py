@@ -134,7 +134,7 @@ def barrier_violations(blocks, max_age, strict=True):
                 if bad:      # (block-entry states only ever grow towards the fixpoint: a violation found on the way stays one)
                     found[inst.line] = ("s_barrier with up to %d LDS-DMA load(s) of this wave possibly in flight that were "
                                         "issued more than %d barrier(s) ago" % (len(bad), max_age))
-                st =tuple((d, min(a + 1, AGE_CAP)) for d, a in st)
+                st = tuple((d, min(a + 1, AGE_CAP)) for d, a in st)
             elif _VM.match(op):
                 st = (st + ((is_lds_dma(inst), 0),))[-CAP:]
             elif op == "s_branch":

@@ -451,7 +451,7 @@ int tal_greedy_step_fwd(tal_greedy_ctx* c, int64_t history_start, int64_t n_gen,
  * when the step delivered the failure marker (token -1: the one-launch form's phase barrier gave up); the context is then marked
  * (needs_reset) and its next step starts from a zeroed ticket block. */
 int tal_greedy_step_poll(tal_greedy_ctx* c, int wait_ms);
-/* The same step for G sessions (1 <= G <= 16) in SHARED launches: one chain of 34 launches advances every session by one token
+/* The same step for G sessions (1 <= G <= 16) in SHARED launches: one chain of 34 launches (26 for sessions on the folded decoder layer) advances every session by one token
  * (the decode loop of System.generate_unaligned is batch 1 -- .item() at tal/asr/system.py:331,411,417 --, so a corpus of
  * episodes is decoded as concurrent sessions; a chain of small dependent launches per session tops out at the device's four
  * hardware queues).  Each session keeps its own context (prefix, window K / V^T, workspace, tickets, pinned result buffer);

@@ -446,7 +446,7 @@ class System:
         (scripts/ubench/launch_rate.hip, profiles/r3_ubench_launch_rate.txt).
 
         group > 1: `streams` host threads, each advancing `group` (<= 16) sessions IN STEP through SHARED launches
-        (tal_greedy_step_multi_fwd: one chain of 34 launches per generated token of every session of the group, each launch
+        (tal_greedy_step_multi_fwd: one chain of 34 launches -- grouped sessions keep the eight-launch decoder layer -- per generated token of every session of the group, each launch
         running the single-session kernel body per session).  A session whose next step does not take the merged kernels' forms
         (first step, prefix beyond 192 tokens, window of 64 frames or fewer) takes that step on launches of its own, in the same
         stream.  While one thread runs the host-side control flow on its group's results, the other threads' steps keep the GPU busy.

@@ -20,8 +20,8 @@ void set_error(const char* fmt, ...) {
 // ---- behaviour switches (tal_set_option) ---------------------------------------------------
 static const char* const g_opt_names[OPT_COUNT] = {
     "tds_exact_f32", "tds_fp32_activations", "gconv_fuse_split", "gconv_c1_generic", "head_no_astationary", "gemm_global_loads",
-    "gemm_no_splitk4", "gemm_no_glds", "gemm_no_splitk_tail", "gemm_no_w64", "logmel_no_fold", "decode_no_small", "decode_small_rows", "gemm_no_row_split", "gemm_no_n96", "gemm_s64_below", "gconv_short_below", "gconv_no_shift18", "gconv_grid_xyz", "gemm_w64_stagger", "gemm_s64_order", "decode_wide_gemm", "gemm_s64_rows", "decode_persist", "decode_persist_wgs", "logmel_mfma", "gru_unfused", "decode_no_fold", "gconv_c1_fuse", "decode_fold_rows", "decode_no_pack", "gconv_long_tt"};
-static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {256}, {0}, {0}, {2}, {4}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {32}, {0}, {0}, {0}, {0}, {64}, {0}, {0}};
+    "gemm_no_splitk4", "gemm_no_glds", "gemm_no_splitk_tail", "gemm_no_w64", "logmel_no_fold", "decode_no_small", "decode_small_rows", "gemm_no_row_split", "gemm_no_n96", "gemm_s64_below", "gconv_short_below", "gconv_no_shift18", "gconv_grid_xyz", "gemm_w64_stagger", "gemm_s64_order", "decode_wide_gemm", "gemm_s64_rows", "decode_persist", "decode_persist_wgs", "logmel_mfma", "gru_unfused", "decode_no_fold", "gconv_c1_fuse", "decode_fold_rows", "gconv_long_tt"};
+static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {256}, {0}, {0}, {2}, {4}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {32}, {0}, {0}, {0}, {0}, {64}, {0}};
 int opt(Option o) { return g_opt[o].load(std::memory_order_relaxed); }
 
 int device_cus() {

@@ -126,7 +126,6 @@ enum Option {
     OPT_DECODE_NO_FOLD,           // latency-oriented decoder layer on its eight launches even when the folded weights are there (six)
     OPT_GCONV_C1_FUSE,            // first resize conv computed inside the first TDSBlock conv's launch (round 6: bit-identical, no faster -- off)
     OPT_DECODE_FOLD_ROWS,         // the folded decoder layer is taken up to this many rows (prefix tokens) per problem (default 64)
-    OPT_DECODE_NO_PACK,           // merged decode steps: one set of 32-row tiles per session (rounds 4-5) instead of tiles shared by neighbouring sessions
     OPT_GCONV_LONG_TT,            // long inputs, 10- / 14-channel TDSBlock convs: 0 = 256- / 128-step tiles (default), 256 / 128 = that length for both
     OPT_COUNT
 };

@@ -37,79 +37,11 @@ struct Blk {
     unsigned x, y, z, gx, gy;
 };
 
-// WHERE A PROBLEM'S ROWS LIVE.  RowsOne: the rows of one problem, `row` = the problem's own row index (every launch form of rounds 1-5).
-// RowsPacked (round 6, merged decode steps): the rows of SEVERAL problems -- the sessions of a merged step, which share the layer's
-// weights, shapes and strides and differ only in their buffers and row counts -- numbered through, so that a 32-row tile is filled
-// with rows of neighbouring sessions instead of being padded per session (a session of 20 prefix tokens used 20 of its tile's 32
-// rows: eight sessions of 8-43 tokens are 10 padded tiles but 6 packed ones).  A workgroup resolves its tile's 32 rows once --
-// (session, local row) by a scan over the cumulative row counts, the session's five buffer pointers -- into an LDS table; every
-// output is still the same chain of MFMAs over K on the same operands: bit-identical to the padded form and to the solo step.
-struct RowsOne {
-    const SkinnyArgs& g;
-    __device__ __forceinline__ void init(int) const {}
-    __device__ __forceinline__ int total() const { return g.M; }
-    __device__ __forceinline__ const float* a(int64_t r) const { return g.A + r * g.lda; }
-    __device__ __forceinline__ const float* a2(int64_t r) const { return g.A2 + r * g.lda2; }
-    __device__ __forceinline__ const float* res(int64_t r) const { return g.res + r * g.ldres; }
-    __device__ __forceinline__ float* y(int64_t r) const { return g.Y + r * g.ldy; }
-    __device__ __forceinline__ float* yt(int64_t r, int tcol) const {        // element (tcol, u) of batch item b = r / U of the transposed output
-        const int b = (int)(r / g.U), u = (int)(r - (int64_t)b * g.U);
-        return g.Yt + (int64_t)b * g.vt_bs + (int64_t)tcol * g.ldt + u;
-    }
-};
-struct PackCum {
-    int cum[TAL_GROUP_MAX + 1];     // cum[i] = rows of the problems before problem i; cum[n] = all rows
-};
-struct RowsPacked {
-    const ArgPack<SkinnyArgs>& p;
-    const PackCum& pc;
-    struct Ent { const float* a; const float* a2; const float* res; float* y; float* yt; };
-    mutable int m0;
-    __device__ __forceinline__ Ent* table() const {
-        __shared__ Ent rt[32];
-        return rt;
-    }
-    // the tile's 32 rows -> table (threads 0..31; rows past the end repeat the last row: loaded, never stored), then a barrier
-    __device__ __forceinline__ void init(int tile_m0) const {
-        m0 = tile_m0;
-        Ent* rt = table();
-        if (threadIdx.x < 32) {
-            const int R = pc.cum[p.n];
-            int gr = tile_m0 + (int)threadIdx.x;
-            gr = gr < R ? gr : R - 1;
-            const SkinnyArgs& g0 = p.a[0];
-            Ent e = {g0.A, g0.A2, g0.res, g0.Y, g0.Yt};
-            int base = 0;
-#pragma unroll
-            for (int k = 1; k < TAL_GROUP_MAX; ++k)
-                if (k < p.n && gr >= pc.cum[k]) {
-                    e.a = p.a[k].A; e.a2 = p.a[k].A2; e.res = p.a[k].res; e.y = p.a[k].Y; e.yt = p.a[k].Yt;
-                    base = pc.cum[k];
-                }
-            const int64_t lr = gr - base;        // the problems share every stride (same layer, same launch): problem 0's
-            e.a += lr * g0.lda;
-            if (e.a2) e.a2 += lr * g0.lda2;
-            if (e.res) e.res += lr * g0.ldres;
-            if (e.y) e.y += lr * g0.ldy;
-            if (e.yt) e.yt += lr;                // (one batch item per problem: u = the local row)
-            rt[threadIdx.x] = e;
-        }
-        __syncthreads();
-    }
-    __device__ __forceinline__ int total() const { return pc.cum[p.n]; }
-    __device__ __forceinline__ const float* a(int64_t r) const { return table()[r - m0].a; }
-    __device__ __forceinline__ const float* a2(int64_t r) const { return table()[r - m0].a2; }
-    __device__ __forceinline__ const float* res(int64_t r) const { return table()[r - m0].res; }
-    __device__ __forceinline__ float* y(int64_t r) const { return table()[r - m0].y; }
-    __device__ __forceinline__ float* yt(int64_t r, int tcol) const { return table()[r - m0].yt + (int64_t)tcol * p.a[0].ldt; }
-};
-
-template <int MODE, int MT, int NW, bool COH = false, class ROWS = RowsOne>
-__device__ __forceinline__ void skinny_gemm_body(const SkinnyArgs& g, const Blk blk, const ROWS rows) {
+template <int MODE, int MT, int NW, bool COH = false>
+__device__ __forceinline__ void skinny_gemm_body(const SkinnyArgs& g, const Blk blk) {
     __shared__ __attribute__((aligned(16))) float part[NW * MT * 256];   // [wave][m tile][row 16][col 16]
     const int n0 = blk.x * 16;
     const int m0 = blk.y * 32;
-    rows.init(m0);
     const int lane = threadIdx.x & 63, w = wave_id();
     const int r16 = lane & 15, kq = lane >> 4;
     const int KS = g.ksplit > 1 ? g.ksplit : 1;
@@ -122,8 +54,8 @@ __device__ __forceinline__ void skinny_gemm_body(const SkinnyArgs& g, const Blk 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int row = m0 + mt * 16 + r16;
-        const int64_t rc = row < rows.total() ? row : rows.total() - 1;
-        ap[mt] = seg2 ? rows.a2(rc) + (kofs - g.K1) + 4 * kq : rows.a(rc) + kofs + 4 * kq;
+        const int64_t rc = row < g.M ? row : g.M - 1;
+        ap[mt] = seg2 ? g.A2 + rc * g.lda2 + (kofs - g.K1) + 4 * kq : g.A + rc * g.lda + kofs + 4 * kq;
     }
     f32x4 acc[MT];
 #pragma unroll
@@ -208,26 +140,23 @@ __device__ __forceinline__ void skinny_gemm_body(const SkinnyArgs& g, const Blk 
             }
         }
     }
-    if (t >= MT * 64 || m >= rows.total()) return;
+    if (t >= MT * 64 || m >= g.M) return;
     const int col = n0 + 4 * c4;
     if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
-    if (col < g.k1_cols) v += *reinterpret_cast<const f32x4*>(rows.a2(m) + col);
+    if (col < g.k1_cols) v += *reinterpret_cast<const f32x4*>(g.A2 + (int64_t)m * g.lda2 + col);
     if (MODE == 1 && col >= g.relu_begin) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (MODE == 2) v = *reinterpret_cast<const f32x4*>(rows.res(m) + col) + g.alpha * v;
+    if (MODE == 2) v = *reinterpret_cast<const f32x4*>(g.res + (int64_t)m * g.ldres + col) + g.alpha * v;
     if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) v = g.alpha * v;
     if (g.Yt && col >= g.vt_begin) {
-        float* yt = rows.yt(m, col - g.vt_begin);
+        const int b = m / g.U, u = m - b * g.U;
+        float* yt = g.Yt + (int64_t)b * g.vt_bs + (int64_t)(col - g.vt_begin) * g.ldt + u;
         store_f32<COH>(yt, v.x);
         store_f32<COH>(yt + g.ldt, v.y);
         store_f32<COH>(yt + 2 * g.ldt, v.z);
         store_f32<COH>(yt + 3 * g.ldt, v.w);
         return;
     }
-    store_f32x4<COH>(rows.y(m) + col, v);
-}
-template <int MODE, int MT, int NW, bool COH = false>
-__device__ __forceinline__ void skinny_gemm_body(const SkinnyArgs& g, const Blk blk) {
-    skinny_gemm_body<MODE, MT, NW, COH, RowsOne>(g, blk, RowsOne{g});
+    store_f32x4<COH>(g.Y + (int64_t)m * g.ldy + col, v);
 }
 
 

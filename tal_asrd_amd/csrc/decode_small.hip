@@ -38,8 +38,8 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_multi_kernel(const ArgPac
 // is two thirds of what a merged step of 8 sessions pulls from L2.  Per output the arithmetic is the narrow form's, instruction
 // for instruction (same chunks in the same order per wave, waves added in wave order, K slices in slice order through the same
 // partial buffers and tickets), so results are bit-identical to the narrow form and to a session's solo step.
-template <int MODE, int MT, int NW, int NT, class ROWS = RowsOne>
-__device__ __forceinline__ void skinny_gemm_wide_body(const SkinnyArgs& g, const Blk blk, const ROWS rows) {
+template <int MODE, int MT, int NW, int NT>
+__device__ __forceinline__ void skinny_gemm_wide_body(const SkinnyArgs& g, const Blk blk) {
     // Round 5: the NT blocks' products first, back to back, and then ONE pass of partial tiles -> LDS -> wave-order sums -> K-slice
     // hand-over (stores, one drain, NT tickets taken side by side) -> epilogues, instead of that whole chain once per block: a
     // merged step's 2048-deep layer took 20.8 us with four serial hand-overs per workgroup where a session alone takes 6.6.
@@ -47,7 +47,6 @@ __device__ __forceinline__ void skinny_gemm_wide_body(const SkinnyArgs& g, const
     __shared__ unsigned ticket[NT];
     constexpr int UNR = 8;                          // Kw == 128: the wave's K slice is exactly one batch of 8 chunks
     const int m0 = blk.y * 32;
-    rows.init(m0);
     const int lane = threadIdx.x & 63, w = wave_id();
     const int r16 = lane & 15, kq = lane >> 4;
     const int KS = g.ksplit > 1 ? g.ksplit : 1;
@@ -58,8 +57,8 @@ __device__ __forceinline__ void skinny_gemm_wide_body(const SkinnyArgs& g, const
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int row = m0 + mt * 16 + r16;
-        const int64_t rc = row < rows.total() ? row : rows.total() - 1;
-        const float* ap = seg2 ? rows.a2(rc) + (kofs - g.K1) + 4 * kq : rows.a(rc) + kofs + 4 * kq;
+        const int64_t rc = row < g.M ? row : g.M - 1;
+        const float* ap = seg2 ? g.A2 + rc * g.lda2 + (kofs - g.K1) + 4 * kq : g.A + rc * g.lda + kofs + 4 * kq;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) av[mt][u] = *reinterpret_cast<const f32x4*>(ap + u * 16);
     }
@@ -143,22 +142,23 @@ __device__ __forceinline__ void skinny_gemm_wide_body(const SkinnyArgs& g, const
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        if (finish[nt] && t < MT * 64 && m < rows.total()) {
+        if (finish[nt] && t < MT * 64 && m < g.M) {
             const int col = (nb0 + nt) * 16 + 4 * c4;
             f32x4 o = v[nt];
             if (g.bias) o += *reinterpret_cast<const f32x4*>(g.bias + col);
-            if (col < g.k1_cols) o += *reinterpret_cast<const f32x4*>(rows.a2(m) + col);
+            if (col < g.k1_cols) o += *reinterpret_cast<const f32x4*>(g.A2 + (int64_t)m * g.lda2 + col);
             if (MODE == 1 && col >= g.relu_begin) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-            if (MODE == 2) o = *reinterpret_cast<const f32x4*>(rows.res(m) + col) + g.alpha * o;
+            if (MODE == 2) o = *reinterpret_cast<const f32x4*>(g.res + (int64_t)m * g.ldres + col) + g.alpha * o;
             if (MODE == 3 && (g.scale_cols == 0 || col < g.scale_cols)) o = g.alpha * o;
             if (g.Yt && col >= g.vt_begin) {
-                float* yt = rows.yt(m, col - g.vt_begin);
+                const int b = m / g.U, u = m - b * g.U;
+                float* yt = g.Yt + (int64_t)b * g.vt_bs + (int64_t)(col - g.vt_begin) * g.ldt + u;
                 yt[0] = o.x;
                 yt[g.ldt] = o.y;
                 yt[2 * g.ldt] = o.z;
                 yt[3 * g.ldt] = o.w;
             } else
-                *reinterpret_cast<f32x4*>(rows.y(m) + col) = o;
+                *reinterpret_cast<f32x4*>(g.Y + (int64_t)m * g.ldy + col) = o;
         }
     }
 }
@@ -168,18 +168,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_wide_multi_kernel(const A
     const SkinnyArgs& g = p.a[blockIdx.z / KS];
     const unsigned gy = (unsigned)((g.M + 31) / 32);
     if (blockIdx.y >= gy) return;
-    skinny_gemm_wide_body<MODE, MT, NW, NT>(g, Blk{blockIdx.x, blockIdx.y, blockIdx.z % KS, gridDim.x, gy}, RowsOne{g});
-}
-
-// PACKED forms of the two multi launches (RowsPacked, csrc/decode_bodies.h): grid (column blocks, tiles of 32 rows over ALL problems' rows);
-// launches without a K split only (a K-split launch's partial tiles and tickets are per session)
-template <int MODE, int MT, int NW>
-__global__ __launch_bounds__(64 * NW) void skinny_gemm_packed_kernel(const ArgPack<SkinnyArgs> p, const PackCum pc) {
-    skinny_gemm_body<MODE, MT, NW, false, RowsPacked>(p.a[0], Blk{blockIdx.x, blockIdx.y, 0u, gridDim.x, gridDim.y}, RowsPacked{p, pc, 0});
-}
-template <int MODE, int MT, int NW, int NT>
-__global__ __launch_bounds__(64 * NW) void skinny_gemm_wide_packed_kernel(const ArgPack<SkinnyArgs> p, const PackCum pc) {
-    skinny_gemm_wide_body<MODE, MT, NW, NT, RowsPacked>(p.a[0], Blk{blockIdx.x, blockIdx.y, 0u, gridDim.x, gridDim.y}, RowsPacked{p, pc, 0});
+    skinny_gemm_wide_body<MODE, MT, NW, NT>(g, Blk{blockIdx.x, blockIdx.y, blockIdx.z % KS, gridDim.x, gy});
 }
 
 bool skinny_gemm_applicable(const SkinnyArgs& g) {
@@ -216,34 +205,6 @@ static void launch_skinny_multi_mt(const ArgPack<SkinnyArgs>& p, int mmax, int K
     //  the same chains for its rows and drops the clamped duplicates)
     if (mmax <= 16) hipLaunchKernelGGL((skinny_gemm_multi_kernel<MODE, 1, NW>), grid, dim3(64 * NW), 0, s, p, KS);
     else hipLaunchKernelGGL((skinny_gemm_multi_kernel<MODE, 2, NW>), grid, dim3(64 * NW), 0, s, p, KS);
-}
-
-// the packed launch: same kernel forms (narrow / wide, waves by K) as the padded one, the grid's row tiles counted over all rows
-template <int MODE>
-static void launch_skinny_packed(const ArgPack<SkinnyArgs>& p, const PackCum& pc, hipStream_t s) {
-    const int k = p.a[0].K, N = p.a[0].N, total = pc.cum[p.n];
-    const int row_tiles = (total + 31) / 32;
-    const int wide_opt = opt(OPT_DECODE_WIDE_GEMM);
-    const bool many = (int64_t)(N / 16) * row_tiles >= 2 * (int64_t)device_cus();
-    if (k == 512 && N % 64 == 0 && total > 16 && wide_opt != 1 && (wide_opt == 2 || (many && (int64_t)(N / 64) * row_tiles * 4 >= 3 * (int64_t)device_cus()))) {
-        hipLaunchKernelGGL((skinny_gemm_wide_packed_kernel<MODE, 2, 4, 4>), dim3((unsigned)(N / 64), (unsigned)row_tiles), dim3(256), 0, s, p, pc);
-        return;
-    }
-    if (k == 1024 && N % 32 == 0 && total > 16 && wide_opt != 1 && (wide_opt == 2 || (many && (int64_t)(N / 32) * row_tiles * 4 >= 3 * (int64_t)device_cus()))) {
-        hipLaunchKernelGGL((skinny_gemm_wide_packed_kernel<MODE, 2, 8, 2>), dim3((unsigned)(N / 32), (unsigned)row_tiles), dim3(512), 0, s, p, pc);
-        return;
-    }
-    const dim3 grid((unsigned)(N / 16), (unsigned)row_tiles);
-    if (k >= 2048 && k % 256 == 0) {
-        if (total <= 16) hipLaunchKernelGGL((skinny_gemm_packed_kernel<MODE, 1, 16>), grid, dim3(1024), 0, s, p, pc);
-        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<MODE, 2, 16>), grid, dim3(1024), 0, s, p, pc);
-    } else if (k >= 1024 && k % 128 == 0) {
-        if (total <= 16) hipLaunchKernelGGL((skinny_gemm_packed_kernel<MODE, 1, 8>), grid, dim3(512), 0, s, p, pc);
-        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<MODE, 2, 8>), grid, dim3(512), 0, s, p, pc);
-    } else {
-        if (total <= 16) hipLaunchKernelGGL((skinny_gemm_packed_kernel<MODE, 1, 4>), grid, dim3(256), 0, s, p, pc);
-        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<MODE, 2, 4>), grid, dim3(256), 0, s, p, pc);
-    }
 }
 
 template <int MODE>
@@ -296,35 +257,6 @@ int launch_skinny_gemm_multi(const SkinnyArgs* g, int G, int mode, hipStream_t s
         work += 2.0 * g[i].M * (double)g[i].N * g[i].K;
     }
     ProfScope prof(PROF_GEMM, work, s);
-    // Packed rows (round 6): the sessions' rows numbered through, 32-row tiles shared by neighbouring sessions -- whenever that needs fewer
-    // tiles than one set of tiles per session (no K split: a split launch's partial tiles and tickets are per session; every problem must
-    // share the strides the row table is built with -- they do, it is one layer's launch -- and hand over one batch item)
-    if (KS == 1 && G >= 2 && !opt(OPT_DECODE_NO_PACK)) {
-        PackCum pc;
-        int padded = 0;
-        bool same = true;
-        pc.cum[0] = 0;
-        for (int i = 0; i < G; ++i) {
-            pc.cum[i + 1] = pc.cum[i] + g[i].M;
-            padded += (g[i].M + 31) / 32;
-            same = same && g[i].lda == g[0].lda && g[i].lda2 == g[0].lda2 && g[i].ldres == g[0].ldres && g[i].ldy == g[0].ldy && g[i].ldt == g[0].ldt &&
-                   g[i].W == g[0].W && g[i].bias == g[0].bias && g[i].alpha == g[0].alpha && g[i].scale_cols == g[0].scale_cols &&
-                   g[i].K1 == g[0].K1 && g[i].k1_cols == g[0].k1_cols && g[i].relu_begin == g[0].relu_begin && g[i].vt_begin == g[0].vt_begin &&
-                   (g[i].A2 != nullptr) == (g[0].A2 != nullptr) && (g[i].res != nullptr) == (g[0].res != nullptr) && (g[i].Yt != nullptr) == (g[0].Yt != nullptr) &&
-                   (!g[i].Yt || g[i].U == g[i].M);
-        }
-        for (int i = G + 1; i <= TAL_GROUP_MAX; ++i) pc.cum[i] = pc.cum[G];
-        if (same && (pc.cum[G] + 31) / 32 < padded) {
-            switch (mode) {
-                case 0: launch_skinny_packed<0>(p, pc, s); break;
-                case 1: launch_skinny_packed<1>(p, pc, s); break;
-                case 2: launch_skinny_packed<2>(p, pc, s); break;
-                default: launch_skinny_packed<3>(p, pc, s); break;
-            }
-            TAL_CHECK_LAUNCH("skinny gemm (multi, packed rows)");
-            return TAL_OK;
-        }
-    }
     switch (mode) {
         case 0: launch_skinny_multi_nw<0>(p, mmax, KS, s); break;
         case 1: launch_skinny_multi_nw<1>(p, mmax, KS, s); break;

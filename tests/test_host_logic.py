@@ -214,3 +214,27 @@ def test_param_epoch_notices_late_submodules_and_survives_pickle(tmp_path):
     ''') % (root, str(p))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_bench_clock_sampler_assigns_samples_to_passes():
+    """bench.ClockSampler.window: samples stamped by the sampler child are averaged over the wall-clock window of a pass; an unavailable
+    sampler says so instead of reporting zeros."""
+    import bench
+    s = bench.ClockSampler.__new__(bench.ClockSampler)
+    s.proc, s.why = None, None
+    s.samples = [(10.0, 1900.0, 1100.0), (10.5, 1800.0, 1300.0), (11.0, None, 1350.0), (12.0, 1700.0, 1400.0)]
+    w = s.window(10.4, 11.5)
+    assert w["samples"] == 1 and w["sclk_mhz"] == 1800.0 and w["sclk_mhz_min"] == 1800.0 and abs(w["power_w"] - 1325.0) < 1e-9
+    assert s.window(20.0, 21.0) == {"sclk_mhz": None, "sclk_mhz_min": None, "power_w": None, "samples": 0}
+    s.why = "ERR no device"
+    assert s.window(10.0, 12.0)["unavailable"] == "ERR no device"
+
+
+def test_the_committed_traffic_figure_describes_this_trees_dense_kernels():
+    """`roofline.traffic` of the bench line is quoted from profiles/rN_pmc_traffic.json only while that file's recorded hash of the
+    dense-kernel sources equals this tree's (bench.load_traffic): an edit of those sources after the round's profile run would leave
+    the driver's line with `traffic: null` -- this test fails first, here."""
+    import bench
+    traffic, source = bench.load_traffic()
+    assert traffic is not None, source
+    assert 0.8e9 < traffic < 3e9

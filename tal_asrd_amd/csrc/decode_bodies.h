@@ -335,8 +335,11 @@ __device__ __forceinline__ void attn_small_body(const AttnArgs& g, const Blk blk
 // -- ticket on a zero-initialised, self-resetting counter -- merges the chunks in chunk order,
 //     M = max m_c,  w_c = exp(m_c - M),  ctx = sum_c w_c o_c / sum_c w_c l_c (+ v bias),
 // and, for the rows >= prob_row0, the per-head probabilities p w_c / L.  Deterministic (fixed merge order).
-constexpr int SPLIT_MAX_CB = 8;      // key blocks per chunk (S <= 960 -> at most 8 chunks of 8 blocks)
-constexpr int SPLIT_NCH = 8;
+#ifndef TAL_SPLIT_NCH          // (ablation builds, scripts/build_ablation.sh: key chunks per (row block, head); measured in round 6:
+#define TAL_SPLIT_NCH 8        //  profiles/r6_cross_attention_chunks.txt)
+#endif
+constexpr int SPLIT_NCH = TAL_SPLIT_NCH;
+constexpr int SPLIT_MAX_CB = (60 + SPLIT_NCH - 1) / SPLIT_NCH;      // key blocks per chunk (S <= 960 = 60 key blocks over SPLIT_NCH chunks)
 __host__ __device__ static inline int split_cb(int S) { const int nblk = (S + 15) / 16; return (nblk + SPLIT_NCH - 1) / SPLIT_NCH; }
 __host__ __device__ static inline size_t split_record_floats(int hd, int cb) { return (size_t)16 * hd + 32 + (size_t)16 * 16 * cb; }
 
